@@ -1,0 +1,155 @@
+"""ctypes front-end of oracle/liboracle.so -- the CPU restatement of the hot path.
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package (bayhunter_amd/) must never import this module.
+
+The call signatures mirror the reference's native entry points:
+  surfdisp96(...)  <-> f2py `BayHunter.surfdisp96_ext.surfdisp96` (surf96_modsw.py:115-117)
+  synrf(...)       <-> Cython `BayHunter.rfmini.synrf`             (rfmini_modrf.py:134-137)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_d = C.POINTER(C.c_double)
+_f = C.POINTER(C.c_float)
+_i32 = C.POINTER(C.c_int32)
+_i64 = C.POINTER(C.c_int64)
+
+LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
+
+
+def build(force=False):
+    """(Re)build liboracle.so with the Makefile next to this file."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("swd_oracle.c", "rf_oracle.c", "like_oracle.c", "oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.bho_surfdisp96.restype = C.c_int
+        L.bho_surfdisp96.argtypes = [_f, _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, _d, _d, _i64]
+        L.bho_dltar1.restype = C.c_double
+        L.bho_dltar1.argtypes = [C.c_double, C.c_double, _f, _f, _f, C.c_int, C.c_int]
+        L.bho_dltar4.restype = C.c_double
+        L.bho_dltar4.argtypes = [C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int]
+        L.bho_gtsolh.restype = C.c_float
+        L.bho_gtsolh.argtypes = [C.c_float, C.c_float]
+        L.bho_swd_batch.restype = None
+        L.bho_swd_batch.argtypes = [C.c_int, C.c_int, _i32, _d, _d, _d, _d, C.c_int, _d, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, _d, _i32, _i64, C.c_int]
+        L.bho_synrf.restype = C.c_int
+        L.bho_synrf.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_int, C.c_int, _d, _d, _d, _d, _d, _d, _d]
+        L.bho_rf_batch.restype = None
+        L.bho_rf_batch.argtypes = [C.c_int, C.c_int, _i32, _d, _d, _d, _d, C.c_double, C.c_double,
+                                   C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _d, C.c_int]
+        L.bho_loglike_dense.restype = C.c_double
+        L.bho_loglike_dense.argtypes = [C.c_int, C.c_int, _d, _d, _d, C.c_double, C.c_double, _d,
+                                        C.c_double]
+        L.bho_rms.restype = C.c_double
+        L.bho_rms.argtypes = [C.c_int, _d, _d]
+        _LIB = L
+    return _LIB
+
+
+def _pd(a):
+    return a.ctypes.data_as(_d)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_f)
+
+
+def surfdisp96(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, cg,
+               return_neval=False):
+    """Same calling convention as the f2py extension: model arrays are cast to float32
+    copies, `t`/`cg` are float64, `cg` is written in place, `err` is returned."""
+    f = [np.ascontiguousarray(np.asarray(x), dtype=np.float32) for x in (thkm, vpm, vsm, rhom)]
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    assert cg.dtype == np.float64 and cg.flags.c_contiguous
+    ne = C.c_int64(0)
+    err = lib().bho_surfdisp96(_pf(f[0]), _pf(f[1]), _pf(f[2]), _pf(f[3]), int(nlayer),
+                               int(iflsph), int(iwave), int(mode), int(igr), int(kmax), _pd(t),
+                               _pd(cg), C.byref(ne))
+    return (err, ne.value) if return_neval else err
+
+
+def dltar(wvno, omega, ifunc, d, a, b, rho):
+    d, a, b, rho = [np.ascontiguousarray(x, dtype=np.float32) for x in (d, a, b, rho)]
+    mmax = d.size
+    llw = 2 if b[0] <= 0.0 else 1
+    if ifunc == 1:
+        return lib().bho_dltar1(wvno, omega, _pf(d), _pf(b), _pf(rho), mmax, llw)
+    return lib().bho_dltar4(wvno, omega, _pf(d), _pf(a), _pf(b), _pf(rho), mmax, llw)
+
+
+def gtsolh(a, b):
+    return float(lib().bho_gtsolh(np.float32(a), np.float32(b)))
+
+
+def swd_batch(nlay, h, vp, vs, rho, periods, iwave, igr, mode=1, flsph=0, nthreads=0):
+    """h, vp, vs, rho: [B, Lmax] float64.  Returns vel[B, K], err[B], total secular evals."""
+    h, vp, vs, rho = [np.ascontiguousarray(x, dtype=np.float64) for x in (h, vp, vs, rho)]
+    B, Lmax = h.shape
+    nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+    periods = np.ascontiguousarray(periods, dtype=np.float64)
+    K = periods.size
+    vel = np.zeros((B, K))
+    err = np.zeros(B, dtype=np.int32)
+    ne = C.c_int64(0)
+    lib().bho_swd_batch(B, Lmax, nlay.ctypes.data_as(_i32), _pd(h), _pd(vp), _pd(vs), _pd(rho), K,
+                        _pd(periods), iwave, igr, mode, flsph, _pd(vel), err.ctypes.data_as(_i32),
+                        C.byref(ne), nthreads)
+    return vel, err, ne.value
+
+
+def synrf(z, vp, vs, rh, qp, qs, p, a, nsamp, fsamp, tshift, nsv, sigma, wave):
+    """Same argument order as the Cython `rfmini.synrf`; returns (None, None, rf)."""
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (z, vp, vs, rh, qp, qs)]
+    nsamp = int(nsamp)
+    waveno = {"P": 0, "SV": 1, "S": 1}[wave] if isinstance(wave, str) else int(wave)
+    rf = np.zeros(nsamp)
+    lib().bho_synrf(nsamp, float(fsamp), float(tshift), float(p), float(a), float(nsv),
+                    float(sigma), waveno, arrs[0].size, *[_pd(x) for x in arrs], _pd(rf))
+    return None, None, rf
+
+
+def rf_batch(nlay, h, vp, vs, rho, p, gauss, nsamp, fsamp, tshift, waveno, nkeep, nthreads=0):
+    h, vp, vs, rho = [np.ascontiguousarray(x, dtype=np.float64) for x in (h, vp, vs, rho)]
+    B, Lmax = h.shape
+    nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+    out = np.zeros((B, nkeep))
+    lib().bho_rf_batch(B, Lmax, nlay.ctypes.data_as(_i32), _pd(h), _pd(vp), _pd(vs), _pd(rho),
+                       float(p), float(gauss), int(nsamp), float(fsamp), float(tshift), int(waveno),
+                       int(nkeep), _pd(out), nthreads)
+    return out
+
+
+def loglike_dense(law, ymod, yobs, corr, sigma, yerr=None, rinv=None, logdet_r=0.0):
+    ymod = np.ascontiguousarray(ymod, dtype=np.float64)
+    yobs = np.ascontiguousarray(yobs, dtype=np.float64)
+    n = ymod.size
+    yerr_p = _pd(np.ascontiguousarray(yerr, dtype=np.float64)) if yerr is not None else None
+    rinv_c = np.ascontiguousarray(rinv, dtype=np.float64) if rinv is not None else None
+    rinv_p = _pd(rinv_c) if rinv_c is not None else None
+    return lib().bho_loglike_dense(law, n, _pd(ymod), _pd(yobs), yerr_p, float(corr), float(sigma),
+                                   rinv_p, float(logdet_r))
+
+
+def rms(ymod, yobs):
+    ymod = np.ascontiguousarray(ymod, dtype=np.float64)
+    yobs = np.ascontiguousarray(yobs, dtype=np.float64)
+    return lib().bho_rms(ymod.size, _pd(ymod), _pd(yobs))

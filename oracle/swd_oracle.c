@@ -1,0 +1,618 @@
+/*
+ * oracle/swd_oracle.c -- CPU restatement of the surf96 dispersion path.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Parity: pinned (tests/test_oracle_swd.py).
+ *
+ * Restates src/extensions/surfdisp96.f of the reference (a Fortran-77 file) in C.  It is
+ * written from the algorithm, with structured control flow, but it honours the things that
+ * decide the bits of the result:
+ *   - which quantities the Fortran keeps in binary32 (implicit typing in the driver,
+ *     gtsolh entirely) and which in binary64 (the search, the secular functions),
+ *   - binary32 literals that get widened (0.005, 1.5, 0.01 in nevill),
+ *   - left-to-right evaluation of every product/sum (no FMA contraction, no re-association;
+ *     compile with -ffp-contract=off),
+ *   - the order of secular-function evaluations in the bracket search and in the hybrid
+ *     bisection / inverse-Neville refinement, including which point is returned.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "oracle.h"
+
+#define NLMAX 100 /* surfdisp96.f:59 */
+#define NPMAX 60  /* surfdisp96.f:61 */
+
+static _Thread_local int64_t g_neval;
+
+static inline int signs_differ(double x, double y) { return (signbit(x) != 0) != (signbit(y) != 0); }
+
+/* ---- Love: SH Thomson-Haskell, half-space up to the surface.  surfdisp96.f:710-769 ---- */
+double bho_dltar1(double wvno, double omega, const float *d, const float *b, const float *rho,
+                  int mmax, int llw)
+{
+    double beta1 = (double)b[mmax - 1];
+    double rho1 = (double)rho[mmax - 1];
+    double xkb = omega / beta1;
+    double wvnop = wvno + xkb;
+    double wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double e1 = rho1 * rb;
+    double e2 = 1.0 / (beta1 * beta1);
+    for (int m = mmax - 2; m >= llw - 1; --m) {
+        double cosq, y, z;
+        beta1 = (double)b[m];
+        rho1 = (double)rho[m];
+        double xmu = rho1 * beta1 * beta1;
+        xkb = omega / beta1;
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        double q = (double)d[m] * rb;
+        if (wvno < xkb) { /* propagating */
+            double sinq = sin(q);
+            y = sinq / rb;
+            z = -rb * sinq;
+            cosq = cos(q);
+        } else if (wvno == xkb) {
+            cosq = 1.0;
+            y = (double)d[m];
+            z = 0.0;
+        } else { /* evanescent, scaled by exp(-q) */
+            double fac = 0.0;
+            if (q < 16.0) fac = exp(-2.0 * q);
+            cosq = (1.0 + fac) * 0.5;
+            double sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb;
+            z = rb * sinq;
+        }
+        double e10 = e1 * cosq + e2 * xmu * z;
+        double e20 = e1 * y / xmu + e2 * cosq;
+        double xnor = fabs(e10);
+        double ynor = fabs(e20);
+        if (ynor > xnor) xnor = ynor;
+        if (xnor < 1.0e-40) xnor = 1.0;
+        e1 = e10 / xnor;
+        e2 = e20 / xnor;
+    }
+    return e1;
+}
+
+/* ---- Rayleigh helpers -------------------------------------------------------------- */
+
+typedef struct {
+    double a0, cpcq, cpy, cpz, cqw, cqx, xy, xz, wy, wz;
+    double w, cosp; /* needed by the water-layer closure only */
+} layer_terms;
+
+/* Eigenfunction products with exponent bookkeeping.  surfdisp96.f:874-991 (`var`). */
+static void layer_products(double p, double q, double ra, double rb, double wvno, double xka,
+                           double xkb, double dpth, layer_terms *o)
+{
+    double cosp, cosq, w, x, y, z;
+    double pex = 0.0, sex = 0.0;
+    if (wvno < xka) {
+        double sinp = sin(p);
+        w = sinp / ra;
+        x = -ra * sinp;
+        cosp = cos(p);
+    } else if (wvno == xka) {
+        cosp = 1.0;
+        w = dpth;
+        x = 0.0;
+    } else {
+        pex = p;
+        double fac = 0.0;
+        if (p < 16.0) fac = exp(-2.0 * p);
+        cosp = (1.0 + fac) * 0.5;
+        double sinp = (1.0 - fac) * 0.5;
+        w = sinp / ra;
+        x = ra * sinp;
+    }
+    if (wvno < xkb) {
+        double sinq = sin(q);
+        y = sinq / rb;
+        z = -rb * sinq;
+        cosq = cos(q);
+    } else if (wvno == xkb) {
+        cosq = 1.0;
+        y = dpth;
+        z = 0.0;
+    } else {
+        sex = q;
+        double fac = 0.0;
+        if (q < 16.0) fac = exp(-2.0 * q);
+        cosq = (1.0 + fac) * 0.5;
+        double sinq = (1.0 - fac) * 0.5;
+        y = sinq / rb;
+        z = rb * sinq;
+    }
+    double exa = pex + sex;
+    double a0 = 0.0;
+    if (exa < 60.0) a0 = exp(-exa);
+    o->a0 = a0;
+    o->cpcq = cosp * cosq;
+    o->cpy = cosp * y;
+    o->cpz = cosp * z;
+    o->cqw = cosq * w;
+    o->cqx = cosq * x;
+    o->xy = x * y;
+    o->xz = x * z;
+    o->wy = w * y;
+    o->wz = w * z;
+    o->w = w;
+    o->cosp = cosp;
+    /* The Fortran goes on to rescale cosq, y, z by exp(sex-pex) (:985-990); those values
+     * are dead in the compound-matrix formulation (dnka only takes the products above), so
+     * the exp() there has no observable effect and is not restated. */
+}
+
+/* Dunkin 5x5 compound matrix, surfdisp96.f:1024-1068 (`dnka`).  ca[j][i] == ca(j+1,i+1). */
+static void compound_matrix(double ca[5][5], double wvno2, double gam, double gammk, double rho,
+                            const layer_terms *v)
+{
+    const double two = 2.0;
+    double gamm1 = gam - 1.0;
+    double twgm1 = gam + gamm1;
+    double gmgmk = gam * gammk;
+    double gmgm1 = gam * gamm1;
+    double gm1sq = gamm1 * gamm1;
+    double rho2 = rho * rho;
+    double a0pq = v->a0 - v->cpcq;
+    ca[0][0] = v->cpcq - two * gmgm1 * a0pq - gmgmk * v->xz - wvno2 * gm1sq * v->wy;
+    ca[0][1] = (wvno2 * v->cpy - v->cqx) / rho;
+    ca[0][2] = -(twgm1 * a0pq + gammk * v->xz + wvno2 * gamm1 * v->wy) / rho;
+    ca[0][3] = (v->cpz - wvno2 * v->cqw) / rho;
+    ca[0][4] = -(two * wvno2 * a0pq + v->xz + wvno2 * wvno2 * v->wy) / rho2;
+    ca[1][0] = (gmgmk * v->cpz - gm1sq * v->cqw) * rho;
+    ca[1][1] = v->cpcq;
+    ca[1][2] = gammk * v->cpz - gamm1 * v->cqw;
+    ca[1][3] = -v->wz;
+    ca[1][4] = ca[0][3];
+    ca[3][0] = (gm1sq * v->cpy - gmgmk * v->cqx) * rho;
+    ca[3][1] = -v->xy;
+    ca[3][2] = gamm1 * v->cpy - gammk * v->cqx;
+    ca[3][3] = ca[1][1];
+    ca[3][4] = ca[0][1];
+    ca[4][0] = -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * v->xz + gm1sq * gm1sq * v->wy) * rho2;
+    ca[4][1] = ca[3][0];
+    ca[4][2] = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * v->xz + gamm1 * gm1sq * v->wy) * rho;
+    ca[4][3] = ca[1][0];
+    ca[4][4] = ca[0][0];
+    double t = -two * wvno2;
+    ca[2][0] = t * ca[4][2];
+    ca[2][1] = t * ca[3][2];
+    ca[2][2] = v->a0 + two * (v->cpcq - ca[0][0]);
+    ca[2][3] = t * ca[1][2];
+    ca[2][4] = t * ca[0][2];
+}
+
+/* ---- Rayleigh: Dunkin compound-matrix secular function.  surfdisp96.f:773-871 ---------- */
+double bho_dltar4(double wvno, double omga, const float *d, const float *a, const float *b,
+                  const float *rho, int mmax, int llw)
+{
+    double e[5], ee[5], ca[5][5];
+    layer_terms v;
+    double omega = omga;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    double wvno2 = wvno * wvno;
+    double xka = omega / (double)a[mmax - 1];
+    double xkb = omega / (double)b[mmax - 1];
+    double wvnop = wvno + xka;
+    double wvnom = fabs(wvno - xka);
+    double ra = sqrt(wvnop * wvnom);
+    wvnop = wvno + xkb;
+    wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double t = (double)b[mmax - 1] / omega;
+    /* E vector of the bottom half-space, :800-808 */
+    double gammk = 2.0 * t * t;
+    double gam = gammk * wvno2;
+    double gamm1 = gam - 1.0;
+    double rho1 = (double)rho[mmax - 1];
+    e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+    e[1] = -rho1 * ra;
+    e[2] = rho1 * (gamm1 - gammk * ra * rb);
+    e[3] = rho1 * rb;
+    e[4] = wvno2 - ra * rb;
+    for (int m = mmax - 2; m >= llw - 1; --m) {
+        xka = omega / (double)a[m];
+        xkb = omega / (double)b[m];
+        t = (double)b[m] / omega;
+        gammk = 2.0 * t * t;
+        gam = gammk * wvno2;
+        wvnop = wvno + xka;
+        wvnom = fabs(wvno - xka);
+        ra = sqrt(wvnop * wvnom);
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        double dpth = (double)d[m];
+        rho1 = (double)rho[m];
+        double p = ra * dpth;
+        double q = rb * dpth;
+        layer_products(p, q, ra, rb, wvno, xka, xkb, dpth, &v);
+        compound_matrix(ca, wvno2, gam, gammk, rho1, &v);
+        for (int i = 0; i < 5; ++i) {
+            double cr = 0.0;
+            for (int j = 0; j < 5; ++j) cr = cr + e[j] * ca[j][i];
+            ee[i] = cr;
+        }
+        /* normc, :995-1020: max-norm rescale (the log of the norm is computed there and
+         * never used). */
+        double t1 = 0.0;
+        for (int i = 0; i < 5; ++i)
+            if (fabs(ee[i]) > t1) t1 = fabs(ee[i]);
+        if (t1 < 1.0e-40) t1 = 1.0;
+        for (int i = 0; i < 5; ++i) e[i] = ee[i] / t1;
+    }
+    if (llw != 1) { /* water layer on top, :850-866 (unreachable from BayHunter: vs > 0) */
+        xka = omega / (double)a[0];
+        wvnop = wvno + xka;
+        wvnom = fabs(wvno - xka);
+        ra = sqrt(wvnop * wvnom);
+        double dpth = (double)d[0];
+        rho1 = (double)rho[0];
+        double p = ra * dpth;
+        double znul = 1.0e-5;
+        layer_products(p, znul, ra, znul, wvno, xka, znul, dpth, &v);
+        double w0 = -rho1 * v.w;
+        return v.cosp * e[0] + w0 * e[1];
+    }
+    return e[0];
+}
+
+typedef struct {
+    const float *d, *a, *b, *rho;
+    int mmax, llw, ifunc;
+} medium;
+
+static inline double secular(const medium *md, double wvno, double omega)
+{
+    ++g_neval;
+    if (md->ifunc == 1) return bho_dltar1(wvno, omega, md->d, md->b, md->rho, md->mmax, md->llw);
+    return bho_dltar4(wvno, omega, md->d, md->a, md->b, md->rho, md->mmax, md->llw);
+}
+
+/* ---- half-space Rayleigh velocity, 5 Newton steps, all binary32.  surfdisp96.f:367-388 -- */
+float bho_gtsolh(float a, float b)
+{
+    float c = 0.95f * b;
+    for (int i = 0; i < 5; ++i) {
+        float gamma = b / a;
+        float kappa = c / b;
+        float k2 = kappa * kappa;
+        float gk = gamma * kappa;
+        float gk2 = gk * gk;
+        float fac1 = sqrtf(1.0f - gk2);
+        float fac2 = sqrtf(1.0f - k2);
+        float tk = 2.0f - k2;
+        float fr = tk * tk - 4.0f * fac1 * fac2;
+        float frp = -4.0f * (2.0f - k2) * kappa + 4.0f * fac2 * gamma * gamma * kappa / fac1 +
+                    4.0f * fac1 * kappa / fac2;
+        frp = frp / b;
+        c = c - fr / frp;
+    }
+    return c;
+}
+
+/* ---- root refinement: hybrid bisection / inverse Neville.  surfdisp96.f:557-686 -------- */
+static double refine_root(const medium *md, double t, double c1, double c2, double del1, double del2)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    const double omega = twopi / t;
+    const double pct = (double)0.01f; /* `0.01*ss1` with a default-real literal, :623-626 */
+    double x[20], y[20];
+    int m = 1;
+    int nev = 1; /* 0 force halving, 1 Neville allowed, 2 Neville running */
+    double c3 = 0.5 * (c1 + c2);
+    double del3 = secular(md, omega / c3, omega);
+    for (int nctrl = 2; nctrl < 100; ++nctrl) {
+        if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) { /* estimate left the bracket */
+            nev = 0;
+            c3 = 0.5 * (c1 + c2);
+            del3 = secular(md, omega / c3, omega);
+        }
+        double s13 = del1 - del3;
+        double s32 = del3 - del2;
+        if (signs_differ(del3, del1)) {
+            c2 = c3;
+            del2 = del3;
+        } else {
+            c1 = c3;
+            del1 = del3;
+        }
+        if (fabs(c1 - c2) <= 1.0e-6 * c1) break;
+        if (signs_differ(s13, s32)) nev = 0;
+        double ss1 = fabs(del1), s1 = pct * ss1;
+        double ss2 = fabs(del2), s2 = pct * ss2;
+        int halve = (s1 > ss2 || s2 > ss1 || nev == 0);
+        if (!halve) {
+            if (nev == 2) {
+                x[m] = c3;
+                y[m] = del3;
+            } else {
+                x[0] = c1;
+                y[0] = del1;
+                x[1] = c2;
+                y[1] = del2;
+                m = 1;
+            }
+            /* solve x(y=0) by Neville's scheme on the swapped table */
+            for (int kk = 1; kk <= m; ++kk) {
+                int j = m - kk; /* 0-based: Fortran j = m-kk+1 */
+                double denom = y[m] - y[j];
+                if (fabs(denom) < 1.0e-10 * fabs(y[m])) {
+                    halve = 1;
+                    break;
+                }
+                x[j] = (-y[j] * x[j + 1] + y[m] * x[j]) / denom;
+            }
+            if (!halve) {
+                c3 = x[0];
+                del3 = secular(md, omega / c3, omega);
+                nev = 2;
+                m = m + 1;
+                if (m > 10) m = 10;
+            }
+        }
+        if (halve) {
+            c3 = 0.5 * (c1 + c2);
+            del3 = secular(md, omega / c3, omega);
+            nev = 1;
+            m = 1;
+        }
+    }
+    return c3; /* the last point evaluated, not a bracket end (:672) */
+}
+
+/* ---- bracket search.  surfdisp96.f:390-482 (`getsol`).  Returns 1 ok / -1 failed. ------- */
+static int bracket_and_refine(const medium *md, double t1, double *c1io, double clow, double dc,
+                              double cm, double betmx, int ifirst, double *del1st)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    double c1 = *c1io, c2;
+    double omega = twopi / t1;
+    double del1 = secular(md, omega / c1, omega);
+    if (ifirst == 1) *del1st = del1;
+    int idir = 1;
+    if (ifirst != 1 && signs_differ(*del1st, del1)) idir = -1;
+    for (;;) {
+        c2 = (idir > 0) ? c1 + dc : c1 - dc;
+        if (c2 <= clow) { /* never search below clow: turn round, restart from clow */
+            idir = 1;
+            c1 = clow;
+            continue;
+        }
+        omega = twopi / t1;
+        double del2 = secular(md, omega / c2, omega);
+        if (signs_differ(del1, del2)) {
+            double cn = refine_root(md, t1, c1, c2, del1, del2);
+            *c1io = cn;
+            if (cn > betmx) return -1;
+            return 1;
+        }
+        c1 = c2;
+        del1 = del2;
+        if (c1 < cm) break;
+        if (c1 >= betmx + dc) break;
+    }
+    *c1io = c1;
+    return -1;
+}
+
+/* ---- earth flattening.  surfdisp96.f:486-553 (`sphere`) ------------------------------- */
+typedef struct {
+    float rtp[NLMAX], dtp[NLMAX], btp[NLMAX];
+    float dhalf;
+} sphere_state;
+
+static float powi_f32(float a, int b) /* integer power the way compiler-rt's __powisf2 does it */
+{
+    int recip = b < 0;
+    float r = 1.0f;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+static void sphere_init(float *d, float *a, float *b, const float *rho, int mmax, sphere_state *s)
+{
+    const double ar = 6370.0;
+    double dr = 0.0, r0 = ar;
+    d[mmax - 1] = 1.0f;
+    for (int i = 0; i < mmax; ++i) {
+        s->dtp[i] = d[i];
+        s->rtp[i] = rho[i];
+    }
+    for (int i = 0; i < mmax; ++i) {
+        dr = dr + (double)d[i];
+        double r1 = ar - dr;
+        double z0 = ar * log(ar / r0);
+        double z1 = ar * log(ar / r1);
+        d[i] = (float)(z1 - z0);
+        double tmp = (ar + ar) / (r0 + r1); /* layer mid-point */
+        a[i] = (float)((double)a[i] * tmp);
+        b[i] = (float)((double)b[i] * tmp);
+        s->btp[i] = (float)tmp;
+        r0 = r1;
+    }
+    s->dhalf = d[mmax - 1];
+    d[mmax - 1] = 0.0f;
+}
+
+static void sphere_density(int ifunc, float *d, float *rho, int mmax, const sphere_state *s)
+{
+    d[mmax - 1] = s->dhalf;
+    for (int i = 0; i < mmax; ++i) {
+        if (ifunc == 1)
+            rho[i] = s->rtp[i] * powi_f32(s->btp[i], -5);
+        else
+            rho[i] = s->rtp[i] * powf(s->btp[i], -2.275f);
+    }
+    d[mmax - 1] = 0.0f;
+}
+
+/* ---- driver.  surfdisp96.f:55-360 ---------------------------------------------------- */
+int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                   int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                   const double *t, double *cg, int64_t *neval)
+{
+    float d[NLMAX], a[NLMAX], b[NLMAX], rho[NLMAX];
+    double c[NPMAX], cb[NPMAX];
+    sphere_state sph;
+    int err = 0;
+    const int mmax = nlayer;
+    g_neval = 0;
+    for (int i = 0; i < mmax; ++i) {
+        b[i] = vsm[i];
+        a[i] = vpm[i];
+        d[i] = thkm[i];
+        rho[i] = rhom[i];
+    }
+    const int ifunc = (iwave == 1) ? 1 : 2;
+    const float ddc = 0.005f, sone = 1.5f, h = 0.005f;
+    const int llw = (b[0] <= 0.0f) ? 2 : 1;
+    const double one = 1.0e-2;
+    if (iflsph == 1) sphere_init(d, a, b, rho, mmax, &sph);
+
+    /* extremal velocities, :145-156 (binary32 compares) */
+    float betmx = -1.e20f, betmn = 1.e20f;
+    int jmn = 0, jsol = 1;
+    for (int i = 0; i < mmax; ++i) {
+        if (b[i] > 0.01f && b[i] < betmn) {
+            betmn = b[i];
+            jmn = i;
+            jsol = 1;
+        } else if (b[i] <= 0.01f && a[i] < betmn) {
+            betmn = a[i];
+            jmn = i;
+            jsol = 0;
+        }
+        if (b[i] > betmx) betmx = b[i];
+    }
+    if (iflsph == 1) sphere_density(ifunc, d, rho, mmax, &sph);
+
+    medium md = {d, a, b, rho, mmax, llw, ifunc};
+    const double onea = (double)sone;
+    /* start value: half-space Rayleigh velocity of the slowest layer, backed off twice */
+    float cc1 = (jsol == 0) ? betmn : bho_gtsolh(a[jmn], b[jmn]);
+    cc1 = 0.95f * cc1;
+    cc1 = 0.90f * cc1;
+    const double cc = (double)cc1;
+    const double dc = fabs((double)ddc);
+    double c1 = cc;
+    const double cm = cc;
+    for (int i = 0; i < kmax; ++i) {
+        cb[i] = 0.0;
+        c[i] = 0.0;
+    }
+    double del1st = 0.0; /* Fortran SAVE variable; always (re)set when ifirst == 1 */
+    int ift = 999;       /* 1-based index of the first period a previous mode failed at */
+    for (int iq = 1; iq <= mode; ++iq) {
+        int k;
+        int failed = 0;
+        for (k = 1; k <= kmax; ++k) {
+            if (k >= ift) {
+                failed = 1;
+                break;
+            }
+            double t1 = t[k - 1];
+            float t1a, t1b = 0.0f;
+            if (igr > 0) {
+                t1a = (float)(t1 / (double)(1.0f + h));
+                t1b = (float)(t1 / (double)(1.0f - h));
+                t1 = (double)t1a;
+            } else {
+                t1a = (float)t1;
+            }
+            double clow;
+            int ifirst;
+            if (k == 1 && iq == 1) {
+                c1 = cc;
+                clow = cc;
+                ifirst = 1;
+            } else if (k == 1 && iq > 1) {
+                c1 = c[0] + one * dc;
+                clow = c1;
+                ifirst = 1;
+            } else if (k > 1 && iq > 1) {
+                ifirst = 0;
+                clow = c[k - 1] + one * dc;
+                c1 = c[k - 2];
+                if (c1 < clow) c1 = clow;
+            } else {
+                ifirst = 0;
+                c1 = c[k - 2] - onea * dc;
+                clow = cm;
+            }
+            int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st);
+            if (iret == -1) {
+                failed = 1;
+                break;
+            }
+            c[k - 1] = c1;
+            if (igr > 0) { /* second root at the slightly longer period */
+                t1 = (double)t1b;
+                clow = cb[k - 1] + one * dc;
+                c1 = c1 - onea * dc;
+                iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, 0, &del1st);
+                if (iret == -1) c1 = c[k - 1];
+                cb[k - 1] = c1;
+            } else {
+                c1 = 0.0;
+            }
+            float cc0 = (float)c[k - 1];
+            float cc1s = (float)c1;
+            if (igr == 0) {
+                cg[k - 1] = (double)cc0;
+            } else { /* all binary32, :305 */
+                float gvel = (1.0f / t1a - 1.0f / t1b) / (1.0f / (t1a * cc0) - 1.0f / (t1b * cc1s));
+                cg[k - 1] = (double)gvel;
+            }
+        }
+        if (failed) {
+            if (iq == 1) err = 1;
+            ift = k;
+            for (int i = k; i <= kmax; ++i) cg[i - 1] = 0.0;
+        }
+    }
+    if (neval) *neval = g_neval;
+    return err;
+}
+
+void bho_swd_batch(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                   const double *vs, const double *rho, int K, const double *periods,
+                   int iwave, int igr, int mode, int flsph, double *vel, int32_t *err,
+                   int64_t *neval_total, int nthreads)
+{
+    int64_t total = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : total)
+    for (int ib = 0; ib < B; ++ib) {
+        float fh[NLMAX], fvp[NLMAX], fvs[NLMAX], frho[NLMAX];
+        double cg[NPMAX];
+        int n = nlay[ib];
+        for (int i = 0; i < n; ++i) {
+            fh[i] = (float)h[(size_t)ib * Lmax + i];
+            fvp[i] = (float)vp[(size_t)ib * Lmax + i];
+            fvs[i] = (float)vs[(size_t)ib * Lmax + i];
+            frho[i] = (float)rho[(size_t)ib * Lmax + i];
+        }
+        int64_t ne = 0;
+        int e = bho_surfdisp96(fh, fvp, fvs, frho, n, flsph, iwave, mode, igr, K, periods, cg, &ne);
+        total += ne;
+        err[ib] = e;
+        for (int k = 0; k < K; ++k) vel[(size_t)ib * K + k] = cg[k];
+    }
+    if (neval_total) *neval_total = total;
+}
