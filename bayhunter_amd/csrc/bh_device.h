@@ -1,0 +1,63 @@
+// bayhunter_amd/csrc/bh_device.h -- shared declarations of the gfx950 kernels.
+//
+// Everything in csrc/ is written for CDNA4 (MI355X, wave64) only and is compiled with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// -ffp-contract=off matters: the reference's Fortran/C++ round every product and sum
+// separately (x86-64 baseline, no FMA); the root search of surf96 branches on signs and on
+// 1e-6-relative comparisons of those values, so the kernels keep the same rounding points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define BH_WAVE 64
+
+struct SwdKernelArgs {
+    int B, Lmax, K, igr;
+    const int32_t *nlay;
+    const double *h, *vp, *vs, *rho;
+    ptrdiff_t sl, sb; // element strides: layer, model
+    const double *periods;
+    double *vel;      // [B][ldv] (+ column offset already applied)
+    int ldv;          // row stride of vel in elements
+    int32_t *err;     // [B]
+    unsigned long long *neval; // optional global counter of secular evaluations (may be null)
+};
+
+struct RfModelConsts; // rf_kernel.hip
+
+void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
+size_t bh_swd_lds_bytes(int Lmax, int K);
+
+struct RfKernelArgs {
+    int B, Lmax, nsamp, nkeep, waveno;
+    const int32_t *nlay;
+    const double *h, *vp, *vs, *rho, *qp, *qs; // qp/qs may be null -> 500/225
+    ptrdiff_t sl, sb;
+    double p_s_per_deg, gauss, fsamp, tshift, nsv;
+    double *coef;  // workspace [B][bh_rf_coef_doubles(Lmax)]
+    double *spec;  // workspace [B][nsamp/2+1][2]
+    double *rf;    // [B][ldr]
+    int ldr;
+};
+size_t bh_rf_coef_doubles(int Lmax);
+void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream);
+
+struct LikeTargetDev {
+    int law, n, off; // off: column offset of this target's samples inside a ymod row
+    const double *yobs, *yerr_scaled, *rinv; // device; yerr_scaled = yerr/min(yerr) (law 1)
+    double logdet_extra;                     // ln prod(scaled err) (law 1) or ln|R| (law 3)
+};
+struct LikeKernelArgs {
+    int B, nt, ldy;
+    const double *ymod; // [B][ldy]
+    const int32_t *err_t; // [nt][B] per-target forward-model failure flags
+    const double *noise; // [B][2*nt]
+    LikeTargetDev t[8];
+    double *logL;    // [B]
+    double *misfits; // [B][nt+1]
+    int32_t *err;    // [B]
+};
+void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream);
+
+void bh_launch_probe(int op, int n, const double *in, double *out, hipStream_t stream);

@@ -1,0 +1,590 @@
+// bayhunter_amd/csrc/bh_engine.hip -- host side of the C ABI declared in include/bh_engine.h.
+//
+// Owns the device workspace, the stream and the registered target data of one GPU, stages
+// host buffers when the caller asks for memspace = BH_HOST and launches the gfx950 kernels of
+// swd_kernel.hip / rf_kernel.hip / like_kernel.hip.  There is no CPU code path in here: if no
+// HIP device is usable, bh_engine_create fails.
+#include "../../include/bh_engine.h"
+#include "bh_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TargetHost {
+    bh_target_desc d{};
+    int off = 0; // column offset in a ymod row
+    DevBuf x, yobs, yerr_scaled, rinv;
+    double logdet_extra = 0.0;
+};
+
+} // namespace
+
+struct bh_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // staging / workspace
+    DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, spec, ymod, noise, logL,
+        misfits, err_t, probe_in, probe_out, counter;
+    // targets
+    int nt = 0;
+    int ldy = 0;
+    std::vector<TargetHost> targets;
+    // instrumentation
+    bool timing = false, counting = false;
+    hipEvent_t ev[8] = {};
+    bool ev_used[4] = {};
+    bool have_events = false;
+    uint64_t last_neval = 0;
+    bool neval_pending = false;
+};
+
+namespace {
+
+int fail(bh_engine *e, int code, const char *what, hipError_t he = hipSuccess)
+{
+    if (e) {
+        e->err = what;
+        if (he != hipSuccess) {
+            e->err += ": ";
+            e->err += hipGetErrorString(he);
+        }
+    }
+    return code;
+}
+
+#define HIPCHK(e, call)                                                  \
+    do {                                                                 \
+        hipError_t _he = (call);                                         \
+        if (_he != hipSuccess) return fail((e), BH_EHIP, #call, _he);    \
+    } while (0)
+
+int ensure(bh_engine *e, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return BH_OK;
+    if (b.p) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t he = hipMalloc(&b.p, want);
+    if (he != hipSuccess) return fail(e, BH_ENOMEM, "hipMalloc", he);
+    b.cap = want;
+    return BH_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// number of elements spanned by a strided [Lmax][B] view (strides must be positive)
+size_t span_elems(int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb)
+{
+    return (size_t)((ptrdiff_t)(Lmax - 1) * sl + (ptrdiff_t)(B - 1) * sb + 1);
+}
+
+__global__ void rho_from_vp_kernel(size_t n, const double *vp, double *rho)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rho[i] = vp[i] * 0.32 + 0.77; // Targets.py:319
+}
+
+int check_models(bh_engine *e, int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb)
+{
+    if (!e) return BH_EINVAL;
+    if (B < 0 || Lmax < 1 || Lmax > BH_MAX_LAYERS) return fail(e, BH_EINVAL, "bad B or Lmax (1..100)");
+    if (sl <= 0 || sb <= 0) return fail(e, BH_EINVAL, "strides must be positive");
+    return BH_OK;
+}
+
+struct Staged {
+    const int32_t *nlay;
+    const double *h, *vp, *vs, *rho, *qp, *qs;
+};
+
+// Copy the model arrays of a BH_HOST call into the engine's device buffers.
+int stage_models(bh_engine *e, int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb, const int32_t *nlay,
+                 const double *h, const double *vp, const double *vs, const double *rho,
+                 const double *qp, const double *qs, Staged &s)
+{
+    const size_t nel = span_elems(B, Lmax, sl, sb), bytes = nel * sizeof(double);
+    int rc;
+    if ((rc = ensure(e, e->nlay, (size_t)B * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(e, e->h, bytes))) return rc;
+    if ((rc = ensure(e, e->vp, bytes))) return rc;
+    if ((rc = ensure(e, e->vs, bytes))) return rc;
+    if ((rc = ensure(e, e->rho, bytes))) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->nlay.p, nlay, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h.p, h, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->vp.p, vp, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->vs.p, vs, bytes, hipMemcpyHostToDevice, e->stream));
+    if (rho) HIPCHK(e, hipMemcpyAsync(e->rho.p, rho, bytes, hipMemcpyHostToDevice, e->stream));
+    s.nlay = (const int32_t *)e->nlay.p;
+    s.h = (const double *)e->h.p;
+    s.vp = (const double *)e->vp.p;
+    s.vs = (const double *)e->vs.p;
+    s.rho = rho ? (const double *)e->rho.p : nullptr;
+    s.qp = s.qs = nullptr;
+    if (qp) {
+        if ((rc = ensure(e, e->qp, bytes))) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->qp.p, qp, bytes, hipMemcpyHostToDevice, e->stream));
+        s.qp = (const double *)e->qp.p;
+    }
+    if (qs) {
+        if ((rc = ensure(e, e->qs, bytes))) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->qs.p, qs, bytes, hipMemcpyHostToDevice, e->stream));
+        s.qs = (const double *)e->qs.p;
+    }
+    return BH_OK;
+}
+
+void ev_begin(bh_engine *e, int fam, hipStream_t st)
+{
+    if (!e->timing) return;
+    if (!e->ev_used[fam]) { // first launch of this family in the call
+        (void)hipEventRecord(e->ev[2 * fam], st);
+        e->ev_used[fam] = true;
+    }
+}
+void ev_end(bh_engine *e, int fam, hipStream_t st)
+{
+    if (!e->timing) return;
+    (void)hipEventRecord(e->ev[2 * fam + 1], st);
+}
+void call_begin(bh_engine *e, hipStream_t st)
+{
+    for (bool &u : e->ev_used) u = false;
+    e->have_events = false;
+    if (e->timing) {
+        (void)hipEventRecord(e->ev[6], st);
+        e->ev_used[3] = true;
+    }
+    e->neval_pending = false;
+}
+void call_end(bh_engine *e, hipStream_t st)
+{
+    if (e->timing) {
+        (void)hipEventRecord(e->ev[7], st);
+        e->have_events = true;
+    }
+}
+
+int swd_supported(bh_engine *e, int K, int iwave, int mode, int flsph)
+{
+    if (K < 0 || K > BH_MAX_PERIODS) return fail(e, BH_EINVAL, "K must be 0..60 (surfdisp96.f:61-62)");
+    if (iwave != BH_WAVE_LOVE && iwave != BH_WAVE_RAYLEIGH) return fail(e, BH_EINVAL, "iwave must be 1 (Love) or 2 (Rayleigh)");
+    if (mode != 1) return fail(e, BH_EUNSUPPORTED, "only the fundamental mode (mode=1) is implemented on the device");
+    if (flsph != 0) return fail(e, BH_EUNSUPPORTED, "earth-flattening (flsph=1) is not implemented on the device");
+    return BH_OK;
+}
+
+int launch_swd(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
+               ptrdiff_t sb, int K, const double *periods_dev, int iwave, int igr, double *vel,
+               int ldv, int32_t *err)
+{
+    if (B == 0 || K == 0) return BH_OK;
+    SwdKernelArgs a{};
+    a.B = B; a.Lmax = Lmax; a.K = K; a.igr = igr;
+    a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho;
+    a.sl = sl; a.sb = sb; a.periods = periods_dev; a.vel = vel; a.ldv = ldv; a.err = err;
+    a.neval = nullptr;
+    if (e->counting) {
+        int rc = ensure(e, e->counter, sizeof(unsigned long long));
+        if (rc) return rc;
+        if (!e->neval_pending) {
+            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned long long), st));
+            e->neval_pending = true;
+        }
+        a.neval = (unsigned long long *)e->counter.p;
+    }
+    if (bh_swd_lds_bytes(Lmax, K) > 160 * 1024) return fail(e, BH_EINVAL, "model too deep for LDS");
+    ev_begin(e, 0, st);
+    bh_launch_swd(a, iwave, st);
+    ev_end(e, 0, st);
+    HIPCHK(e, hipGetLastError());
+    return BH_OK;
+}
+
+int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
+              ptrdiff_t sb, double p, double gauss, int nsamp, double fsamp, double tshift,
+              double nsv, int waveno, int nkeep, double *rf, int ldr)
+{
+    if (B == 0) return BH_OK;
+    int rc;
+    if ((rc = ensure(e, e->coef, (size_t)B * bh_rf_coef_doubles(Lmax) * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->spec, (size_t)B * (nsamp / 2 + 1) * 2 * sizeof(double)))) return rc;
+    RfKernelArgs a{};
+    a.B = B; a.Lmax = Lmax; a.nsamp = nsamp; a.nkeep = nkeep; a.waveno = waveno;
+    a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.qp = m.qp; a.qs = m.qs;
+    a.sl = sl; a.sb = sb;
+    a.p_s_per_deg = p; a.gauss = gauss; a.fsamp = fsamp; a.tshift = tshift; a.nsv = nsv;
+    a.coef = (double *)e->coef.p; a.spec = (double *)e->spec.p; a.rf = rf; a.ldr = ldr;
+    ev_begin(e, 1, st);
+    bh_launch_rf(a, st);
+    ev_end(e, 1, st);
+    HIPCHK(e, hipGetLastError());
+    return BH_OK;
+}
+
+int rf_args_ok(bh_engine *e, int nsamp, int nkeep, double gauss, double fsamp, int waveno)
+{
+    if (nsamp < 4 || (nsamp & (nsamp - 1)) != 0 || nsamp > 4096)
+        return fail(e, BH_EINVAL, "nsamp must be a power of two in 4..4096");
+    if (nkeep < 0 || nkeep > nsamp) return fail(e, BH_EINVAL, "nkeep must be 0..nsamp");
+    if (!(gauss > 0.0) || !(fsamp > 0.0)) return fail(e, BH_EINVAL, "gauss and fsamp must be > 0");
+    if (waveno != BH_RF_P && waveno != BH_RF_SV) return fail(e, BH_EINVAL, "waveno must be 0 (P) or 1 (SV)");
+    return BH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int bh_abi_version(void) { return BH_ABI_VERSION; }
+
+int bh_engine_create(int device, bh_engine **out)
+{
+    if (!out) return BH_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BH_EHIP;
+    if (device < 0 || device >= ndev) return BH_EINVAL;
+    bh_engine *e = new (std::nothrow) bh_engine;
+    if (!e) return BH_ENOMEM;
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess) {
+        delete e;
+        return BH_EHIP;
+    }
+    for (auto &ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            delete e;
+            return BH_EHIP;
+        }
+    *out = e;
+    return BH_OK;
+}
+
+void bh_engine_destroy(bh_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
+                      &e->errb, &e->rf, &e->coef, &e->spec, &e->ymod, &e->noise, &e->logL, &e->misfits,
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter})
+        release(*b);
+    for (auto &t : e->targets) {
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv);
+    }
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *bh_engine_last_error(const bh_engine *e) { return e ? e->err.c_str() : "null engine"; }
+void *bh_engine_stream(bh_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int bh_engine_synchronize(bh_engine *e)
+{
+    if (!e) return BH_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return BH_OK;
+}
+
+int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting)
+{
+    if (!e) return BH_EINVAL;
+    e->timing = timing != 0;
+    e->counting = counting != 0;
+    return BH_OK;
+}
+
+int bh_last_timing(bh_engine *e, double *total_ms, double family_ms[3])
+{
+    if (!e) return BH_EINVAL;
+    if (!e->have_events) return fail(e, BH_EINVAL, "no timed call (enable timing first)");
+    HIPCHK(e, hipEventSynchronize(e->ev[7]));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev[6], e->ev[7]));
+    if (total_ms) *total_ms = ms;
+    for (int f = 0; f < 3; ++f) {
+        float fm = 0.f;
+        if (e->ev_used[f]) HIPCHK(e, hipEventElapsedTime(&fm, e->ev[2 * f], e->ev[2 * f + 1]));
+        if (family_ms) family_ms[f] = fm;
+    }
+    return BH_OK;
+}
+
+int bh_last_neval(bh_engine *e, uint64_t *neval)
+{
+    if (!e || !neval) return BH_EINVAL;
+    if (e->neval_pending) {
+        unsigned long long v = 0;
+        HIPCHK(e, hipMemcpy(&v, e->counter.p, sizeof(v), hipMemcpyDeviceToHost));
+        e->last_neval = v;
+        e->neval_pending = false;
+    }
+    *neval = e->last_neval;
+    return BH_OK;
+}
+
+int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, const int32_t *nlay,
+                 const double *h, const double *vp, const double *vs, const double *rho,
+                 ptrdiff_t sl, ptrdiff_t sb, int K, const double *periods, int iwave, int igr,
+                 int mode, int flsph, double *vel, int32_t *err)
+{
+    int rc;
+    if ((rc = check_models(e, B, Lmax, sl, sb))) return rc;
+    if ((rc = swd_supported(e, K, iwave, mode, flsph))) return rc;
+    if (!nlay || !h || !vp || !vs || !rho || !periods || !vel || !err) return fail(e, BH_EINVAL, "null argument");
+    if (B == 0) return BH_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (memspace == BH_DEVICE) {
+        hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+        Staged m{nlay, h, vp, vs, rho, nullptr, nullptr};
+        call_begin(e, st);
+        rc = launch_swd(e, st, B, Lmax, m, sl, sb, K, periods, iwave, igr, vel, K, err);
+        call_end(e, st);
+        return rc;
+    }
+    hipStream_t st = e->stream;
+    Staged m{};
+    if ((rc = stage_models(e, B, Lmax, sl, sb, nlay, h, vp, vs, rho, nullptr, nullptr, m))) return rc;
+    if ((rc = ensure(e, e->periods, (size_t)BH_MAX_PERIODS * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->vel, (size_t)B * K * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->errb, (size_t)B * sizeof(int32_t)))) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->periods.p, periods, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
+    call_begin(e, st);
+    rc = launch_swd(e, st, B, Lmax, m, sl, sb, K, (const double *)e->periods.p, iwave, igr,
+                    (double *)e->vel.p, K, (int32_t *)e->errb.p);
+    call_end(e, st);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(vel, e->vel.p, (size_t)B * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(err, e->errb.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return BH_OK;
+}
+
+int bh_rf_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, const int32_t *nlay,
+                const double *h, const double *vp, const double *vs, const double *rho,
+                const double *qp, const double *qs, ptrdiff_t sl, ptrdiff_t sb, double p,
+                double gauss, int nsamp, double fsamp, double tshift, double nsv, int waveno,
+                int nkeep, double *rf)
+{
+    int rc;
+    if ((rc = check_models(e, B, Lmax, sl, sb))) return rc;
+    if ((rc = rf_args_ok(e, nsamp, nkeep, gauss, fsamp, waveno))) return rc;
+    if (!nlay || !h || !vp || !vs || !rho || !rf) return fail(e, BH_EINVAL, "null argument");
+    if (B == 0 || nkeep == 0) return BH_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (memspace == BH_DEVICE) {
+        hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+        Staged m{nlay, h, vp, vs, rho, qp, qs};
+        call_begin(e, st);
+        rc = launch_rf(e, st, B, Lmax, m, sl, sb, p, gauss, nsamp, fsamp, tshift, nsv, waveno, nkeep, rf, nkeep);
+        call_end(e, st);
+        return rc;
+    }
+    hipStream_t st = e->stream;
+    Staged m{};
+    if ((rc = stage_models(e, B, Lmax, sl, sb, nlay, h, vp, vs, rho, qp, qs, m))) return rc;
+    if ((rc = ensure(e, e->rf, (size_t)B * nkeep * sizeof(double)))) return rc;
+    call_begin(e, st);
+    rc = launch_rf(e, st, B, Lmax, m, sl, sb, p, gauss, nsamp, fsamp, tshift, nsv, waveno, nkeep,
+                   (double *)e->rf.p, nkeep);
+    call_end(e, st);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(rf, e->rf.p, (size_t)B * nkeep * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    return BH_OK;
+}
+
+int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
+{
+    if (!e) return BH_EINVAL;
+    if (nt < 0 || nt > BH_MAX_TARGETS || (nt > 0 && !td)) return fail(e, BH_EINVAL, "nt must be 0..8");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (auto &t : e->targets) {
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv);
+    }
+    e->targets.clear();
+    e->nt = 0;
+    e->ldy = 0;
+    int off = 0;
+    std::vector<TargetHost> tmp((size_t)nt);
+    for (int i = 0; i < nt; ++i) {
+        const bh_target_desc &d = td[i];
+        TargetHost &t = tmp[(size_t)i];
+        t.d = d;
+        t.off = off;
+        int rc = BH_OK;
+        if (d.n < 1 || !d.yobs) rc = fail(e, BH_EINVAL, "target needs n >= 1 and yobs");
+        if (!rc && d.law != BH_LAW_NOCORR && d.law != BH_LAW_NOCORR_SCALED && d.law != BH_LAW_EXP && d.law != BH_LAW_GAUSS)
+            rc = fail(e, BH_EINVAL, "unknown covariance law");
+        if (!rc && d.kind == BH_TARGET_SWD) {
+            if (!d.x) rc = fail(e, BH_EINVAL, "SWD target needs periods x");
+            if (!rc && d.n > BH_MAX_PERIODS)
+                rc = fail(e, BH_EUNSUPPORTED, "more than 60 periods per SWD target is not implemented in bh_evaluate_batch");
+            if (!rc) rc = swd_supported(e, d.n, d.iwave, d.mode, d.flsph);
+        } else if (!rc && d.kind == BH_TARGET_RF) {
+            rc = rf_args_ok(e, d.nsamp, d.n, d.gauss, d.fsamp, d.waveno);
+        } else if (!rc) {
+            rc = fail(e, BH_EINVAL, "unknown target kind");
+        }
+        if (!rc && d.law == BH_LAW_NOCORR_SCALED && !d.yerr) rc = fail(e, BH_EINVAL, "scaled-error law needs yerr");
+        if (!rc && d.law == BH_LAW_GAUSS && !d.rinv) rc = fail(e, BH_EINVAL, "Gauss law needs rinv");
+        const size_t nb = (size_t)d.n * sizeof(double);
+        if (!rc) rc = ensure(e, t.yobs, nb);
+        if (!rc && hipMemcpy(t.yobs.p, d.yobs, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy yobs");
+        if (!rc && d.kind == BH_TARGET_SWD) {
+            rc = ensure(e, t.x, nb);
+            if (!rc && hipMemcpy(t.x.p, d.x, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy x");
+        }
+        if (!rc && d.law == BH_LAW_NOCORR_SCALED) { // Targets.py:124-128
+            std::vector<double> se(d.yerr, d.yerr + d.n);
+            double mn = se[0];
+            for (double v : se) mn = v < mn ? v : mn;
+            double prod = 1.0;
+            for (double &v : se) {
+                v = v / mn;
+                prod *= v;
+            }
+            t.logdet_extra = std::log(prod);
+            rc = ensure(e, t.yerr_scaled, nb);
+            if (!rc && hipMemcpy(t.yerr_scaled.p, se.data(), nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy yerr");
+        }
+        if (!rc && d.law == BH_LAW_GAUSS) {
+            t.logdet_extra = d.logdet_r;
+            rc = ensure(e, t.rinv, nb * (size_t)d.n);
+            if (!rc && hipMemcpy(t.rinv.p, d.rinv, nb * (size_t)d.n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy rinv");
+        }
+        if (rc) {
+            for (auto &u : tmp) {
+                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv);
+            }
+            return rc;
+        }
+        // the engine keeps no host pointers
+        t.d.x = t.d.yobs = t.d.yerr = t.d.rinv = nullptr;
+        off += d.n;
+    }
+    e->targets.swap(tmp);
+    e->nt = nt;
+    e->ldy = off;
+    return BH_OK;
+}
+
+int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
+                      const int32_t *nlay, const double *h, const double *vp, const double *vs,
+                      const double *rho, ptrdiff_t sl, ptrdiff_t sb, const double *noise,
+                      double *logL, double *misfits, int32_t *err, double *ymod)
+{
+    int rc;
+    if ((rc = check_models(e, B, Lmax, sl, sb))) return rc;
+    if (e->nt < 1) return fail(e, BH_EINVAL, "no targets registered (bh_targets_set)");
+    if (!nlay || !h || !vp || !vs || !noise || !logL || !misfits || !err) return fail(e, BH_EINVAL, "null argument");
+    if (B == 0) return BH_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int nt = e->nt, ldy = e->ldy;
+    const bool host = (memspace != BH_DEVICE);
+    hipStream_t st = (!host && stream) ? (hipStream_t)stream : e->stream;
+    Staged m{nlay, h, vp, vs, rho, nullptr, nullptr};
+    const double *noise_d = noise;
+    double *logL_d = logL, *misf_d = misfits, *ymod_d = ymod;
+    int32_t *err_d = err;
+    if (host) {
+        if ((rc = stage_models(e, B, Lmax, sl, sb, nlay, h, vp, vs, rho, nullptr, nullptr, m))) return rc;
+        if ((rc = ensure(e, e->noise, (size_t)B * 2 * nt * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->logL, (size_t)B * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->misfits, (size_t)B * (nt + 1) * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->errb, (size_t)B * sizeof(int32_t)))) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->noise.p, noise, (size_t)B * 2 * nt * sizeof(double), hipMemcpyHostToDevice, st));
+        noise_d = (const double *)e->noise.p;
+        logL_d = (double *)e->logL.p;
+        misf_d = (double *)e->misfits.p;
+        err_d = (int32_t *)e->errb.p;
+        ymod_d = nullptr;
+    }
+    if (!ymod_d) {
+        if ((rc = ensure(e, e->ymod, (size_t)B * ldy * sizeof(double)))) return rc;
+        ymod_d = (double *)e->ymod.p;
+    }
+    if ((rc = ensure(e, e->err_t, (size_t)nt * B * sizeof(int32_t)))) return rc;
+    if (!m.rho) { // rho = 0.32 vp + 0.77 (Targets.py:319)
+        const size_t nel = span_elems(B, Lmax, sl, sb);
+        if ((rc = ensure(e, e->rho, nel * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(rho_from_vp_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, nel, m.vp, (double *)e->rho.p);
+        m.rho = (const double *)e->rho.p;
+    }
+    call_begin(e, st);
+    HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
+    LikeKernelArgs la{};
+    la.B = B; la.nt = nt; la.ldy = ldy; la.ymod = ymod_d; la.err_t = (const int32_t *)e->err_t.p;
+    la.noise = noise_d; la.logL = logL_d; la.misfits = misf_d; la.err = err_d;
+    for (int t = 0; t < nt; ++t) {
+        TargetHost &T = e->targets[(size_t)t];
+        const bh_target_desc &d = T.d;
+        if (d.kind == BH_TARGET_SWD)
+            rc = launch_swd(e, st, B, Lmax, m, sl, sb, d.n, (const double *)T.x.p, d.iwave, d.igr,
+                            ymod_d + T.off, ldy, (int32_t *)e->err_t.p + (size_t)t * B);
+        else
+            rc = launch_rf(e, st, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp,
+                           d.tshift, d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
+        if (rc) return rc;
+        la.t[t].law = d.law; la.t[t].n = d.n; la.t[t].off = T.off;
+        la.t[t].yobs = (const double *)T.yobs.p;
+        la.t[t].yerr_scaled = (const double *)T.yerr_scaled.p;
+        la.t[t].rinv = (const double *)T.rinv.p;
+        la.t[t].logdet_extra = T.logdet_extra;
+    }
+    ev_begin(e, 2, st);
+    bh_launch_like(la, st);
+    ev_end(e, 2, st);
+    call_end(e, st);
+    HIPCHK(e, hipGetLastError());
+    if (host) {
+        HIPCHK(e, hipMemcpyAsync(logL, logL_d, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipMemcpyAsync(misfits, misf_d, (size_t)B * (nt + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipMemcpyAsync(err, err_d, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (ymod) HIPCHK(e, hipMemcpyAsync(ymod, ymod_d, (size_t)B * ldy * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}
+
+int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out)
+{
+    if (!e || n < 0 || !in || !out) return BH_EINVAL;
+    if (n == 0) return BH_OK;
+    int rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    if ((rc = ensure(e, e->probe_in, (size_t)n * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->probe_out, (size_t)n * sizeof(double)))) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->probe_in.p, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    bh_launch_probe(op, n, (const double *)e->probe_in.p, (double *)e->probe_out.p, e->stream);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(out, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return BH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,422 @@
+// bayhunter_amd/csrc/rf_kernel.hip -- receiver-function synthesis on gfx950.
+//
+// Replaces the reference's rfmini path  synrf_cwrap (rfmini/wrap.cpp:58-80) -> synrf
+// (rfmini/synrf.cpp:16-55) -> calcresp/calcresp_core (rfmini/greens.cpp:400-756) -> compute_rf
+// (:343-398) -> iftr (:136-158) -> ccfork (rfmini/fork.cpp:11-60) for a batch of models.
+//
+// Three kernels per batch (all FP64 VALU, no MFMA -- complex 2x2 recursions, not contractions):
+//   rf_coef_kernel      lane = model.  Earth-flattening (rfmini/model.cpp:221-252), the
+//                       frequency-independent interface reflection/transmission matrices
+//                       (greens.cpp:19-112), the free-surface displacement matrix (:307-322) and
+//                       the Z/R -> P/SV rotation constants (:324-341), written to a per-model
+//                       coefficient record in HBM (L2-resident: 3.4 KB/model at 10 layers).
+//   rf_spectrum_kernel  lane = (model, frequency): the 1025 frequencies of a model are
+//                       independent (greens.cpp:528), so the Kennett/Mueller top-down
+//                       reflectivity recursion (:196-224) runs with one frequency per lane; a
+//                       workgroup covers 256 consecutive frequencies of ONE model, so its
+//                       coefficient record is wave-uniform (scalar loads).  The deconvolution +
+//                       Gauss filter + time shift (:343-398) is fused; the lane writes one complex
+//                       spectral sample (16 B, coalesced).  The Nyquist bin (j = nsamp/2) of 256
+//                       models at a time is handled by trailing workgroups (lane = model).
+//   rf_ifft_kernel      workgroup = model: Hermitian-extended inverse FFT of length nsamp staged
+//                       entirely in LDS (32 KB at nsamp = 2048 + 16 KB twiddles), only the first
+//                       nkeep real samples are written (rfmini_modrf.py:142).
+#include "bh_device.h"
+
+namespace {
+
+struct cd {
+    double re, im;
+};
+__device__ __forceinline__ cd C(double r, double i = 0.0) { return cd{r, i}; }
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cd operator-(cd a) { return cd{-a.re, -a.im}; }
+__device__ __forceinline__ cd operator*(cd a, cd b)
+{
+    return cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ cd operator*(double s, cd a) { return cd{s * a.re, s * a.im}; }
+__device__ __forceinline__ cd operator*(cd a, double s) { return cd{s * a.re, s * a.im}; }
+__device__ __forceinline__ cd operator+(double s, cd a) { return cd{s + a.re, a.im}; }
+__device__ __forceinline__ cd operator-(cd a, double s) { return cd{a.re - s, a.im}; }
+__device__ __forceinline__ cd conj(cd a) { return cd{a.re, -a.im}; }
+__device__ __forceinline__ cd crecip(cd b)
+{
+    const double den = b.re * b.re + b.im * b.im;
+    return cd{b.re / den, -b.im / den};
+}
+__device__ __forceinline__ cd operator/(cd a, cd b) { return a * crecip(b); }
+__device__ __forceinline__ cd csqrt_d(cd z)
+{
+    if (z.re == 0.0 && z.im == 0.0) return cd{0.0, z.im};
+    const double r = hypot(z.re, z.im);
+    if (z.re >= 0.0) {
+        const double t = sqrt(0.5 * (r + z.re));
+        return cd{t, z.im / (2.0 * t)};
+    }
+    const double t = sqrt(0.5 * (r - z.re));
+    return cd{fabs(z.im) / (2.0 * t), copysign(t, z.im)};
+}
+__device__ __forceinline__ cd cexp_d(cd z)
+{
+    double s, c;
+    sincos(z.im, &s, &c);
+    const double m = exp(z.re);
+    return cd{m * c, m * s};
+}
+
+struct cm2 {
+    cd c11, c12, c21, c22;
+};
+__device__ __forceinline__ cm2 operator*(const cm2 &x, const cm2 &y)
+{
+    return cm2{x.c11 * y.c11 + x.c12 * y.c21, x.c11 * y.c12 + x.c12 * y.c22,
+               x.c21 * y.c11 + x.c22 * y.c21, x.c21 * y.c12 + x.c22 * y.c22};
+}
+__device__ __forceinline__ cm2 operator+(const cm2 &x, const cm2 &y)
+{
+    return cm2{x.c11 + y.c11, x.c12 + y.c12, x.c21 + y.c21, x.c22 + y.c22};
+}
+
+// ---- per-model coefficient record (doubles) ---------------------------------------------------
+//  [0] nlay  [1] p (s/km)  [2] do_decomp  [3] bad (NaN propagation of t0 / decomp)
+//  [4..7] m11 m12 m21 m22 (rotation)   [8..15] 2*h matrix (4 complex)
+//  [16..23] free-surface ru (4 complex)
+//  [24 + 8*l ...]           layer l = 0..Lmax-1 : vp, vs, h (flattened), qp, qs, -, -, -
+//  [24 + 8*Lmax + 32*i ...] interface below layer i (i = 0..Lmax-2): rd, td, ru, tu (4 complex each)
+constexpr int REC_HEAD = 24;
+__host__ __device__ inline size_t rec_doubles(int Lmax) { return REC_HEAD + 8 * (size_t)Lmax + 32 * (size_t)Lmax; }
+
+__device__ __forceinline__ void store_cm2(double *p, const cm2 &m)
+{
+    p[0] = m.c11.re; p[1] = m.c11.im; p[2] = m.c12.re; p[3] = m.c12.im;
+    p[4] = m.c21.re; p[5] = m.c21.im; p[6] = m.c22.re; p[7] = m.c22.im;
+}
+__device__ __forceinline__ cm2 load_cm2(const double *p)
+{
+    return cm2{cd{p[0], p[1]}, cd{p[2], p[3]}, cd{p[4], p[5]}, cd{p[6], p[7]}};
+}
+
+// greens.cpp:19-85 (P/SV part)
+__device__ void interface_coeffs(double u, double vp1, double vs1, double rho1, double vp2,
+                                 double vs2, double rho2, cm2 &rd, cm2 &td, cm2 &ru, cm2 &tu)
+{
+    const double mue1 = rho1 * vs1 * vs1, mue2 = rho2 * vs2 * vs2;
+    const double c = 2. * (mue1 - mue2), u2 = u * u, cu2 = c * u2;
+    const cd a1 = conj(csqrt_d(C(1. / (vp1 * vp1) - u2)));
+    const cd a2 = conj(csqrt_d(C(1. / (vp2 * vp2) - u2)));
+    const cd b1 = conj(csqrt_d(C(1. / (vs1 * vs1) - u2)));
+    const cd b2 = conj(csqrt_d(C(1. / (vs2 * vs2) - u2)));
+    const double t1 = cu2 - rho1 + rho2;
+    const double t2 = cu2 - rho1;
+    const double t3 = cu2 + rho2;
+    const cd t4 = t3 * a1 - t2 * a2;
+    const cd a1a2b1b2 = (c * c * u2) * a1 * a2 * b1 * b2;
+    {
+        const cd d1 = (t1 * t1 * u2) + (t2 * t2) * a2 * b2 + (rho1 * rho2) * a2 * b1;
+        const cd d2 = a1a2b1b2 + (t3 * t3) * a1 * b1 + (rho1 * rho2) * a1 * b2;
+        const cd t5 = crecip(d1 + d2);
+        const cd t7 = (2. * rho1) * t5;
+        const cd mix = (t1 * t3) + (c * t2) * a2 * b2;
+        rd.c11 = (d2 - d1) * t5;                                              // rpp
+        rd.c21 = (-2. * u) * a1 * t5 * mix;                                   // rps
+        td.c11 = a1 * t7 * (t3 * b1 - t2 * b2);                               // tpp
+        td.c21 = -(a1 * t7) * u * (t1 + c * (a2 * b1));                       // tps
+        rd.c22 = (d2 - d1 - (2. * rho1 * rho2) * (a1 * b2 - a2 * b1)) * t5;   // rss
+        rd.c12 = (2. * u) * b1 * t5 * mix;                                    // rsp
+        td.c22 = b1 * t7 * t4;                                                // tss
+        td.c12 = b1 * t7 * u * (t1 + c * (a1 * b2));                          // tsp
+    }
+    {
+        const cd d1 = (t1 * t1 * u2) + (t3 * t3) * a1 * b1 + (rho1 * rho2) * a1 * b2;
+        const cd d2 = a1a2b1b2 + (t2 * t2) * a2 * b2 + (rho1 * rho2) * a2 * b1;
+        const cd t5 = crecip(d1 + d2);
+        const cd t7 = (2. * rho2) * t5;
+        const cd mix = (t1 * t2) + (c * t3) * a1 * b1;
+        ru.c11 = (d2 - d1) * t5;
+        ru.c21 = (2. * u) * a2 * t5 * mix;
+        tu.c11 = a2 * t7 * (t3 * b1 - t2 * b2);
+        tu.c21 = -(a2 * t7) * u * (t1 + c * (a1 * b2));
+        ru.c22 = (d2 - d1 - (2. * rho1 * rho2) * (a2 * b1 - a1 * b2)) * t5;
+        ru.c12 = (-2. * u) * b2 * t5 * mix;
+        tu.c22 = b2 * t7 * t4;
+        tu.c12 = b2 * t7 * u * (t1 + c * (a2 * b1));
+    }
+}
+
+__global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
+{
+    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= A.B) return;
+    const int Lmax = A.Lmax;
+    double *rec = A.coef + (size_t)ib * rec_doubles(Lmax);
+    const int nlay = A.nlay[ib];
+    const ptrdiff_t base = (ptrdiff_t)ib * A.sb;
+    const double R = 6371.0;
+    const double p = A.p_s_per_deg * 0.00899; // wrap.cpp:55
+    const double p2 = p * p;
+    double bad = 0.0;
+
+    // top-layer quantities before flattening (q = 1 for the top layer anyway)
+    const double vp0 = A.vp[base], vs0 = A.vs[base];
+    // rfmini_modrf.py:125-130 and wrap.cpp:13,73-74
+    const double kap = vp0 / vs0;
+    const double poisson = (2 - kap * kap) / (2 - 2 * (kap * kap));
+    const double nsv = (A.nsv > 0.0) ? A.nsv : vs0;
+    const double vptop = nsv * sqrt((1. - poisson) / (.5 - poisson));
+    const double vstop = nsv;
+
+    // flatten layer by layer (model.cpp:221-252); z = depth of the layer top = running sum of h
+    double ztop = 0.0, t0 = 0.0;
+    double pvp = 0, pvs = 0, prh = 0; // previous (upper) layer, flattened
+    for (int l = 0; l < nlay; ++l) {
+        const ptrdiff_t o = base + (ptrdiff_t)l * A.sl;
+        // thickness the way synrf.cpp:28-32 forms it from the depths z = cumsum(h)
+        // (rfmini_modrf.py:119-123): z[l+1] - z[l]; the half-space gets -1
+        const double znext = ztop + A.h[o];
+        const bool half = (l == nlay - 1);
+        double hh = half ? -1.0 : (znext - ztop);
+        double vp = A.vp[o], vs = A.vs[o], rh = A.rho[o];
+        const double qp = A.qp ? A.qp[o] : 500.0, qs = A.qs ? A.qs[o] : 225.0;
+        const double zb = ztop + hh;
+        double r = R - ztop;
+        double q = R / r;
+        const double zf = R * log(q);
+        vp *= q;
+        vs *= q;
+        rh /= q;
+        const bool lower_halfspace = !(hh > 0.0) && !(vp < 1.0 && rh < 0.1);
+        if (!lower_halfspace) {
+            r = R - zb;
+            q = R / r;
+            hh = R * log(q) - zf;
+        }
+        double *lay = rec + REC_HEAD + 8 * l;
+        lay[0] = vp; lay[1] = vs; lay[2] = hh; lay[3] = qp; lay[4] = qs;
+        // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
+        const double vv = (A.waveno == 0) ? vp : vs;
+        t0 += hh * sqrt(1. / (vv * vv) - p2);
+        if (l == 0) {
+            // free surface, greens.cpp:87-112 (plain sqrt) and displacement matrix :307-322
+            const cd a = csqrt_d(C(1. / (vp * vp) - p2));
+            const cd b = csqrt_d(C(1. / (vs * vs) - p2));
+            const double t1 = 2. * vs * vs;
+            const double t2 = t1 * p2 - 1.;
+            const cd d1 = C(t2 * t2);
+            const cd d2 = (t1 * t1 * p2) * a * b;
+            const cd d = d1 + d2;
+            const cd t3 = C(2. * t1 * p * t2) / d;
+            cm2 ru;
+            ru.c11 = (d2 - d1) / d;
+            ru.c12 = -(b * t3);
+            ru.c21 = a * t3;
+            ru.c22 = ru.c11;
+            store_cm2(rec + 16, ru);
+            const double vp2 = vp * vp, vs2 = vs * vs, x = 1. - 2. * vs2 * p2;
+            const cd a1 = conj(a), b1 = conj(b);
+            const cd qq = crecip(C(x * x) + (4. * vs2 * vs2 * p2) * a1 * b1);
+            cm2 hm;
+            hm.c11 = qq * a1 * b1 * (2. * vs2 * p);
+            hm.c12 = qq * b1 * (1. - 2. * vs2 * p2);
+            hm.c21 = qq * a1 * (1. - 2. * vs2 * p2);
+            hm.c22 = -(qq * a1 * b1 * (2. * vs2 * p));
+            hm.c11 = 2.0 * hm.c11; hm.c12 = 2.0 * hm.c12; hm.c21 = 2.0 * hm.c21; hm.c22 = 2.0 * hm.c22;
+            store_cm2(rec + 8, hm);
+            (void)vp2;
+        } else {
+            cm2 rd, td, ru, tu;
+            interface_coeffs(p, pvp, pvs, prh, vp, vs, rh, rd, td, ru, tu);
+            double *ic = rec + REC_HEAD + 8 * Lmax + 32 * (l - 1);
+            store_cm2(ic, rd);
+            store_cm2(ic + 8, td);
+            store_cm2(ic + 16, ru);
+            store_cm2(ic + 24, tu);
+        }
+        pvp = vp; pvs = vs; prh = rh;
+        ztop = znext;
+    }
+    if (t0 != t0) bad = 1.0;
+    if (nlay < 2) bad = 1.0; // the reference reads an uninitialised matrix here
+    // rotation Z/R -> P/SV with REAL vertical slownesses (greens.cpp:324-341)
+    double do_decomp = 0.0, m11 = 0, m12 = 0, m21 = 0, m22 = 0;
+    if (vstop > 0.01 && fabs(p) > 0.0001) {
+        do_decomp = 1.0;
+        const double aa = sqrt(1. / (vptop * vptop) - p * p), bb = sqrt(1. / (vstop * vstop) - p * p);
+        m11 = -(2 * vstop * vstop * p * p - 1.) / (vptop * aa);
+        m12 = 2. * p * vstop * vstop / vptop;
+        m21 = -2. * p * vstop;
+        m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
+    }
+    rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
+    rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
+}
+
+// One frequency of one model: greens.cpp:528-585 + :343-398.  `rec` may be wave-uniform.
+__device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, int Lmax, int j,
+                                               double dw, double qg, double gauss, double tshift,
+                                               int waveno)
+{
+    const int nlay = (int)rec[0];
+    const double p2 = rec[1] * rec[1];
+    const double w = dw * j;
+    const double wref = 2. * M_PI * 1.0;
+    const double lgw = j ? log(w / wref) : 0.0;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    if (rec[3] != 0.0) return cd{nanv, nanv};
+
+    cm2 nb, q, g;
+    nb = q = g = cm2{C(0), C(0), C(0), C(0)};
+    const double *lay = rec + REC_HEAD;
+    const double *ifc = rec + REC_HEAD + 8 * Lmax;
+    for (int i = 1; i < nlay; ++i) {
+        const double *L = lay + 8 * (i - 1);
+        const double vp = L[0], vs = L[1], d = L[2], qp = L[3], qs = L[4];
+        // complex velocities with causal Q (greens.cpp:539-543), vertical slownesses, phases
+        const cd vpc = vp * cd{1. + lgw / (M_PI * qp), 1. / (2. * qp)};
+        const cd vsc = vs * cd{1. + lgw / (M_PI * qs), 1. / (2. * qs)};
+        const cd plc = csqrt_d(crecip(vpc * vpc) - p2);
+        const cd slc = csqrt_d(crecip(vsc * vsc) - p2);
+        const cd miwd = cd{0., -w * d};
+        const cd e11 = cexp_d(miwd * plc);
+        const cd e22 = cexp_d(miwd * slc);
+        // Mueller (1985) top-down recursion, greens.cpp:196-224
+        cm2 nt;
+        if (i == 1)
+            nt = load_cm2(rec + 16);
+        else {
+            const double *ic = ifc + 32 * (i - 2); // interface above layer i
+            nt = load_cm2(ic + 16) + (load_cm2(ic + 8) * nb) * q; // ru[i] + td[i]*nb[i-1]*q
+        }
+        const cd e12 = e11 * e22;
+        nb = cm2{nt.c11 * (e11 * e11), nt.c12 * e12, nt.c21 * e12, nt.c22 * (e22 * e22)};
+        const double *icn = ifc + 32 * (i - 1); // interface below layer i
+        const cm2 rdn = load_cm2(icn), tun = load_cm2(icn + 24);
+        const cm2 rn = rdn * nb;
+        const cm2 m = cm2{C(1.) - rn.c11, -rn.c12, -rn.c21, C(1.) - rn.c22};
+        const cd idet = crecip(m.c11 * m.c22 - m.c12 * m.c21);
+        const cm2 minv = cm2{idet * m.c22, -(idet * m.c12), -(idet * m.c21), idet * m.c11};
+        q = minv * tun;
+        if (i == 1)
+            g = cm2{e11 * q.c11, e11 * q.c12, e22 * q.c21, e22 * q.c22};
+        else {
+            const cm2 ge = cm2{g.c11 * e11, g.c12 * e22, g.c21 * e11, g.c22 * e22};
+            g = ge * q;
+        }
+    }
+    const cm2 hm = load_cm2(rec + 8); // already 2*h
+    cd cr, cz;
+    if (waveno == 0) {
+        cr = hm.c11 * g.c11 + hm.c12 * g.c21;
+        cz = hm.c21 * g.c11 + hm.c22 * g.c21;
+    } else {
+        cr = hm.c11 * g.c12 + hm.c12 * g.c22;
+        cz = hm.c21 * g.c12 + hm.c22 * g.c22;
+    }
+    // (the common factor exp(i w t0) of greens.cpp:583-585 cancels in cr*conj(cz)/|cz|^2)
+    if (rec[2] != 0.0) {
+        const cd cx = cz * rec[4] + cr * rec[5];
+        const cd cy = cz * rec[6] + cr * rec[7];
+        cz = cx;
+        cr = cy;
+    }
+    if (waveno == 1) {
+        const cd t = cz;
+        cz = cr;
+        cr = t;
+    }
+    const double denom = cz.re * cz.re + cz.im * cz.im;
+    const cd num = cr * conj(cz);
+    const cd v = cd{num.re / denom, num.im / denom};
+    double wa = w / gauss;
+    wa = (wa > 50.0) ? 50.0 : wa;
+    const cd cq = qg * cexp_d(cd{-0.25 * (wa * wa), -w * tshift});
+    return v * cq;
+}
+
+__global__ __launch_bounds__(256) void rf_spectrum_kernel(RfKernelArgs A, int nbpm)
+{
+    const int half = A.nsamp / 2;
+    const int nfreq = half + 1;
+    const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
+    const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
+    const size_t recsz = rec_doubles(A.Lmax);
+    const int nmain = A.B * nbpm;
+    int ib, j;
+    if ((int)blockIdx.x < nmain) {
+        ib = blockIdx.x / nbpm; // wave-uniform
+        j = (blockIdx.x % nbpm) * 256 + threadIdx.x;
+        if (j >= half) return;
+    } else { // Nyquist bins, lane = model
+        ib = (blockIdx.x - nmain) * 256 + threadIdx.x;
+        j = half;
+        if (ib >= A.B) return;
+    }
+    const cd s = rf_one_frequency(A.coef + (size_t)ib * recsz, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
+    double2 *out = reinterpret_cast<double2 *>(A.spec) + (size_t)ib * nfreq + j;
+    *out = make_double2(s.re, s.im);
+}
+
+// Inverse FFT of the Hermitian-extended spectrum, length N = nsamp, all in LDS.
+// iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) sum_k X[k] e^{+2 pi i k n / N}.
+__global__ __launch_bounds__(256) void rf_ifft_kernel(RfKernelArgs A, int logn)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = A.nsamp, half = N / 2, nfreq = half + 1;
+    double2 *x = reinterpret_cast<double2 *>(smem);       // [N]
+    double2 *tw = x + N;                                   // [N/2]  e^{+2 pi i k / N}
+    const int ib = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double2 *spec = reinterpret_cast<const double2 *>(A.spec) + (size_t)ib * nfreq;
+    for (int k = tid; k < half; k += 256) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)N, &s, &c);
+        tw[k] = make_double2(c, s);
+    }
+    // load in bit-reversed order with the Hermitian extension cx[i] = conj(cx[N-i]), i > N/2
+    for (int i = tid; i < N; i += 256) {
+        double2 v;
+        if (i <= half) v = spec[i];
+        else {
+            v = spec[N - i];
+            v.y = -v.y;
+        }
+        const int r = (int)(__brev((unsigned)i) >> (32 - logn));
+        x[r] = v;
+    }
+    __syncthreads();
+    for (int s = 0; s < logn; ++s) {
+        const int l = 1 << s;          // half-size of the butterflies of this stage
+        const int tstride = half >> s; // twiddle stride
+        for (int bfly = tid; bfly < half; bfly += 256) {
+            const int m = bfly & (l - 1);
+            const int i = ((bfly >> s) << (s + 1)) + m;
+            const double2 w = tw[m * tstride];
+            const double2 u = x[i], v = x[i + l];
+            const double2 t = make_double2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
+            x[i + l] = make_double2(u.x - t.x, u.y - t.y);
+            x[i] = make_double2(u.x + t.x, u.y + t.y);
+        }
+        __syncthreads();
+    }
+    const double scale = 1.0 / (double)N;
+    double *out = A.rf + (size_t)ib * A.ldr;
+    for (int n = tid; n < A.nkeep; n += 256) out[n] = scale * x[n].x;
+}
+
+} // namespace
+
+size_t bh_rf_coef_doubles(int Lmax) { return rec_doubles(Lmax); }
+
+void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
+{
+    const int half = a.nsamp / 2;
+    int logn = 0;
+    while ((1 << logn) < a.nsamp) ++logn;
+    hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
+    const int nbpm = (half + 255) / 256;
+    const int grid = a.B * nbpm + (a.B + 255) / 256;
+    hipLaunchKernelGGL(rf_spectrum_kernel, dim3(grid), dim3(256), 0, stream, a, nbpm);
+    const size_t lds = (size_t)a.nsamp * 16 + (size_t)half * 16;
+    hipLaunchKernelGGL(rf_ifft_kernel, dim3(a.B), dim3(256), lds, stream, a, logn);
+}

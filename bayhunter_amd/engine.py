@@ -1,0 +1,305 @@
+"""ctypes binding of the engine's C ABI (include/bh_engine.h -> bayhunter_amd/libbh_engine.so).
+
+This is the only place Python touches the native library.  There is NO CPU fallback: if the
+shared library is missing, or no MI355X/HIP device is usable, creating an `Engine` raises
+`EngineError`.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)
+
+Host API  : numpy arrays in, numpy arrays out (the library stages through its own device buffers).
+Device API: raw device pointers (`tensor.data_ptr()`), asynchronous on a HIP stream -- what
+            bench.py and the multi-GPU chain driver use with torch-owned HBM buffers.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbh_engine.so")
+
+BH_OK, BH_EINVAL, BH_EHIP, BH_ENOMEM, BH_EUNSUPPORTED = 0, -1, -2, -3, -4
+HOST, DEVICE = 0, 1
+WAVE_LOVE, WAVE_RAYLEIGH = 1, 2
+VEL_PHASE, VEL_GROUP = 0, 1
+RF_P, RF_SV = 0, 1
+LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
+TARGET_SWD, TARGET_RF = 0, 1
+MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
+
+_d = C.POINTER(C.c_double)
+_i32 = C.POINTER(C.c_int32)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class TargetDesc(C.Structure):
+    """Mirror of `bh_target_desc` (include/bh_engine.h)."""
+    _fields_ = [("kind", C.c_int32), ("law", C.c_int32), ("n", C.c_int32),
+                ("iwave", C.c_int32), ("igr", C.c_int32), ("mode", C.c_int32), ("flsph", C.c_int32),
+                ("waveno", C.c_int32), ("nsamp", C.c_int32),
+                ("p_s_per_deg", C.c_double), ("gauss", C.c_double), ("fsamp", C.c_double),
+                ("tshift", C.c_double), ("nsv", C.c_double),
+                ("x", _d), ("yobs", _d), ("yerr", _d), ("rinv", _d), ("logdet_r", C.c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libbh_engine.so once.  torch (when the process uses it) must be imported BEFORE
+    the library so that both share one HIP runtime (torch ships its own libamdhip64.so with the
+    same SONAME); importing it here first makes the order irrelevant for callers."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError("native engine %s is not built; run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (or `make -C bayhunter_amd/csrc`)" % LIB_PATH)
+    if "torch" not in sys.modules and os.environ.get("BH_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional for the plugin path
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    L.bh_abi_version.restype = C.c_int
+    L.bh_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.bh_engine_destroy.argtypes = [vp]
+    L.bh_engine_destroy.restype = None
+    L.bh_engine_last_error.argtypes = [vp]
+    L.bh_engine_last_error.restype = C.c_char_p
+    L.bh_engine_stream.argtypes = [vp]
+    L.bh_engine_stream.restype = vp
+    L.bh_engine_synchronize.argtypes = [vp]
+    L.bh_engine_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
+    L.bh_last_timing.argtypes = [vp, _d, _d]
+    L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bh_swd_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_ssize_t,
+                               C.c_ssize_t, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.bh_rf_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                              C.c_ssize_t, C.c_ssize_t, C.c_double, C.c_double, C.c_int, C.c_double,
+                              C.c_double, C.c_double, C.c_int, C.c_int, vp]
+    L.bh_targets_set.argtypes = [vp, C.c_int, C.POINTER(TargetDesc)]
+    L.bh_evaluate_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                    C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, vp]
+    L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation",
+                 "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                 "bh_evaluate_batch", "bh_probe_math"):
+        getattr(L, name).restype = C.c_int
+    if L.bh_abi_version() != 1:
+        raise EngineError("ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation",
+                    "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                    "bh_evaluate_batch", "bh_probe_math")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def pack_models(models, Lmax=None):
+    """List of (h, vp, vs, rho) 1-D arrays -> layer-major float64 [Lmax, B] arrays + nlay[B]."""
+    B = len(models)
+    nlay = np.array([len(m[0]) for m in models], dtype=np.int32)
+    if Lmax is None:
+        Lmax = int(nlay.max()) if B else 1
+    out = [np.zeros((Lmax, B)) for _ in range(4)]
+    for b, m in enumerate(models):
+        for a, v in zip(out, m):
+            a[:nlay[b], b] = v
+    return nlay, out[0], out[1], out[2], out[3]
+
+
+class Engine(object):
+    """One engine = one GPU (HIP device ordinal `device`) = one stream."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.bh_engine_create(int(device), C.byref(h))
+        if rc != BH_OK:
+            raise EngineError("bh_engine_create(device=%d) failed with %d: no usable HIP device "
+                              "(this package has no CPU fallback)" % (device, rc))
+        self._h = h
+        self.device = int(device)
+        self._keep = None  # host arrays referenced by the last bh_targets_set call
+        self.ntargets = 0
+        self.ldy = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bh_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != BH_OK:
+            msg = self._L.bh_engine_last_error(self._h)
+            raise EngineError("engine call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+    # -- plumbing ---------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return self._L.bh_engine_stream(self._h)
+
+    def synchronize(self):
+        self._check(self._L.bh_engine_synchronize(self._h))
+
+    def set_instrumentation(self, timing=False, counting=False):
+        self._check(self._L.bh_engine_set_instrumentation(self._h, int(timing), int(counting)))
+
+    def last_timing(self):
+        """(total_ms, {'swd': ms, 'rf': ms, 'like': ms}) of the most recent timed call."""
+        tot = C.c_double(0)
+        fam = (C.c_double * 3)()
+        self._check(self._L.bh_last_timing(self._h, C.byref(tot), fam))
+        return tot.value, {"swd": fam[0], "rf": fam[1], "like": fam[2]}
+
+    def last_neval(self):
+        v = C.c_uint64(0)
+        self._check(self._L.bh_last_neval(self._h, C.byref(v)))
+        return int(v.value)
+
+    @staticmethod
+    def _model_args(nlay, h, vp, vs, rho, layout):
+        """Validate host model arrays; returns (B, Lmax, stride_l, stride_b, arrays...)."""
+        h = _f64(h)
+        if layout == "layer_major":   # [Lmax, B]
+            Lmax, B = h.shape
+            sl, sb = B, 1
+        elif layout == "model_major":  # [B, Lmax]
+            B, Lmax = h.shape
+            sl, sb = 1, Lmax
+        else:
+            raise ValueError("layout must be 'layer_major' or 'model_major'")
+        arrs = [h] + [None if a is None else _f64(a) for a in (vp, vs, rho)]
+        for a in arrs:
+            if a is not None and a.shape != h.shape:
+                raise ValueError("model arrays must have identical shapes")
+        nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+        if nlay.shape != (B,):
+            raise ValueError("nlay must have shape (B,)")
+        if B and (nlay.min() < 1 or nlay.max() > Lmax):
+            raise ValueError("nlay entries must be in 1..Lmax")
+        return B, Lmax, sl, sb, nlay, arrs
+
+    # -- host API ---------------------------------------------------------------------------
+    def swd_batch(self, nlay, h, vp, vs, rho, periods, iwave, igr, mode=1, flsph=0,
+                  layout="layer_major"):
+        """Batched surfdisp96.  Returns (vel[B, K], err[B])."""
+        B, Lmax, sl, sb, nlay, (h, vp, vs, rho) = self._model_args(nlay, h, vp, vs, rho, layout)
+        periods = _f64(periods)
+        K = periods.size
+        vel = np.zeros((B, K))
+        err = np.zeros(B, dtype=np.int32)
+        self._check(self._L.bh_swd_batch(self._h, HOST, None, B, Lmax, _ptr(nlay), _ptr(h), _ptr(vp),
+                                         _ptr(vs), _ptr(rho), sl, sb, K, _ptr(periods), int(iwave),
+                                         int(igr), int(mode), int(flsph), _ptr(vel), _ptr(err)))
+        return vel, err
+
+    def rf_batch(self, nlay, h, vp, vs, rho, p, gauss, nsamp, fsamp, tshift, waveno, nkeep,
+                 nsv=0.0, qp=None, qs=None, layout="layer_major"):
+        """Batched rfmini synrf.  Returns rf[B, nkeep]."""
+        B, Lmax, sl, sb, nlay, (h, vp, vs, rho) = self._model_args(nlay, h, vp, vs, rho, layout)
+        qp = None if qp is None else _f64(qp)
+        qs = None if qs is None else _f64(qs)
+        rf = np.zeros((B, int(nkeep)))
+        self._check(self._L.bh_rf_batch(self._h, HOST, None, B, Lmax, _ptr(nlay), _ptr(h), _ptr(vp),
+                                        _ptr(vs), _ptr(rho), _ptr(qp), _ptr(qs), sl, sb, float(p),
+                                        float(gauss), int(nsamp), float(fsamp), float(tshift),
+                                        float(nsv), int(waveno), int(nkeep), _ptr(rf)))
+        return rf
+
+    def set_targets(self, descs):
+        """descs: list of dicts with the `bh_target_desc` fields (arrays as numpy)."""
+        arr = (TargetDesc * max(1, len(descs)))()
+        keep = []
+        ldy = 0
+        for i, d in enumerate(descs):
+            t = arr[i]
+            t.kind, t.law, t.n = int(d["kind"]), int(d["law"]), int(d["n"])
+            t.iwave, t.igr = int(d.get("iwave", 2)), int(d.get("igr", 0))
+            t.mode, t.flsph = int(d.get("mode", 1)), int(d.get("flsph", 0))
+            t.waveno, t.nsamp = int(d.get("waveno", 0)), int(d.get("nsamp", 0))
+            t.p_s_per_deg, t.gauss = float(d.get("p", 6.4)), float(d.get("gauss", 1.0))
+            t.fsamp, t.tshift, t.nsv = float(d.get("fsamp", 1.0)), float(d.get("tshift", 0.0)), float(d.get("nsv", 0.0))
+            for key in ("x", "yobs", "yerr", "rinv"):
+                v = d.get(key)
+                if v is not None:
+                    v = _f64(v)
+                    keep.append(v)
+                    setattr(t, key, v.ctypes.data_as(_d))
+            t.logdet_r = float(d.get("logdet_r", 0.0))
+            ldy += t.n
+        self._check(self._L.bh_targets_set(self._h, len(descs), arr))
+        self.ntargets = len(descs)
+        self.ldy = ldy
+
+    def evaluate_batch(self, nlay, h, vp, vs, noise, rho=None, layout="layer_major", want_ymod=False):
+        """Batched JointTarget.evaluate.  noise[B, 2*nt].  Returns (logL[B], misfits[B, nt+1],
+        err[B][, ymod[B, ldy]])."""
+        B, Lmax, sl, sb, nlay, (h, vp, vs, rho) = self._model_args(nlay, h, vp, vs, rho, layout)
+        nt = self.ntargets
+        noise = _f64(noise)
+        if noise.shape != (B, 2 * nt):
+            raise ValueError("noise must have shape (B, 2*ntargets)")
+        logL = np.zeros(B)
+        misf = np.zeros((B, nt + 1))
+        err = np.zeros(B, dtype=np.int32)
+        ymod = np.zeros((B, self.ldy)) if want_ymod else None
+        self._check(self._L.bh_evaluate_batch(self._h, HOST, None, B, Lmax, _ptr(nlay), _ptr(h),
+                                              _ptr(vp), _ptr(vs), _ptr(rho), sl, sb, _ptr(noise),
+                                              _ptr(logL), _ptr(misf), _ptr(err), _ptr(ymod)))
+        return (logL, misf, err, ymod) if want_ymod else (logL, misf, err)
+
+    def probe_math(self, op, x):
+        x = _f64(x).ravel()
+        out = np.zeros_like(x)
+        self._check(self._L.bh_probe_math(self._h, int(op), x.size, x.ctypes.data_as(_d), out.ctypes.data_as(_d)))
+        return out
+
+    # -- device API (raw pointers; asynchronous) ---------------------------------------------
+    def swd_batch_dev(self, B, Lmax, nlay, h, vp, vs, rho, sl, sb, K, periods, iwave, igr, vel, err,
+                      stream=None, mode=1, flsph=0):
+        self._check(self._L.bh_swd_batch(self._h, DEVICE, stream, B, Lmax, nlay, h, vp, vs, rho, sl, sb,
+                                         K, periods, iwave, igr, mode, flsph, vel, err))
+
+    def rf_batch_dev(self, B, Lmax, nlay, h, vp, vs, rho, sl, sb, p, gauss, nsamp, fsamp, tshift,
+                     waveno, nkeep, rf, stream=None, nsv=0.0, qp=None, qs=None):
+        self._check(self._L.bh_rf_batch(self._h, DEVICE, stream, B, Lmax, nlay, h, vp, vs, rho, qp, qs,
+                                        sl, sb, p, gauss, nsamp, fsamp, tshift, nsv, waveno, nkeep, rf))
+
+    def evaluate_batch_dev(self, B, Lmax, nlay, h, vp, vs, rho, sl, sb, noise, logL, misfits, err,
+                           ymod=None, stream=None):
+        self._check(self._L.bh_evaluate_batch(self._h, DEVICE, stream, B, Lmax, nlay, h, vp, vs, rho,
+                                              sl, sb, noise, logL, misfits, err, ymod))
+
+
+_default = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine per device (what the plugin classes use)."""
+    e = _default.get(device)
+    if e is None:
+        e = Engine(device)
+        _default[device] = e
+    return e

@@ -1,0 +1,177 @@
+/*
+ * include/bh_engine.h -- C ABI of the MI355X forward-model + likelihood engine.
+ *
+ * This is the drop-in boundary: the entry points below are what BayHunter's two native
+ * FFI surfaces for the hot path bind to, batched over many candidate models.
+ *
+ *   reference interface replaced                                    entry point here
+ *   ----------------------------------------------------------      -----------------
+ *   f2py  surfdisp96(thkm,vpm,vsm,rhom,nlayer,iflsph,iwave,mode,    bh_swd_batch
+ *         igr,kmax,t,cg) -> err      src/extensions/surfdisp96.f:55
+ *         (call site src/surf96_modsw.py:115-117)
+ *   C     int synrf_cwrap(nsamp,fsamp,tshift,p,a,nsv,sigma,waveno,  bh_rf_batch
+ *         nlay,z,vp,vs,rh,qp,qs,fz,fr,rf)
+ *         src/extensions/rfmini/wrap.cpp:58-80
+ *         (call site src/rfmini_modrf.py:134-137 via rfmini.pyx)
+ *   Python JointTarget.evaluate(h,vp,vs,noise)  src/Targets.py:314-347   bh_targets_set +
+ *         + Valuation.get_covariance_* / get_likelihood :105-183    bh_evaluate_batch
+ *
+ * Conventions
+ *   - Plain C: pointers + sizes, no C++/torch types.  Every function returns BH_OK (0) or a
+ *     negative BH_E* code; bh_engine_last_error() gives the text.  A NUMERICAL failure of one
+ *     model (surf96 finds no root) is reported IN-BAND per model -- err[b] = 1, velocities 0
+ *     from the failing period on, logL = -1e15, misfits = 1e15 -- exactly like the reference
+ *     (surfdisp96.f:313-354, surf96_modsw.py:119-126, Targets.py:325-328), never as a
+ *     non-zero return.
+ *   - memspace = BH_HOST: every array argument is a host pointer; the call stages through
+ *     engine-owned device buffers and returns after the results are back on the host.
+ *     memspace = BH_DEVICE: every array argument is a device pointer on the engine's GPU
+ *     (e.g. torch tensor .data_ptr()); the call only enqueues work on `stream` (a hipStream_t
+ *     cast to void*; NULL = the engine's own stream) and returns without synchronising.
+ *   - Model arrays h, vp, vs, rho are float64 with element (layer l, model b) at
+ *     ptr[l*stride_l + b*stride_b].  Layer-major storage (stride_l = B, stride_b = 1) gives
+ *     coalesced loads on the device; model-major rows (stride_l = 1, stride_b = Lmax) are what
+ *     a host caller naturally has.  nlay[b] <= Lmax is the number of layers of model b
+ *     INCLUDING the half-space (whose thickness entry is ignored); entries l >= nlay[b] are
+ *     never read.
+ *   - The caller owns every buffer it passes.  The engine keeps no pointer after a call
+ *     returns, except copies of the constant target data registered by bh_targets_set.
+ *   - One engine = one GPU = one stream; calls on one engine must be serialised by the caller
+ *     (the reference is single-threaded per chain as well).
+ */
+#ifndef BH_ENGINE_H
+#define BH_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_ABI_VERSION 1
+
+enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
+enum { BH_HOST = 0, BH_DEVICE = 1 };
+
+/* surfdisp96's `iwave` (surfdisp96.f:76) and `igr` (:78) */
+enum { BH_WAVE_LOVE = 1, BH_WAVE_RAYLEIGH = 2 };
+enum { BH_VEL_PHASE = 0, BH_VEL_GROUP = 1 };
+/* rfmini's `waveno` (rfmini/wave.h:4-6) */
+enum { BH_RF_P = 0, BH_RF_SV = 1 };
+
+/* surfdisp96.f:59-62 hard limits, kept so that anything the reference accepts is accepted */
+#define BH_MAX_LAYERS 100
+#define BH_MAX_PERIODS 60
+#define BH_MAX_TARGETS 8
+
+typedef struct bh_engine bh_engine;
+
+int bh_abi_version(void);
+
+/* Create an engine on GPU `device` (hipSetDevice ordinal).  Fails with BH_EHIP when no
+ * usable gfx950 device is present: there is no CPU fallback in this library. */
+int bh_engine_create(int device, bh_engine **out);
+void bh_engine_destroy(bh_engine *e);
+const char *bh_engine_last_error(const bh_engine *e);
+/* The engine's own stream as a hipStream_t cast to void*. */
+void *bh_engine_stream(bh_engine *e);
+/* Block until everything enqueued on the engine's stream has finished. */
+int bh_engine_synchronize(bh_engine *e);
+
+/* ---- surface-wave dispersion: replaces surfdisp96 (surfdisp96.f:55-360) -----------------
+ * For each of B models: velocities at K <= 60 periods [s] for wave type `iwave`, velocity
+ * type `igr`, fundamental mode (`mode` = 1; higher modes: BH_EUNSUPPORTED for now), flat
+ * earth (`flsph` = 0; 1: BH_EUNSUPPORTED for now).
+ *   vel[b*K + k]  float64, values are binary32-rounded like the reference's output
+ *   err[b]        0 ok / 1 no root found (then vel[b][k..] = 0 from the failing period on)
+ */
+int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, const int32_t *nlay,
+                 const double *h, const double *vp, const double *vs, const double *rho,
+                 ptrdiff_t stride_l, ptrdiff_t stride_b, int K, const double *periods, int iwave,
+                 int igr, int mode, int flsph, double *vel, int32_t *err);
+
+/* ---- receiver function: replaces synrf_cwrap (rfmini/wrap.cpp:58-80) ----------------------
+ * For each of B models: the (Q-component) receiver function for incident `waveno`, ray
+ * parameter p [s/deg], Gauss parameter `gauss`, nsamp (power of two) samples at fsamp [Hz],
+ * time origin shifted by tshift [s]; the first nkeep <= nsamp samples are returned, which is
+ * what rfmini_modrf.py:142 keeps.  Depths of layer tops are cumsum(h) as in
+ * rfmini_modrf.py:119-123.  qp/qs: per-layer quality factors with the model-array strides, or
+ * NULL for the reference defaults 500/225 (rfmini_modrf.py:116-117).  nsv <= 0 selects the
+ * reference default nsv = vs[0] with Poisson's ratio from vp[0]/vs[0]
+ * (rfmini_modrf.py:125-130); nsv > 0 is used as given with the same Poisson ratio.
+ *   rf[b*nkeep + i] float64
+ */
+int bh_rf_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, const int32_t *nlay,
+                const double *h, const double *vp, const double *vs, const double *rho,
+                const double *qp, const double *qs, ptrdiff_t stride_l, ptrdiff_t stride_b,
+                double p_s_per_deg, double gauss, int nsamp, double fsamp, double tshift,
+                double nsv, int waveno, int nkeep, double *rf);
+
+/* ---- fused forward model + likelihood: replaces JointTarget.evaluate -----------------------
+ * Noise-covariance laws of src/Targets.py:105-173, selected per target the way
+ * SingleChain.set_target_covariance does (src/SingleChain.py:159-205). */
+enum {
+    BH_LAW_NOCORR = 0,        /* Targets.py:105-115 */
+    BH_LAW_NOCORR_SCALED = 1, /* Targets.py:117-129, needs yerr */
+    BH_LAW_EXP = 2,           /* Targets.py:131-148 */
+    BH_LAW_GAUSS = 3          /* Targets.py:150-173, needs rinv (n x n, row-major) + logdet_r */
+};
+enum { BH_TARGET_SWD = 0, BH_TARGET_RF = 1 };
+
+typedef struct bh_target_desc {
+    int32_t kind; /* BH_TARGET_SWD | BH_TARGET_RF */
+    int32_t law;  /* BH_LAW_* */
+    int32_t n;    /* number of observed samples (periods or time samples) */
+    /* SWD (ignored for RF): */
+    int32_t iwave, igr, mode, flsph;
+    /* RF (ignored for SWD): */
+    int32_t waveno, nsamp;
+    double p_s_per_deg, gauss, fsamp, tshift, nsv;
+    /* observed data, HOST pointers, copied by bh_targets_set: */
+    const double *x;    /* [n] periods [s] (SWD) -- for RF the time axis is implied by fsamp/tshift */
+    const double *yobs; /* [n] */
+    const double *yerr; /* [n] or NULL (only BH_LAW_NOCORR_SCALED reads it) */
+    const double *rinv; /* [n*n] or NULL (only BH_LAW_GAUSS reads it) */
+    double logdet_r;    /* ln|R| for BH_LAW_GAUSS */
+} bh_target_desc;
+
+/* Register nt <= BH_MAX_TARGETS targets (constant data is copied to the device). */
+int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *targets);
+
+/* For each of B models: run every registered target's forward model, then
+ *   logL[b]            = sum_t -1/2 (n_t ln 2pi + ln|C_t|) - 1/2 d_t^T C_t^-1 d_t   (Targets.py:339-344)
+ *   misfits[b*(nt+1)+t]= RMS_t, last entry their sum                         (Targets.py:307-312)
+ *   err[b]             = 1 if any target's forward model failed (then logL = -1e15, misfits = 1e15)
+ * noise[b*2*nt + 2*t + {0,1}] = (corr, sigma) of target t (Targets.py:335).
+ * rho may be NULL: rho = 0.32*vp + 0.77 (Targets.py:319).
+ * ymod (optional, may be NULL): the synthetic data, target after target, [b][sum_t n_t].
+ */
+int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
+                      const int32_t *nlay, const double *h, const double *vp, const double *vs,
+                      const double *rho, ptrdiff_t stride_l, ptrdiff_t stride_b,
+                      const double *noise, double *logL, double *misfits, int32_t *err,
+                      double *ymod);
+
+/* ---- diagnostics -------------------------------------------------------------------------
+ * Evaluate one elementary function on the device for n float64 inputs (host pointers):
+ * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x.  Used by the tests to document how far the
+ * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
+int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
+
+/* Instrumentation (off by default; bench.py and the tests turn it on).
+ *   timing:   HIP events are recorded on the stream the kernels are launched on, around each
+ *             kernel family of a *_batch call.  bh_last_timing() waits for them and returns the
+ *             span first-kernel-start -> last-kernel-end (total_ms) and the time inside each
+ *             family: family_ms[0] dispersion (swd), [1] receiver function, [2] likelihood.
+ *   counting: the dispersion kernels add up their secular-function evaluations; bh_last_neval()
+ *             returns the count of the most recent call (the flop model of SURVEY.md 8(d) is
+ *             layer-propagator steps = evaluations x (nlay-1)). */
+int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
+int bh_last_timing(bh_engine *e, double *total_ms, double family_ms[3]);
+int bh_last_neval(bh_engine *e, uint64_t *neval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
