@@ -1,0 +1,12 @@
+"""bayhunter_amd -- MI355X-native forward-model + likelihood engine behind BayHunter's plugin
+surface.  Importing this package does not touch the GPU; the native library is
+loaded when the first `Engine` is created."""
+from .engine import Engine, EngineError, default_engine, pack_models  # noqa: F401
+from .Models import Model  # noqa: F401
+from .surf96_modsw import SurfDisp  # noqa: F401
+from .rfmini_modrf import RFminiModRF  # noqa: F401
+from .Targets import (ObservedData, ModeledData, Valuation, SingleTarget, JointTarget,  # noqa: F401
+                      RayleighDispersionPhase, RayleighDispersionGroup, LoveDispersionPhase,
+                      LoveDispersionGroup, PReceiverFunction, SReceiverFunction, select_noise_laws)
+
+__version__ = "0.1.0"

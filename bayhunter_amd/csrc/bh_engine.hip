@@ -447,6 +447,8 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
             if (!rc) rc = swd_supported(e, d.n, d.iwave, d.mode, d.flsph);
         } else if (!rc && d.kind == BH_TARGET_RF) {
             rc = rf_args_ok(e, d.nsamp, d.n, d.gauss, d.fsamp, d.waveno);
+        } else if (!rc && d.kind == BH_TARGET_USER) {
+            /* likelihood-only target */
         } else if (!rc) {
             rc = fail(e, BH_EINVAL, "unknown target kind");
         }
@@ -501,6 +503,8 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     int rc;
     if ((rc = check_models(e, B, Lmax, sl, sb))) return rc;
     if (e->nt < 1) return fail(e, BH_EINVAL, "no targets registered (bh_targets_set)");
+    for (const auto &T : e->targets)
+        if (T.d.kind == BH_TARGET_USER) return fail(e, BH_EINVAL, "a BH_TARGET_USER target has no forward model: use bh_loglike_batch");
     if (!nlay || !h || !vp || !vs || !noise || !logL || !misfits || !err) return fail(e, BH_EINVAL, "null argument");
     if (B == 0) return BH_OK;
     HIPCHK(e, hipSetDevice(e->device));
@@ -566,6 +570,64 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         HIPCHK(e, hipMemcpyAsync(misfits, misf_d, (size_t)B * (nt + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipMemcpyAsync(err, err_d, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (ymod) HIPCHK(e, hipMemcpyAsync(ymod, ymod_d, (size_t)B * ldy * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+    }
+    return BH_OK;
+}
+
+int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const double *ymod,
+                     const int32_t *failflags, const double *noise, double *logL, double *misfits,
+                     int32_t *err)
+{
+    int rc;
+    if (!e) return BH_EINVAL;
+    if (e->nt < 1) return fail(e, BH_EINVAL, "no targets registered (bh_targets_set)");
+    if (B < 0 || !ymod || !noise || !logL || !misfits || !err) return fail(e, BH_EINVAL, "null argument");
+    if (B == 0) return BH_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int nt = e->nt, ldy = e->ldy;
+    const bool host = (memspace != BH_DEVICE);
+    hipStream_t st = (!host && stream) ? (hipStream_t)stream : e->stream;
+    if ((rc = ensure(e, e->err_t, (size_t)nt * B * sizeof(int32_t)))) return rc;
+    LikeKernelArgs la{};
+    la.B = B; la.nt = nt; la.ldy = ldy;
+    la.ymod = ymod; la.noise = noise; la.logL = logL; la.misfits = misfits; la.err = err;
+    la.err_t = failflags;
+    if (host) {
+        if ((rc = ensure(e, e->ymod, (size_t)B * ldy * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->noise, (size_t)B * 2 * nt * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->logL, (size_t)B * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->misfits, (size_t)B * (nt + 1) * sizeof(double)))) return rc;
+        if ((rc = ensure(e, e->errb, (size_t)B * sizeof(int32_t)))) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->ymod.p, ymod, (size_t)B * ldy * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(e, hipMemcpyAsync(e->noise.p, noise, (size_t)B * 2 * nt * sizeof(double), hipMemcpyHostToDevice, st));
+        if (failflags) HIPCHK(e, hipMemcpyAsync(e->err_t.p, failflags, (size_t)nt * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        la.ymod = (const double *)e->ymod.p; la.noise = (const double *)e->noise.p;
+        la.logL = (double *)e->logL.p; la.misfits = (double *)e->misfits.p; la.err = (int32_t *)e->errb.p;
+        la.err_t = failflags ? (const int32_t *)e->err_t.p : nullptr;
+    }
+    if (!la.err_t) {
+        HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
+        la.err_t = (const int32_t *)e->err_t.p;
+    }
+    for (int t = 0; t < nt; ++t) {
+        TargetHost &T = e->targets[(size_t)t];
+        la.t[t].law = T.d.law; la.t[t].n = T.d.n; la.t[t].off = T.off;
+        la.t[t].yobs = (const double *)T.yobs.p;
+        la.t[t].yerr_scaled = (const double *)T.yerr_scaled.p;
+        la.t[t].rinv = (const double *)T.rinv.p;
+        la.t[t].logdet_extra = T.logdet_extra;
+    }
+    call_begin(e, st);
+    ev_begin(e, 2, st);
+    bh_launch_like(la, st);
+    ev_end(e, 2, st);
+    call_end(e, st);
+    HIPCHK(e, hipGetLastError());
+    if (host) {
+        HIPCHK(e, hipMemcpyAsync(logL, la.logL, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipMemcpyAsync(misfits, la.misfits, (size_t)B * (nt + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipMemcpyAsync(err, la.err, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(e, hipStreamSynchronize(st));
     }
     return BH_OK;

@@ -24,7 +24,7 @@ WAVE_LOVE, WAVE_RAYLEIGH = 1, 2
 VEL_PHASE, VEL_GROUP = 0, 1
 RF_P, RF_SV = 0, 1
 LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
-TARGET_SWD, TARGET_RF = 0, 1
+TARGET_SWD, TARGET_RF, TARGET_USER = 0, 1, 2
 MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
 
 _d = C.POINTER(C.c_double)
@@ -85,10 +85,11 @@ def load_library():
     L.bh_targets_set.argtypes = [vp, C.c_int, C.POINTER(TargetDesc)]
     L.bh_evaluate_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                     C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, vp]
+    L.bh_loglike_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation",
                  "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                 "bh_evaluate_batch", "bh_probe_math"):
+                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 1:
         raise EngineError("ABI version mismatch")
@@ -99,7 +100,7 @@ def load_library():
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation",
                     "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                    "bh_evaluate_batch", "bh_probe_math")
+                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math")
 
 
 def _f64(a):
@@ -135,7 +136,7 @@ class Engine(object):
                               "(this package has no CPU fallback)" % (device, rc))
         self._h = h
         self.device = int(device)
-        self._keep = None  # host arrays referenced by the last bh_targets_set call
+        self._owner = None  # the JointTarget whose targets are currently registered
         self.ntargets = 0
         self.ldy = 0
 
@@ -184,7 +185,7 @@ class Engine(object):
         h = _f64(h)
         if layout == "layer_major":   # [Lmax, B]
             Lmax, B = h.shape
-            sl, sb = B, 1
+            sl, sb = max(B, 1), 1
         elif layout == "model_major":  # [B, Lmax]
             B, Lmax = h.shape
             sl, sb = 1, Lmax
@@ -269,6 +270,27 @@ class Engine(object):
                                               _ptr(vp), _ptr(vs), _ptr(rho), sl, sb, _ptr(noise),
                                               _ptr(logL), _ptr(misf), _ptr(err), _ptr(ymod)))
         return (logL, misf, err, ymod) if want_ymod else (logL, misf, err)
+
+    def loglike_batch(self, ymod, noise, fail=None):
+        """Likelihood of caller-supplied synthetics ymod[B, ldy] (see bh_loglike_batch)."""
+        ymod = _f64(ymod)
+        B = ymod.shape[0]
+        nt = self.ntargets
+        if ymod.shape != (B, self.ldy):
+            raise ValueError("ymod must have shape (B, %d)" % self.ldy)
+        noise = _f64(noise)
+        if noise.shape != (B, 2 * nt):
+            raise ValueError("noise must have shape (B, 2*ntargets)")
+        if fail is not None:
+            fail = np.ascontiguousarray(fail, dtype=np.int32)
+            if fail.shape != (nt, B):
+                raise ValueError("fail must have shape (ntargets, B)")
+        logL = np.zeros(B)
+        misf = np.zeros((B, nt + 1))
+        err = np.zeros(B, dtype=np.int32)
+        self._check(self._L.bh_loglike_batch(self._h, HOST, None, B, _ptr(ymod), _ptr(fail), _ptr(noise),
+                                             _ptr(logL), _ptr(misf), _ptr(err)))
+        return logL, misf, err
 
     def probe_math(self, op, x):
         x = _f64(x).ravel()

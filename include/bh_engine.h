@@ -117,10 +117,12 @@ enum {
     BH_LAW_EXP = 2,           /* Targets.py:131-148 */
     BH_LAW_GAUSS = 3          /* Targets.py:150-173, needs rinv (n x n, row-major) + logdet_r */
 };
-enum { BH_TARGET_SWD = 0, BH_TARGET_RF = 1 };
+/* BH_TARGET_USER: observed data + noise law only, no forward model in the engine (synthetics
+ * come from a user plugin through bh_loglike_batch; bh_evaluate_batch refuses such a set). */
+enum { BH_TARGET_SWD = 0, BH_TARGET_RF = 1, BH_TARGET_USER = 2 };
 
 typedef struct bh_target_desc {
-    int32_t kind; /* BH_TARGET_SWD | BH_TARGET_RF */
+    int32_t kind; /* BH_TARGET_SWD | BH_TARGET_RF | BH_TARGET_USER */
     int32_t law;  /* BH_LAW_* */
     int32_t n;    /* number of observed samples (periods or time samples) */
     /* SWD (ignored for RF): */
@@ -152,6 +154,14 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
                       const double *rho, ptrdiff_t stride_l, ptrdiff_t stride_b,
                       const double *noise, double *logL, double *misfits, int32_t *err,
                       double *ymod);
+
+/* Likelihood only, on synthetics the caller already has (e.g. produced by a user-supplied
+ * forward-modelling plugin, Targets.py:201-202 `update_plugin`): same outputs as
+ * bh_evaluate_batch, with ymod[b][sum_t n_t] given and fail[t*B + b] != 0 marking a failed
+ * forward model of target t (may be NULL = none failed). */
+int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const double *ymod,
+                     const int32_t *fail, const double *noise, double *logL, double *misfits,
+                     int32_t *err);
 
 /* ---- diagnostics -------------------------------------------------------------------------
  * Evaluate one elementary function on the device for n float64 inputs (host pointers):

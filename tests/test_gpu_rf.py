@@ -1,0 +1,64 @@
+"""Parity of the HIP receiver-function path (bh_rf_batch) with the oracle and the reference
+golden vectors.  north_star tolerance: 1e-4 on RF amplitudes; asserted here: 1e-9 of the peak."""
+import numpy as np
+import pytest
+
+from conftest import golden, st3
+from bayhunter_amd.synth import synth_models
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.mark.parametrize("nsamp,fsamp,nkeep", [(512, 5.0, 201), (2048, 20.0, 1024), (64, 2.0, 32), (4096, 40.0, 2048)])
+@pytest.mark.parametrize("waveno", [0, 1])
+def test_random_ragged_models_match_oracle(engine, oracle, nsamp, fsamp, nkeep, waveno):
+    rs = np.random.RandomState(nsamp + waveno)
+    nlay, h, vp, vs, rho = synth_models(rs, 70, 21, lvz_frac=0.3, ragged=True)
+    rf = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, 2.5, nsamp, fsamp, 5.0, waveno, nkeep)
+    orf = oracle.rf_batch(nlay, h.T, vp.T, vs.T, rho.T, 6.4, 2.5, nsamp, fsamp, 5.0, waveno, nkeep)
+    peak = np.abs(orf).max(axis=1, keepdims=True)
+    assert np.max(np.abs(rf - orf) / peak) <= TOL
+
+
+@pytest.mark.parametrize("axis", ["n201", "n1024"])
+def test_reference_golden_vectors(engine, axis):
+    g = golden("rf_golden.npz")
+    tx = g["x_" + axis]
+    nsamp = 2 ** int(np.ceil(np.log2(tx.size * 2)))
+    fsamp = 1.0 / float(np.round(tx[1] - tx[0], 4))
+    for ic, (gauss, p) in enumerate(g["gauss_p"]):
+        for iw in range(2):
+            rf = engine.rf_batch(g["nlay"], g["h"], g["vp"], g["vs"], g["rho"], p, gauss, nsamp, fsamp, -tx[0], iw, tx.size,
+                                 layout="model_major")
+            ref = g["y_" + axis][:, ic, iw]
+            assert np.max(np.abs(rf - ref)) <= 1e-4 * np.abs(ref).max()   # north_star bar
+            assert np.max(np.abs(rf - ref)) <= TOL * np.abs(ref).max()     # what is achieved
+
+
+@pytest.mark.parametrize("ref,waveno", [("prf", 0), ("srf", 1)])
+def test_tutorial_files(engine, ref, waveno):
+    x, y = st3(ref)
+    h = np.array([[5., 23., 8., 0.]]).T; vs = np.array([[2.7, 3.6, 3.8, 4.4]]).T; vp = vs * 1.73
+    rf = engine.rf_batch(np.array([4]), h, vp, vs, vp * 0.32 + 0.77, 6.4, 1.0, 512, 5.0, 5.0, waveno, 201)
+    assert np.max(np.abs(rf[0] - y)) <= 1e-4
+
+
+def test_quality_factors_and_nsv(engine, oracle):
+    rs = np.random.RandomState(9)
+    nlay, h, vp, vs, rho = synth_models(rs, 6, 8)
+    qp = rs.uniform(100, 900, h.shape); qs = rs.uniform(50, 400, h.shape)
+    rf = engine.rf_batch(nlay, h, vp, vs, rho, 5.0, 1.5, 512, 5.0, 5.0, 0, 300, qp=qp, qs=qs, nsv=3.1)
+    for b in range(6):
+        z = np.concatenate(([0], np.cumsum(h[:, b])[:-1]))
+        k = vp[0, b] / vs[0, b]
+        o = oracle.synrf(z, vp[:, b], vs[:, b], rho[:, b], qp[:, b], qs[:, b], 5.0, 1.5, 512, 5.0, 5.0, 3.1,
+                         (2 - k ** 2) / (2 - 2 * k ** 2), "P")[2][:300]
+        assert np.max(np.abs(rf[b] - o)) <= TOL * np.abs(o).max()
+
+
+def test_bad_arguments_fail_loudly(engine):
+    from bayhunter_amd.engine import EngineError
+    nlay, h, vp, vs, rho = synth_models(np.random.RandomState(1), 2, 3)
+    with pytest.raises(EngineError):
+        engine.rf_batch(nlay, h, vp, vs, rho, 6.4, 1.0, 500, 5.0, 5.0, 0, 100)  # nsamp not 2^k

@@ -1,0 +1,86 @@
+"""Host-side logic of the plugin mirror (no GPU): model parametrisation, sampling parameters,
+covariance-law selection, dense-vs-closed-form likelihood identities."""
+import numpy as np
+import pytest
+
+from conftest import golden
+import bayhunter_amd as bh
+from bayhunter_amd import Targets
+
+
+def test_get_vp_vs_h_matches_reference():
+    g = golden("model_golden.npz")
+    L = g["nuclei"].shape[1] // 2
+    for i in range(g["n"].size):
+        n = g["n"][i]
+        model = np.concatenate((g["nuclei"][i, :n], g["nuclei"][i, L:L + n]))
+        mantle = list(g["mantle"]) if g["use_mantle"][i] else None
+        vp, vs, h = bh.Model.get_vp_vs_h(model, g["vpvs"][i], mantle)
+        assert np.array_equal(vp, g["vp"][i, :n]) and np.array_equal(vs, g["vs"][i, :n])
+        assert np.array_equal(h, g["h"][i, :n])
+        # NaN-padded storage form (SingleChain.py:207-241) splits the same way
+        assert bh.Model.split_modelparams(g["nuclei"][i])[0] == n
+
+
+def test_pack_batch_layout():
+    g = golden("model_golden.npz")
+    L = g["nuclei"].shape[1] // 2
+    models = [np.concatenate((g["nuclei"][i, :g["n"][i]], g["nuclei"][i, L:L + g["n"][i]])) for i in range(6)]
+    nlay, h, vp, vs = bh.Model.pack_batch(models, g["vpvs"][:6])
+    assert h.shape == (nlay.max(), 6)
+    for b in range(6):
+        assert np.array_equal(vp[:nlay[b], b], g["vs"][b, :nlay[b]] * g["vpvs"][b])
+        assert np.all(h[nlay[b]:, b] == 0)
+
+
+def test_rf_sampling_parameters():
+    p = bh.RFminiModRF(np.linspace(-5, 35, 201), "prf")
+    assert (p.fsamp, p.tshft, p.nsamp) == (5.0, 5.0, 512)
+    p = bh.RFminiModRF(-5 + 0.05 * np.arange(1024), "srf")
+    assert (round(p.fsamp, 9), p.tshft, p.nsamp) == (20.0, 5.0, 2048)
+    assert p.modelparams["wtype"] == "SV"
+    with pytest.raises(ValueError):
+        bh.RFminiModRF(np.array([0., 1., 2.5]), "prf")
+
+
+def test_surfdisp_tags_and_resampling_grid():
+    assert bh.SurfDisp(np.arange(1, 5.), "rdispgr").get_surftags("ldispph") == (1, 0)
+    with pytest.raises(ReferenceError):
+        bh.SurfDisp(np.arange(1, 5.), "xdisp")
+    s = bh.SurfDisp(np.linspace(1.5, 70, 80), "rdispph")
+    assert s.obsx_int.size == 60 and s.obsx_int[0] == 1.5 and s.obsx_int[-1] == 70
+
+
+def test_noise_law_selection_rules():
+    x = np.linspace(1, 30, 10); y = np.ones(10)
+    tx = np.linspace(-5, 35, 201)
+    t_sw = bh.RayleighDispersionPhase(x, y)
+    t_sw_err = bh.RayleighDispersionPhase(x, y, yerr=np.full(10, 0.1))
+    t_rf = bh.PReceiverFunction(tx, np.zeros(201))
+    t_rf2 = bh.PReceiverFunction(tx, np.zeros(201))
+    t_sw2 = bh.LoveDispersionPhase(x, y)
+    bh.select_noise_laws([t_sw, t_sw_err, t_rf, t_rf2, t_sw2], corrfix=[True, True, True, False, True],
+                         noise_corr=[0, 0, 0.9, (0.2, 0.9), 0.5], rcond=1e-6)
+    assert [t.noise_law for t in (t_sw, t_sw_err, t_rf, t_rf2, t_sw2)] == \
+        ["nocorr", "nocorr_scalederr", "gauss", "exp", "exp"]
+    assert t_rf.valuation.corr_inv.shape == (201, 201)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64])
+def test_closed_forms_equal_dense_forms(oracle, n):
+    """App. C of SURVEY.md: the O(n) expressions the engine uses == the reference's dense ones."""
+    rs = np.random.RandomState(n)
+    d = rs.normal(0, 0.1, n); yobs = rs.normal(0, 1, n); ymod = yobs + d
+    r, s = 0.63, 0.07
+    v = Targets.Valuation()
+    if n > 1:
+        c_inv, ld = v.get_covariance_exp(r, s, n)
+        dense = v.get_likelihood(yobs, ymod, c_inv, ld)
+        assert abs(dense - oracle.loglike_dense(2, ymod, yobs, r, s)) <= 1e-10 * abs(dense)
+    edge = d[0] ** 2 + d[-1] ** 2 if n > 1 else d[0] ** 2
+    phi = ((1 + r * r) * np.sum(d * d) - r * r * edge - 2 * r * np.sum(d[:-1] * d[1:])) / (s * s * (1 - r * r))
+    closed = -0.5 * (n * np.log(2 * np.pi) + 2 * n * np.log(s) + (n - 1) * np.log(1 - r * r)) - 0.5 * phi
+    assert abs(closed - oracle.loglike_dense(2, ymod, yobs, r, s)) <= 1e-9 * abs(closed)
+    yerr = rs.uniform(0.01, 0.05, n)
+    c_inv, ld = v.get_covariance_nocorr_scalederr(s, n, yerr)
+    assert abs(v.get_likelihood(yobs, ymod, c_inv, ld) - oracle.loglike_dense(1, ymod, yobs, 0, s, yerr=yerr)) <= 1e-9 * abs(ld)

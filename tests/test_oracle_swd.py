@@ -1,0 +1,101 @@
+"""The CPU oracle (oracle/swd_oracle.c) against the reference: golden vectors produced by the
+reference's own SurfDisp.run_model + compiled surfdisp96.f (tests/golden/gen_golden.py) and the
+reference's own tutorial files st3_*.dat.  These pin the oracle (-m "not gpu")."""
+import numpy as np
+import pytest
+
+from conftest import golden, st3
+
+REFS = {"rdispph": (2, 0), "rdispgr": (2, 1), "ldispph": (1, 0), "ldispgr": (1, 1)}
+
+
+def run(oracle, h, vp, vs, rho, per, iwave, igr, mode=1, flsph=0):
+    cg = np.zeros(per.size)
+    err = oracle.surfdisp96(h, vp, vs, rho, h.size, flsph, iwave, mode, igr, per.size, per, cg)
+    return err, cg
+
+
+@pytest.mark.parametrize("pset", ["p21", "p30"])
+def test_oracle_matches_reference_golden(oracle, pset):
+    g = golden("swd_golden.npz")
+    per = g["x_" + pset]
+    nbad = 0
+    for im in range(g["nlay"].size):
+        n = g["nlay"][im]
+        for ir, ref in enumerate(g["refs"]):
+            iwave, igr = REFS[str(ref)]
+            err, cg = run(oracle, g["h"][im, :n], g["vp"][im, :n], g["vs"][im, :n], g["rho"][im, :n], per, iwave, igr)
+            assert (err == 0) == bool(g["ok_" + pset][im, ir])
+            if err == 0:
+                # gate of SURVEY.md 7.2 is 1e-9 / 1e-6; the restatement is in fact bit-identical
+                assert np.array_equal(cg, g["y_" + pset][im, ir]), (im, ref)
+            else:
+                nbad += 1
+    assert nbad > 0  # the fixture contains models surf96 fails on
+
+
+def test_oracle_resampling_path_inputs(oracle):
+    """>60 periods: the reference computes on linspace-60 and interpolates (surf96_modsw.py:35-43)."""
+    g = golden("swd_golden.npz")
+    per = g["x_p80"]
+    p60 = np.linspace(per.min(), per.max(), 60)
+    for im in (0, 5, 72):
+        n = g["nlay"][im]
+        for ir, ref in enumerate(g["refs"]):
+            if not g["ok_p80"][im, ir]:
+                continue
+            iwave, igr = REFS[str(ref)]
+            err, cg = run(oracle, g["h"][im, :n], g["vp"][im, :n], g["vs"][im, :n], g["rho"][im, :n], p60, iwave, igr)
+            assert err == 0
+            assert np.array_equal(np.interp(per, p60, cg), g["y_p80"][im, ir])
+
+
+@pytest.mark.parametrize("tag,kw", [("mode2", dict(mode=2)), ("sph", dict(flsph=1))])
+def test_oracle_options(oracle, tag, kw):
+    g = golden("swd_golden.npz")
+    per = g["x_p30"]
+    for jj, im in enumerate(g["sub_idx"]):
+        n = g["nlay"][im]
+        for ir, ref in enumerate(g["refs"]):
+            iwave, igr = REFS[str(ref)]
+            err, cg = run(oracle, g["h"][im, :n], g["vp"][im, :n], g["vs"][im, :n], g["rho"][im, :n], per, iwave, igr, **kw)
+            assert (err == 0) == bool(g["ok_" + tag][jj, ir])
+            if err == 0:
+                assert np.array_equal(cg, g["y_" + tag][jj, ir])
+
+
+@pytest.mark.parametrize("ref", sorted(REFS))
+def test_oracle_matches_tutorial_files(oracle, ref):
+    """tutorial/observed/st3_*.dat: 4-decimal files written by the reference's own forward code."""
+    x, y = st3(ref)
+    h = np.array([5., 23., 8., 0.]); vs = np.array([2.7, 3.6, 3.8, 4.4]); vp = vs * 1.73
+    err, cg = run(oracle, h, vp, vs, vp * 0.32 + 0.77, x, *REFS[ref])
+    assert err == 0
+    assert np.max(np.abs(cg - y)) <= 5.1e-5
+
+
+def test_oracle_matches_compiled_reference_random(oracle):
+    """Where oracle/_ref exists (it travels with the repo): bit-equality on fresh random models."""
+    from oracle import refshim
+    if not refshim.available():
+        pytest.skip("oracle/_ref not built (needs the build container)")
+    rs = np.random.RandomState(5)
+    per = np.linspace(2, 60, 30)
+    for it in range(60):
+        L = rs.randint(2, 22)
+        vs = np.sort(rs.uniform(2.0, 4.8, L))
+        if it % 4 == 0 and L > 3:
+            vs[rs.randint(1, L - 1)] *= 0.85
+        h = rs.uniform(0.5, 8, L); h[-1] = 0
+        vp = vs * rs.uniform(1.5, 2.0); rho = 0.32 * vp + 0.77
+        for iwave, igr in REFS.values():
+            a = np.zeros(30); b = np.zeros(30)
+            ea = oracle.surfdisp96(h, vp, vs, rho, L, 0, iwave, 1, igr, 30, per, a)
+            eb = refshim.surfdisp96(h, vp, vs, rho, L, 0, iwave, 1, igr, 30, per, b)
+            assert ea == eb and np.array_equal(a, b)
+    for _ in range(200):
+        L = rs.randint(2, 12)
+        vs = np.sort(rs.uniform(2.0, 4.8, L)); h = rs.uniform(0.5, 8, L); vp = vs * 1.75; rho = 0.32 * vp + 0.77
+        om = 2 * np.pi / rs.uniform(1, 60); c = rs.uniform(1.7, 5.0)
+        for ifunc in (1, 2):
+            assert oracle.dltar(om / c, om, ifunc, h, vp, vs, rho) == refshim.dltar(om / c, om, ifunc, h, vp, vs, rho)
