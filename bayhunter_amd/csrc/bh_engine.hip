@@ -43,9 +43,13 @@ struct bh_engine {
     std::vector<TargetHost> targets;
     // instrumentation
     bool timing = false, counting = false;
-    hipEvent_t ev[8] = {};
-    bool ev_used[4] = {};
-    bool have_events = false;
+    // one EventSet per timed *_batch call since the last bh_timing_reset()
+    struct EventSet {
+        hipEvent_t ev[8];
+        bool used[4];
+    };
+    std::vector<EventSet> evsets; // pool (events are reused after a reset)
+    size_t ncalls = 0;            // sets in use
     uint64_t last_neval = 0;
     bool neval_pending = false;
 };
@@ -154,35 +158,43 @@ int stage_models(bh_engine *e, int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb, cons
     return BH_OK;
 }
 
+bh_engine::EventSet *cur_set(bh_engine *e)
+{
+    return (e->timing && e->ncalls > 0) ? &e->evsets[e->ncalls - 1] : nullptr;
+}
 void ev_begin(bh_engine *e, int fam, hipStream_t st)
 {
-    if (!e->timing) return;
-    if (!e->ev_used[fam]) { // first launch of this family in the call
-        (void)hipEventRecord(e->ev[2 * fam], st);
-        e->ev_used[fam] = true;
+    bh_engine::EventSet *s = cur_set(e);
+    if (!s) return;
+    if (!s->used[fam]) { // first launch of this family in the call
+        (void)hipEventRecord(s->ev[2 * fam], st);
+        s->used[fam] = true;
     }
 }
 void ev_end(bh_engine *e, int fam, hipStream_t st)
 {
-    if (!e->timing) return;
-    (void)hipEventRecord(e->ev[2 * fam + 1], st);
+    bh_engine::EventSet *s = cur_set(e);
+    if (s) (void)hipEventRecord(s->ev[2 * fam + 1], st);
 }
 void call_begin(bh_engine *e, hipStream_t st)
 {
-    for (bool &u : e->ev_used) u = false;
-    e->have_events = false;
-    if (e->timing) {
-        (void)hipEventRecord(e->ev[6], st);
-        e->ev_used[3] = true;
-    }
     e->neval_pending = false;
+    if (!e->timing) return;
+    if (e->ncalls == e->evsets.size()) {
+        bh_engine::EventSet s{};
+        for (auto &ev : s.ev)
+            if (hipEventCreate(&ev) != hipSuccess) return; // timing silently unavailable
+        e->evsets.push_back(s);
+    }
+    bh_engine::EventSet &s = e->evsets[e->ncalls++];
+    for (bool &u : s.used) u = false;
+    (void)hipEventRecord(s.ev[6], st);
+    s.used[3] = true;
 }
 void call_end(bh_engine *e, hipStream_t st)
 {
-    if (e->timing) {
-        (void)hipEventRecord(e->ev[7], st);
-        e->have_events = true;
-    }
+    bh_engine::EventSet *s = cur_set(e);
+    if (s) (void)hipEventRecord(s->ev[7], st);
 }
 
 int swd_supported(bh_engine *e, int K, int iwave, int mode, int flsph)
@@ -272,11 +284,6 @@ int bh_engine_create(int device, bh_engine **out)
         delete e;
         return BH_EHIP;
     }
-    for (auto &ev : e->ev)
-        if (hipEventCreate(&ev) != hipSuccess) {
-            delete e;
-            return BH_EHIP;
-        }
     *out = e;
     return BH_OK;
 }
@@ -293,8 +300,9 @@ void bh_engine_destroy(bh_engine *e)
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv);
     }
-    for (auto &ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &s : e->evsets)
+        for (auto &ev : s.ev)
+            if (ev) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -317,19 +325,34 @@ int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting)
     return BH_OK;
 }
 
-int bh_last_timing(bh_engine *e, double *total_ms, double family_ms[3])
+int bh_timing_reset(bh_engine *e)
 {
     if (!e) return BH_EINVAL;
-    if (!e->have_events) return fail(e, BH_EINVAL, "no timed call (enable timing first)");
-    HIPCHK(e, hipEventSynchronize(e->ev[7]));
-    float ms = 0.f;
-    HIPCHK(e, hipEventElapsedTime(&ms, e->ev[6], e->ev[7]));
-    if (total_ms) *total_ms = ms;
-    for (int f = 0; f < 3; ++f) {
-        float fm = 0.f;
-        if (e->ev_used[f]) HIPCHK(e, hipEventElapsedTime(&fm, e->ev[2 * f], e->ev[2 * f + 1]));
-        if (family_ms) family_ms[f] = fm;
+    e->ncalls = 0;
+    return BH_OK;
+}
+
+int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3])
+{
+    if (!e) return BH_EINVAL;
+    double tot = 0.0, fam[3] = {0.0, 0.0, 0.0};
+    for (size_t i = 0; i < e->ncalls; ++i) {
+        bh_engine::EventSet &s = e->evsets[i];
+        HIPCHK(e, hipEventSynchronize(s.ev[7]));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, s.ev[6], s.ev[7]));
+        tot += ms;
+        for (int f = 0; f < 3; ++f) {
+            if (!s.used[f]) continue;
+            float fm = 0.f;
+            HIPCHK(e, hipEventElapsedTime(&fm, s.ev[2 * f], s.ev[2 * f + 1]));
+            fam[f] += fm;
+        }
     }
+    if (ncalls) *ncalls = (int)e->ncalls;
+    if (total_ms) *total_ms = tot;
+    if (family_ms)
+        for (int f = 0; f < 3; ++f) family_ms[f] = fam[f];
     return BH_OK;
 }
 

@@ -75,7 +75,8 @@ def load_library():
     L.bh_engine_stream.restype = vp
     L.bh_engine_synchronize.argtypes = [vp]
     L.bh_engine_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
-    L.bh_last_timing.argtypes = [vp, _d, _d]
+    L.bh_timing_reset.argtypes = [vp]
+    L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bh_swd_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_ssize_t,
                                C.c_ssize_t, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -88,7 +89,7 @@ def load_library():
     L.bh_loglike_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation",
-                 "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 1:
@@ -99,7 +100,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation",
-                    "bh_last_timing", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math")
 
 
@@ -167,12 +168,23 @@ class Engine(object):
     def set_instrumentation(self, timing=False, counting=False):
         self._check(self._L.bh_engine_set_instrumentation(self._h, int(timing), int(counting)))
 
-    def last_timing(self):
-        """(total_ms, {'swd': ms, 'rf': ms, 'like': ms}) of the most recent timed call."""
+    def timing_reset(self):
+        self._check(self._L.bh_timing_reset(self._h))
+
+    def timing_collect(self):
+        """(ncalls, total_ms, {'swd': ms, 'rf': ms, 'like': ms}) summed over the timed calls
+        since timing_reset(); waits for them to finish."""
+        n = C.c_int(0)
         tot = C.c_double(0)
         fam = (C.c_double * 3)()
-        self._check(self._L.bh_last_timing(self._h, C.byref(tot), fam))
-        return tot.value, {"swd": fam[0], "rf": fam[1], "like": fam[2]}
+        self._check(self._L.bh_timing_collect(self._h, C.byref(n), C.byref(tot), fam))
+        return n.value, tot.value, {"swd": fam[0], "rf": fam[1], "like": fam[2]}
+
+    def last_timing(self):
+        """(total_ms, families) of the calls since the last reset, then resets."""
+        n, tot, fam = self.timing_collect()
+        self.timing_reset()
+        return tot, fam
 
     def last_neval(self):
         v = C.c_uint64(0)

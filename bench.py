@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- forward-model + logL evaluations per second on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--batch B]
+
+A "step" is ONE pass of the hot path over one batch of B synthetic candidate models that are
+already resident in HBM: `bh_evaluate_batch` (C ABI, memspace = device) = every registered
+target's forward model + RMS misfits + log-likelihood for all B models.
+
+Workloads (BASELINE.json configs):
+  c2 (default, the configuration the metric is quoted on): joint Rayleigh + Love PHASE dispersion,
+     10-layer models, 30 periods linspace(2, 60, 30) s, batch = 4096 models / step / GPU,
+     uncorrelated noise law.
+  c3: c2 + P receiver function (Gauss a = 2.5, 1024 kept samples @ 20 Hz -> nsamp 2048,
+     p = 6.4 s/deg), exponential-correlated noise law on the RF.
+N > 1: one process per GPU (torchrun), independent batches per rank, no data-path collective
+(the path shards by model) -> "scaling": "weak"; barrier + max-over-ranks timing.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the Rayleigh dispersion
+kernel `swd_kernel<2>`): achieved = algorithmic bytes per launch / its average launch duration
+measured with HIP events on the launch stream during the timed region.  `cpu_baseline` is the
+oracle (the bit-exact CPU restatement of the reference, kind "port") timed on this box's host
+cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6    # CDNA4 FP64 vector peak; this path uses no MFMA
+# flop-equivalents per layer-propagator step: Rayleigh ~320, Love ~65
+FLOP_PER_LPS = {2: 320.0, 1: 65.0}
+NPOOL = 4                   # distinct batches rotated through the steps
+
+
+def build_workload(name, B, L, seed):
+    """Returns (targets for the engine, targets for the oracle, batches, noise) -- host arrays."""
+    from bayhunter_amd import engine as E
+    from bayhunter_amd.synth import synth_models, true_model, SWD_PERIODS, RF_TIME, SEED
+    rs = np.random.RandomState(seed)
+    batches = [synth_models(rs, B, L, lvz_frac=0.1) for _ in range(NPOOL)]
+    per = SWD_PERIODS
+    spec = [dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=2, igr=0, name="rdispph"),
+            dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=1, igr=0, name="ldispph")]
+    if name == "c3":
+        spec.append(dict(kind=E.TARGET_RF, law=E.LAW_EXP, n=RF_TIME.size, waveno=0, nsamp=2048, p=6.4,
+                         gauss=2.5, fsamp=20.0, tshift=5.0, name="prf"))
+    nt = len(spec)
+    noise = np.zeros((B, 2 * nt))
+    for t, s in enumerate(spec):
+        if s["law"] == E.LAW_EXP:
+            noise[:, 2 * t] = rs.uniform(0.35, 0.75, B)
+            noise[:, 2 * t + 1] = rs.uniform(1e-3, 0.05, B)
+        else:
+            noise[:, 2 * t + 1] = rs.uniform(0.005, 0.05, B)
+    return spec, batches, noise, true_model(L), np.random.RandomState(SEED + 2)
+
+
+def observed_data(eng, spec, truth, nrs):
+    """y_obs = engine forward model of the fixed 'true' model + N(0, sigma^2)."""
+    from bayhunter_amd import engine as E
+    nlay, h, vp, vs, rho = truth
+    for s in spec:
+        if s["kind"] == E.TARGET_SWD:
+            y, err = eng.swd_batch(nlay, h, vp, vs, rho, s["x"], s["iwave"], s["igr"])
+            assert err[0] == 0
+            s["yobs"] = y[0] + nrs.normal(0, 0.012, s["n"])
+        else:
+            y = eng.rf_batch(nlay, h, vp, vs, rho, s["p"], s["gauss"], s["nsamp"], s["fsamp"], s["tshift"],
+                             s["waveno"], s["n"])
+            s["yobs"] = y[0] + nrs.normal(0, 0.005, s["n"])
+
+
+def cpu_baseline(spec, batch, noise, workload):
+    """The oracle on this box's host cores, bounded to roughly 10-30 s of CPU work."""
+    from oracle import oracle as O
+    nlay, h, vp, vs, rho = batch
+    ht, vpt, vst, rhot = [np.ascontiguousarray(a.T) for a in (h, vp, vs, rho)]
+    ncores = os.cpu_count() or 1
+    probe = 16
+    t0 = time.perf_counter()
+    O.joint_batch(nlay[:probe], ht[:probe], vpt[:probe], vst[:probe], rhot[:probe], spec, noise[:probe], nthreads=1)
+    per_model = (time.perf_counter() - t0) / probe            # single-thread seconds per evaluation
+    n = int(max(4 * ncores, 20.0 / per_model))                # ~20 s of CPU work in total
+    reps = (n + nlay.size - 1) // nlay.size                   # tile the batch up to the sample size
+    if reps > 1:
+        nlay, ht, vpt, vst, rhot, noise = [np.concatenate([a] * reps)[:n] for a in (nlay, ht, vpt, vst, rhot, noise)]
+    n = min(n, nlay.size)
+    O.joint_batch(nlay[:ncores], ht[:ncores], vpt[:ncores], vst[:ncores], rhot[:ncores], spec, noise[:ncores], nthreads=ncores)
+    t0 = time.perf_counter()
+    O.joint_batch(nlay[:n], ht[:n], vpt[:n], vst[:n], rhot[:n], spec, noise[:n], nthreads=ncores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": ncores, "kind": "port",
+            "sample": "%d models of the %s batch, all targets + dense logL, OpenMP over models; "
+                      "1-thread rate %.1f evals/s" % (n, workload, 1.0 / per_model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torchrun (one rank per GPU)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from bayhunter_amd import engine as E
+    eng = E.Engine(local_rank)
+    B, L = args.batch, args.layers
+    spec, batches, noise, truth, nrs = build_workload(args.workload, B, L, seed=20260927 + 1000 * rank)
+    observed_data(eng, spec, truth, nrs)
+    eng.set_targets(spec)
+    nt = len(spec)
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_batches = [tuple(to_dev(a) for a in b) for b in batches]        # (nlay, h, vp, vs, rho) in HBM
+    d_noise = to_dev(noise)
+    d_logL = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_misf = torch.zeros((B, nt + 1), dtype=torch.float64, device=dev)
+    d_err = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        nl, h, vp, vs, rho = d_batches[i % NPOOL]
+        eng.evaluate_batch_dev(B, L, nl.data_ptr(), h.data_ptr(), vp.data_ptr(), vs.data_ptr(), rho.data_ptr(),
+                               B, 1, d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(),
+                               stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.set_instrumentation(timing=False, counting=True)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    neval = eng.last_neval() if args.warmup > 0 else 0   # secular evaluations of one step (last warmup)
+    eng.set_instrumentation(timing=True, counting=False)
+    eng.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ncalls, tot_ms, fam_ms = eng.timing_collect()
+    n_failed = int((d_err != 0).sum().item())
+    finite = bool(torch.isfinite(d_logL).all().item())
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # dominant kernel: the dispersion family (one Rayleigh + one Love launch per step);
+        # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model
+        K = spec[0]["n"]
+        nswd = sum(1 for s in spec if s["kind"] == E.TARGET_SWD)
+        bytes_per_launch = B * (4 * L * 8 + K * 8 + 4)
+        swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls) / max(1, nswd)
+        achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
+        out = {
+            "metric": "forward-model+logL evals/sec (batched 10-layer models)",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
+                                    "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF"}[args.workload],
+                       "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
+                       "parallelism": "models sharded one batch per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "swd_kernel (Rayleigh+Love dispersion, avg per launch)",
+                         "kernel_ms_per_launch": swd_ms_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "scalar FP64 recurrence: HBM is not the binding roof (SURVEY.md 8(d)); see fp64_valu"},
+            "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
+            "gpu_ms_per_step": tot_ms / max(1, ncalls),
+            "failed_models_last_step": n_failed, "logL_finite": finite,
+        }
+        if neval:
+            # flop model of SURVEY.md 8(d): layer-propagator steps x flop-equivalents per step;
+            # the counter covers all dispersion launches of a step, split by the per-type ratio
+            lps = neval * (L - 1)
+            flop = lps * (0.5 * FLOP_PER_LPS[2] + 0.5 * FLOP_PER_LPS[1])
+            out["fp64_valu"] = {"secular_evals_per_step": neval, "layer_steps_per_step": lps,
+                                "achieved_tflops": flop / (fam_ms["swd"] / max(1, ncalls) * 1e-3) / 1e12,
+                                "peak_tflops": FP64_VALU_PEAK_TF,
+                                "note": "flop-equivalents (Rayleigh 320, Love 65 per layer step, ~equal eval counts)"}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, args.workload)
+            except Exception as ex:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,14 +171,17 @@ int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
 
 /* Instrumentation (off by default; bench.py and the tests turn it on).
  *   timing:   HIP events are recorded on the stream the kernels are launched on, around each
- *             kernel family of a *_batch call.  bh_last_timing() waits for them and returns the
- *             span first-kernel-start -> last-kernel-end (total_ms) and the time inside each
- *             family: family_ms[0] dispersion (swd), [1] receiver function, [2] likelihood.
+ *             kernel family of every *_batch call made after bh_timing_reset().  Nothing is
+ *             synchronised until bh_timing_collect(), which waits for the events and returns the
+ *             number of calls, the SUM over those calls of the span first-kernel-start ->
+ *             last-kernel-end (total_ms) and of the time inside each kernel family:
+ *             family_ms[0] dispersion (swd), [1] receiver function, [2] likelihood.
  *   counting: the dispersion kernels add up their secular-function evaluations; bh_last_neval()
  *             returns the count of the most recent call (the flop model of SURVEY.md 8(d) is
  *             layer-propagator steps = evaluations x (nlay-1)). */
 int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
-int bh_last_timing(bh_engine *e, double *total_ms, double family_ms[3]);
+int bh_timing_reset(bh_engine *e);
+int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3]);
 int bh_last_neval(bh_engine *e, uint64_t *neval);
 
 #ifdef __cplusplus

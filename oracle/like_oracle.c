@@ -8,6 +8,10 @@
  */
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "oracle.h"
 
 /* Targets.py:99-103 */
@@ -78,4 +82,67 @@ double bho_loglike_dense(int law, int n, const double *ymod, const double *yobs,
     free(cinv);
     double part = -0.5 * ((double)n * log(2.0 * M_PI) + logdet);
     return part - madist / 2.0;
+}
+
+void bho_joint_batch(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                     const double *vs, const double *rho, int nt, const bho_target *targets,
+                     const double *noise, double *logL, double *misfits, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    int nmax = 1, nsmax = 1;
+    for (int t = 0; t < nt; ++t) {
+        if (targets[t].n > nmax) nmax = targets[t].n;
+        if (targets[t].kind == 1 && targets[t].nsamp > nsmax) nsmax = targets[t].nsamp;
+    }
+    if (nsmax > nmax) nmax = nsmax;
+#pragma omp parallel
+    {
+        double *ymod = (double *)malloc(sizeof(double) * (size_t)nmax);
+        double *zz = (double *)malloc(sizeof(double) * (size_t)Lmax * 3);
+        double *qp = zz + Lmax, *qs = qp + Lmax;
+#pragma omp for schedule(dynamic, 4)
+        for (int ib = 0; ib < B; ++ib) {
+            const int n = nlay[ib];
+            const double *hh = h + (size_t)ib * Lmax, *pvp = vp + (size_t)ib * Lmax;
+            const double *pvs = vs + (size_t)ib * Lmax, *prh = rho + (size_t)ib * Lmax;
+            double ll = 0.0, joint = 0.0;
+            int failed = 0;
+            for (int t = 0; t < nt && !failed; ++t) {
+                const bho_target *T = &targets[t];
+                if (T->kind == 0) {
+                    float fh[100], fvp[100], fvs[100], frho[100];
+                    for (int i = 0; i < n; ++i) {
+                        fh[i] = (float)hh[i]; fvp[i] = (float)pvp[i]; fvs[i] = (float)pvs[i]; frho[i] = (float)prh[i];
+                    }
+                    if (bho_surfdisp96(fh, fvp, fvs, frho, n, 0, T->iwave, 1, T->igr, T->n, T->x, ymod, NULL)) failed = 1;
+                } else {
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i) { zz[i] = acc; acc += hh[i]; qp[i] = 500.; qs[i] = 225.; }
+                    double k = pvp[0] / pvs[0];
+                    double poisson = (2 - k * k) / (2 - 2 * (k * k));
+                    bho_synrf(T->nsamp, T->fsamp, T->tshift, T->p_s_per_deg, T->gauss, pvs[0], poisson,
+                              T->waveno, n, zz, pvp, pvs, prh, qp, qs, ymod);
+                }
+                if (failed) break;
+                const double corr = noise[(size_t)ib * 2 * nt + 2 * t], sigma = noise[(size_t)ib * 2 * nt + 2 * t + 1];
+                ll += bho_loglike_dense(T->law, T->n, ymod, T->yobs, T->yerr, corr, sigma, NULL, 0.0);
+                double r = bho_rms(T->n, ymod, T->yobs);
+                misfits[(size_t)ib * (nt + 1) + t] = r;
+                joint += r;
+            }
+            if (failed) { /* Targets.py:325-328 */
+                logL[ib] = -1e15;
+                for (int t = 0; t <= nt; ++t) misfits[(size_t)ib * (nt + 1) + t] = 1e15;
+            } else {
+                logL[ib] = ll;
+                misfits[(size_t)ib * (nt + 1) + nt] = joint;
+            }
+        }
+        free(ymod);
+        free(zz);
+    }
 }

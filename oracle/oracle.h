@@ -83,6 +83,23 @@ double bho_loglike_dense(int law, int n, const double *ymod, const double *yobs,
 /* Targets.py:99-103 */
 double bho_rms(int n, const double *ymod, const double *yobs);
 
+/* JointTarget.evaluate (Targets.py:314-347) for B models, OpenMP over models: per target the
+ * forward model above + the dense likelihood.  This is bench.py's cpu_baseline ("port"). */
+typedef struct bho_target {
+    int32_t kind;  /* 0 SWD, 1 RF */
+    int32_t law;   /* BHO_LAW_* (Gauss law not supported here) */
+    int32_t n;
+    int32_t iwave, igr;              /* SWD */
+    int32_t waveno, nsamp;           /* RF */
+    double p_s_per_deg, gauss, fsamp, tshift;
+    const double *x;                 /* [n] periods (SWD) */
+    const double *yobs;              /* [n] */
+    const double *yerr;              /* [n] or NULL */
+} bho_target;
+void bho_joint_batch(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                     const double *vs, const double *rho, int nt, const bho_target *targets,
+                     const double *noise, double *logL, double *misfits, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,46 @@ def loglike_dense(law, ymod, yobs, corr, sigma, yerr=None, rinv=None, logdet_r=0
                                    rinv_p, float(logdet_r))
 
 
+class Target(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("law", C.c_int32), ("n", C.c_int32), ("iwave", C.c_int32),
+                ("igr", C.c_int32), ("waveno", C.c_int32), ("nsamp", C.c_int32),
+                ("p_s_per_deg", C.c_double), ("gauss", C.c_double), ("fsamp", C.c_double),
+                ("tshift", C.c_double), ("x", _d), ("yobs", _d), ("yerr", _d)]
+
+
+def joint_batch(nlay, h, vp, vs, rho, targets, noise, nthreads=0):
+    """targets: list of dicts (kind, law, n, iwave, igr, waveno, nsamp, p, gauss, fsamp, tshift,
+    x, yobs, yerr).  h.. are [B, Lmax].  Returns (logL[B], misfits[B, nt+1])."""
+    h, vp, vs, rho = [np.ascontiguousarray(a, dtype=np.float64) for a in (h, vp, vs, rho)]
+    B, Lmax = h.shape
+    nlay = np.ascontiguousarray(nlay, dtype=np.int32)
+    nt = len(targets)
+    arr = (Target * nt)()
+    keep = []
+    for i, d in enumerate(targets):
+        t = arr[i]
+        t.kind, t.law, t.n = int(d["kind"]), int(d["law"]), int(d["n"])
+        t.iwave, t.igr = int(d.get("iwave", 2)), int(d.get("igr", 0))
+        t.waveno, t.nsamp = int(d.get("waveno", 0)), int(d.get("nsamp", 0))
+        t.p_s_per_deg, t.gauss = float(d.get("p", 6.4)), float(d.get("gauss", 1.0))
+        t.fsamp, t.tshift = float(d.get("fsamp", 1.0)), float(d.get("tshift", 0.0))
+        for key in ("x", "yobs", "yerr"):
+            v = d.get(key)
+            if v is not None:
+                v = np.ascontiguousarray(v, dtype=np.float64)
+                keep.append(v)
+                setattr(t, key, _pd(v))
+    noise = np.ascontiguousarray(noise, dtype=np.float64)
+    logL = np.zeros(B)
+    misf = np.zeros((B, nt + 1))
+    fn = lib().bho_joint_batch
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, _i32, _d, _d, _d, _d, C.c_int, C.POINTER(Target), _d, _d, _d, C.c_int]
+    fn(B, Lmax, nlay.ctypes.data_as(_i32), _pd(h), _pd(vp), _pd(vs), _pd(rho), nt, arr, _pd(noise),
+       _pd(logL), _pd(misf), int(nthreads))
+    return logL, misf
+
+
 def rms(ymod, yobs):
     ymod = np.ascontiguousarray(ymod, dtype=np.float64)
     yobs = np.ascontiguousarray(yobs, dtype=np.float64)
