@@ -12,6 +12,37 @@
 
 #define BH_WAVE 64
 
+// ---- IEEE division with the denominator-only work factored out ----------------------------------
+// hipcc expands the f64 `a / b` to   d = div_scale(b), n = div_scale(a), r = rcp(d),
+// two Newton steps on r, q = n*r, rem = fma(-d, q, n), div_fmas(rem, r, q), div_fixup.
+// When neither operand needs the power-of-two pre-scaling (both magnitudes in
+// [2^-400, 2^400] here, far inside the hardware's trigger points) d = b, n = a, div_fmas is a
+// plain fma and div_fixup returns its input, so  bh_quot(a, b, bh_rcp_refined(b))  is the SAME
+// instruction sequence and returns the same bits as a / b -- but the five denominator-only
+// instructions can be shared by several divisions or hoisted out of a dependent chain.
+// tests/test_gpu_swd.py::test_shared_reciprocal_division_is_exact checks this on the device.
+__device__ __forceinline__ double bh_rcp_refined(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double bh_quot(double a, double b, double r)
+{
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+// |x| in [2^-400, 2^400]  (biased exponent 623..1423); false for 0, denormals, inf, NaN
+__device__ __forceinline__ bool bh_div_safe(double x)
+{
+    const unsigned ex = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    return (ex - 623u) <= 800u;
+}
+
 struct SwdKernelArgs {
     int B, Lmax, K, igr;
     const int32_t *nlay;
@@ -24,10 +55,27 @@ struct SwdKernelArgs {
     unsigned long long *neval; // optional global counter of secular evaluations (may be null)
 };
 
-struct RfModelConsts; // rf_kernel.hip
-
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
 size_t bh_swd_lds_bytes(int Lmax, int K);
+
+// group kernel: G lanes per model, all dispersion targets of a call in one launch
+struct SwdTarget {
+    int iwave, igr, K, ldv;
+    const double *periods;
+    double *vel;  // [B][ldv] (+ column offset already applied)
+    int32_t *err; // [B]
+};
+struct SwdMultiArgs {
+    int B, Lmax, ntargets;
+    const int32_t *nlay;
+    const double *h, *vp, *vs, *rho;
+    ptrdiff_t sl, sb;
+    unsigned long long *neval;
+    SwdTarget t[8];
+};
+int bh_swd_pick_group(int B, int ntargets, int Lmax);
+size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax);
+void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
 
 struct RfKernelArgs {
     int B, Lmax, nsamp, nkeep, waveno;

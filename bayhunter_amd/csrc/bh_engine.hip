@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -43,6 +44,7 @@ struct bh_engine {
     std::vector<TargetHost> targets;
     // instrumentation
     bool timing = false, counting = false;
+    int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
         hipEvent_t ev[8];
@@ -217,10 +219,10 @@ int launch_swd(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, p
     a.sl = sl; a.sb = sb; a.periods = periods_dev; a.vel = vel; a.ldv = ldv; a.err = err;
     a.neval = nullptr;
     if (e->counting) {
-        int rc = ensure(e, e->counter, sizeof(unsigned long long));
+        int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
         if (rc) return rc;
         if (!e->neval_pending) {
-            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, sizeof(unsigned long long), st));
+            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
             e->neval_pending = true;
         }
         a.neval = (unsigned long long *)e->counter.p;
@@ -228,6 +230,59 @@ int launch_swd(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, p
     if (bh_swd_lds_bytes(Lmax, K) > 160 * 1024) return fail(e, BH_EINVAL, "model too deep for LDS");
     ev_begin(e, 0, st);
     bh_launch_swd(a, iwave, st);
+    ev_end(e, 0, st);
+    HIPCHK(e, hipGetLastError());
+    return BH_OK;
+}
+
+struct SwdJob {
+    int K, iwave, igr, ldv;
+    const double *periods_dev;
+    double *vel;
+    int32_t *err;
+};
+
+// All dispersion targets of one call.  Small batches go to the group kernel (G lanes per model,
+// one launch for all targets); batches that fill the chip by themselves use one lane per model.
+int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
+                    ptrdiff_t sb, int njobs, const SwdJob *jobs)
+{
+    if (B == 0 || njobs == 0) return BH_OK;
+    int G = e->force_group > 0 ? e->force_group : bh_swd_pick_group(B, njobs, Lmax);
+    int kmax = 0;
+    for (int j = 0; j < njobs; ++j) kmax = jobs[j].K > kmax ? jobs[j].K : kmax;
+    while (G > 1 && bh_swd_group_lds_bytes(G, Lmax, kmax) > 64 * 1024) G += 1; // fewer models per wave
+    if (G > 32) G = 1;
+    if (G <= 1) {
+        for (int j = 0; j < njobs; ++j) {
+            int rc = launch_swd(e, st, B, Lmax, m, sl, sb, jobs[j].K, jobs[j].periods_dev, jobs[j].iwave,
+                                jobs[j].igr, jobs[j].vel, jobs[j].ldv, jobs[j].err);
+            if (rc) return rc;
+        }
+        return BH_OK;
+    }
+    SwdMultiArgs a{};
+    a.B = B; a.Lmax = Lmax; a.ntargets = 0;
+    a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.sl = sl; a.sb = sb;
+    a.neval = nullptr;
+    if (e->counting) {
+        int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
+        if (rc) return rc;
+        if (!e->neval_pending) {
+            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
+            e->neval_pending = true;
+        }
+        a.neval = (unsigned long long *)e->counter.p;
+    }
+    for (int j = 0; j < njobs; ++j) {
+        if (jobs[j].K == 0) continue;
+        SwdTarget &t = a.t[a.ntargets++];
+        t.iwave = jobs[j].iwave; t.igr = jobs[j].igr; t.K = jobs[j].K; t.ldv = jobs[j].ldv;
+        t.periods = jobs[j].periods_dev; t.vel = jobs[j].vel; t.err = jobs[j].err;
+    }
+    if (a.ntargets == 0) return BH_OK;
+    ev_begin(e, 0, st);
+    bh_launch_swd_group(a, G, st);
     ev_end(e, 0, st);
     HIPCHK(e, hipGetLastError());
     return BH_OK;
@@ -284,7 +339,17 @@ int bh_engine_create(int device, bh_engine **out)
         delete e;
         return BH_EHIP;
     }
+    if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     *out = e;
+    return BH_OK;
+}
+
+int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model)
+{
+    if (!e) return BH_EINVAL;
+    if (lanes_per_model < 0 || lanes_per_model > 32)
+        return fail(e, BH_EINVAL, "lanes per model must be 0 (auto) or 1..32");
+    e->force_group = lanes_per_model;
     return BH_OK;
 }
 
@@ -356,6 +421,15 @@ int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family
     return BH_OK;
 }
 
+int bh_debug_counters(bh_engine *e, uint64_t out[8])
+{
+    if (!e || !out) return BH_EINVAL;
+    if (!e->counter.p) return fail(e, BH_EINVAL, "counting was never enabled");
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, e->counter.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
 int bh_last_neval(bh_engine *e, uint64_t *neval)
 {
     if (!e || !neval) return BH_EINVAL;
@@ -384,7 +458,8 @@ int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, cons
         hipStream_t st = stream ? (hipStream_t)stream : e->stream;
         Staged m{nlay, h, vp, vs, rho, nullptr, nullptr};
         call_begin(e, st);
-        rc = launch_swd(e, st, B, Lmax, m, sl, sb, K, periods, iwave, igr, vel, K, err);
+        SwdJob job{K, iwave, igr, K, periods, vel, err};
+        rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, 1, &job);
         call_end(e, st);
         return rc;
     }
@@ -396,8 +471,8 @@ int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, cons
     if ((rc = ensure(e, e->errb, (size_t)B * sizeof(int32_t)))) return rc;
     HIPCHK(e, hipMemcpyAsync(e->periods.p, periods, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
     call_begin(e, st);
-    rc = launch_swd(e, st, B, Lmax, m, sl, sb, K, (const double *)e->periods.p, iwave, igr,
-                    (double *)e->vel.p, K, (int32_t *)e->errb.p);
+    SwdJob job{K, iwave, igr, K, (const double *)e->periods.p, (double *)e->vel.p, (int32_t *)e->errb.p};
+    rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, 1, &job);
     call_end(e, st);
     if (rc) return rc;
     HIPCHK(e, hipMemcpyAsync(vel, e->vel.p, (size_t)B * K * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -567,21 +642,28 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     LikeKernelArgs la{};
     la.B = B; la.nt = nt; la.ldy = ldy; la.ymod = ymod_d; la.err_t = (const int32_t *)e->err_t.p;
     la.noise = noise_d; la.logL = logL_d; la.misfits = misf_d; la.err = err_d;
+    SwdJob jobs[BH_MAX_TARGETS];
+    int njobs = 0;
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];
         const bh_target_desc &d = T.d;
         if (d.kind == BH_TARGET_SWD)
-            rc = launch_swd(e, st, B, Lmax, m, sl, sb, d.n, (const double *)T.x.p, d.iwave, d.igr,
-                            ymod_d + T.off, ldy, (int32_t *)e->err_t.p + (size_t)t * B);
-        else
-            rc = launch_rf(e, st, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp,
-                           d.tshift, d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
-        if (rc) return rc;
+            jobs[njobs++] = SwdJob{d.n, d.iwave, d.igr, ldy, (const double *)T.x.p, ymod_d + T.off,
+                                   (int32_t *)e->err_t.p + (size_t)t * B};
         la.t[t].law = d.law; la.t[t].n = d.n; la.t[t].off = T.off;
         la.t[t].yobs = (const double *)T.yobs.p;
         la.t[t].yerr_scaled = (const double *)T.yerr_scaled.p;
         la.t[t].rinv = (const double *)T.rinv.p;
         la.t[t].logdet_extra = T.logdet_extra;
+    }
+    if ((rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs))) return rc;
+    for (int t = 0; t < nt; ++t) {
+        TargetHost &T = e->targets[(size_t)t];
+        const bh_target_desc &d = T.d;
+        if (d.kind != BH_TARGET_RF) continue;
+        rc = launch_rf(e, st, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
+                       d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
+        if (rc) return rc;
     }
     ev_begin(e, 2, st);
     bh_launch_like(la, st);
@@ -662,9 +744,10 @@ int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out)
     if (n == 0) return BH_OK;
     int rc;
     HIPCHK(e, hipSetDevice(e->device));
-    if ((rc = ensure(e, e->probe_in, (size_t)n * sizeof(double)))) return rc;
+    const size_t nin = (op == 6 || op == 7) ? (size_t)2 * n : (size_t)n; // division probes read pairs
+    if ((rc = ensure(e, e->probe_in, nin * sizeof(double)))) return rc;
     if ((rc = ensure(e, e->probe_out, (size_t)n * sizeof(double)))) return rc;
-    HIPCHK(e, hipMemcpyAsync(e->probe_in.p, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->probe_in.p, in, nin * sizeof(double), hipMemcpyHostToDevice, e->stream));
     bh_launch_probe(op, n, (const double *)e->probe_in.p, (double *)e->probe_out.p, e->stream);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(out, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -105,8 +105,13 @@ __global__ void probe_kernel(int op, int n, const double *in, double *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double x = in[i];
+    const double x = (op < 6) ? in[i] : 0.0;
     double r;
+    if (op == 6 || op == 7) { // division probes: in = pairs (a, b)
+        const double a = in[2 * i], b = in[2 * i + 1];
+        out[i] = (op == 6) ? bh_quot(a, b, bh_rcp_refined(b)) : a / b;
+        return;
+    }
     switch (op) {
     case 0: r = sqrt(x); break;
     case 1: r = sin(x); break;

@@ -27,6 +27,7 @@
 //     reference exactly; only the device sin/cos/exp differ from the host
 //     libm in the last ulp.
 #include "bh_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -38,17 +39,84 @@ __device__ __forceinline__ bool signs_differ(double x, double y)
 }
 
 // LDS views -----------------------------------------------------------------------------------
-struct ModelLds {
-    const float *d, *a, *b, *rho; // each [Lmax][64], this lane's column pre-offset
-    __device__ __forceinline__ double D(int m) const { return (double)d[m * BH_WAVE]; }
-    __device__ __forceinline__ double A(int m) const { return (double)a[m * BH_WAVE]; }
-    __device__ __forceinline__ double Bv(int m) const { return (double)b[m * BH_WAVE]; }
-    __device__ __forceinline__ double R(int m) const { return (double)rho[m * BH_WAVE]; }
+// Model arrays in LDS as [array][layer][column]; S = number of columns (models) per wave.
+template <int S>
+struct ModelLdsT {
+    const float *d, *a, *b, *rho; // column pre-offset
+    __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
+    __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
+    __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }
+    __device__ __forceinline__ double D(int m) const { return (double)d[m * S]; }
+    __device__ __forceinline__ double A(int m) const { return (double)a[m * S]; }
+    __device__ __forceinline__ double Bv(int m) const { return (double)b[m * S]; }
+    __device__ __forceinline__ double R(int m) const { return (double)rho[m * S]; }
+};
+using ModelLds = ModelLdsT<BH_WAVE>;
+struct ModelLdsRt { // same, with the column count known only at run time
+    const float *d, *a, *b, *rho;
+    int S;
+    __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
+    __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
+    __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }
+    __device__ __forceinline__ double D(int m) const { return (double)d[m * S]; }
+    __device__ __forceinline__ double A(int m) const { return (double)a[m * S]; }
+    __device__ __forceinline__ double Bv(int m) const { return (double)b[m * S]; }
+    __device__ __forceinline__ double R(int m) const { return (double)rho[m * S]; }
 };
 
+// ---- range tracking for the shared-reciprocal divisions ------------------------------------------
+// The fast division route (bh_device.h) returns the bits of a plain IEEE division as long as the
+// operands lie in [2^-400, 2^400].  Checking that with a branch inside the layer recursion costs
+// more than it saves (an exec-mask branch is ~100 cycles on this chip), so the recursion only
+// TRACKS the smallest and largest magnitude it divided (two cheap min/max per operand, no
+// branch); after the whole recursion one test decides whether the value can be trusted, and the
+// (never observed in practice) out-of-range case re-runs the recursion with plain divisions.
+struct DivRange {
+    double lo, hi;
+    __device__ __forceinline__ void reset() { lo = 1.0; hi = 1.0; }
+    __device__ __forceinline__ void see(double a) { lo = fmin(lo, a); hi = fmax(hi, a); } // a >= 0
+    __device__ __forceinline__ bool ok() const
+    {
+        return lo >= 3.8725919148493183e-121 /* 2^-400 */ && hi <= 2.5822498780869086e+120 /* 2^400 */;
+    }
+};
+
+// One layer of the Love recursion (surfdisp96.f:758-767) given the layer terms.
+// EXACT = true: the reference's operations verbatim.  EXACT = false: the three divisions take
+// the shared-reciprocal route (rx = bh_rcp_refined(xmu)) and report their operand range.
+template <bool EXACT>
+__device__ __forceinline__ void love_step(double &e1, double &e2, double cosq, double y, double z,
+                                          double xmu, double rx, DivRange &dr)
+{
+    const double e10 = e1 * cosq + e2 * xmu * z;
+    double e20;
+    if (EXACT) {
+        e20 = e1 * y / xmu + e2 * cosq;
+    } else {
+        const double num = e1 * y;
+        dr.see(fabs(num));
+        dr.see(xmu);
+        e20 = bh_quot(num, xmu, rx) + e2 * cosq;
+    }
+    const double a10 = fabs(e10), a20 = fabs(e20);
+    double xnor = fmax(a10, a20);
+    if (xnor < 1.0e-40) xnor = 1.0;
+    if (EXACT) {
+        e1 = e10 / xnor;
+        e2 = e20 / xnor;
+    } else {
+        dr.see(fmin(a10, a20));
+        dr.see(xnor);
+        const double r = bh_rcp_refined(xnor);
+        e1 = bh_quot(e10, xnor, r);
+        e2 = bh_quot(e20, xnor, r);
+    }
+}
+
 // ---- Love: SH Thomson-Haskell (surfdisp96.f:710-769) ----------------------------------------
+template <bool EXACT>
 __device__ double love_secular(double wvno, double omega, const ModelLds &md, int mmax, int llw,
-                               int mtop)
+                               int mtop, DivRange &dr)
 {
     double beta1 = md.Bv(mmax - 1);
     double rho1 = md.R(mmax - 1);
@@ -87,14 +155,7 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
                 y = sinq / rb;
                 z = rb * sinq;
             }
-            const double e10 = e1 * cosq + e2 * xmu * z;
-            const double e20 = e1 * y / xmu + e2 * cosq;
-            double xnor = fabs(e10);
-            const double ynor = fabs(e20);
-            if (ynor > xnor) xnor = ynor;
-            if (xnor < 1.0e-40) xnor = 1.0;
-            e1 = e10 / xnor;
-            e2 = e20 / xnor;
+            love_step<EXACT>(e1, e2, cosq, y, z, xmu, EXACT ? 0.0 : bh_rcp_refined(xmu), dr);
         }
     }
     return e1;
@@ -164,11 +225,20 @@ __device__ __forceinline__ void layer_products(double p, double q, double ra, do
     o.cosp = cosp;
 }
 
-// One layer of the Dunkin recursion: e <- normalise(e * CA(layer)).  CA is the 5x5 compound
-// matrix of surfdisp96.f:1024-1068 (`dnka`); its entries are formed with the reference's
-// operation order and consumed column by column so that only one column is live at a time.
-__device__ __forceinline__ void rayleigh_layer(double e[5], double wvno2, double gam, double gammk,
-                                               double rho, const LayerTerms &v)
+// The 19 distinct entries of the 5x5 Dunkin compound matrix CA of one layer
+// (surfdisp96.f:1024-1068, `dnka`), formed with the reference's operation order.  Stored as
+//   c[0..4]  = ca11 ca12 ca13 ca14 ca15          (ca55 = ca11, ca45 = ca12, ca25 = ca14)
+//   c[5..7]  = ca21 ca23 ca24                    (ca54 = ca21), ca22 = ca44 = c[8]
+//   c[8]     = ca22 (= cpcq)
+//   c[9..11] = ca41 ca42 ca43                    (ca52 = ca41)
+//   c[12..13]= ca51 ca53
+//   c[14..18]= ca31 ca32 ca33 ca34 ca35
+struct Ca19 {
+    double c[19];
+};
+
+__device__ __forceinline__ void rayleigh_ca19(Ca19 &o, double wvno2, double gam, double gammk,
+                                              double rho, const LayerTerms &v)
 {
     const double two = 2.0;
     const double gamm1 = gam - 1.0;
@@ -187,50 +257,86 @@ __device__ __forceinline__ void rayleigh_layer(double e[5], double wvno2, double
     const double ca22 = v.cpcq;
     const double ca23 = gammk * v.cpz - gamm1 * v.cqw;
     const double ca24 = -v.wz;
-    const double ca25 = ca14;
     const double ca41 = (gm1sq * v.cpy - gmgmk * v.cqx) * rho;
     const double ca42 = -v.xy;
     const double ca43 = gamm1 * v.cpy - gammk * v.cqx;
-    const double ca44 = ca22;
-    const double ca45 = ca12;
     const double ca51 =
         -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * v.xz + gm1sq * gm1sq * v.wy) * rho2;
-    const double ca52 = ca41;
     const double ca53 =
         -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * v.xz + gamm1 * gm1sq * v.wy) * rho;
-    const double ca54 = ca21;
-    const double ca55 = ca11;
     const double t = -two * wvno2;
-    const double ca31 = t * ca53;
-    const double ca32 = t * ca43;
-    const double ca33 = v.a0 + two * (v.cpcq - ca11);
-    const double ca34 = t * ca23;
-    const double ca35 = t * ca13;
-    // ee(i) = sum_j e(j)*ca(j,i), accumulated from 0.0 in j order (surfdisp96.f:836-842)
+    o.c[0] = ca11; o.c[1] = ca12; o.c[2] = ca13; o.c[3] = ca14; o.c[4] = ca15;
+    o.c[5] = ca21; o.c[6] = ca23; o.c[7] = ca24; o.c[8] = ca22;
+    o.c[9] = ca41; o.c[10] = ca42; o.c[11] = ca43;
+    o.c[12] = ca51; o.c[13] = ca53;
+    o.c[14] = t * ca53;
+    o.c[15] = t * ca43;
+    o.c[16] = v.a0 + two * (v.cpcq - ca11);
+    o.c[17] = t * ca23;
+    o.c[18] = t * ca13;
+}
+
+// normc (surfdisp96.f:995-1020): divide the 5-vector by its max-norm (floor 1e-40); the log()
+// the Fortran takes of the norm is never used.  max is order-independent, so a tree is used.
+// EXACT = false: the five divisions share one refined reciprocal and report their range.
+template <bool EXACT>
+__device__ __forceinline__ void normalize5(const double ee0, const double ee1, const double ee2,
+                                           const double ee3, const double ee4, double e[5],
+                                           DivRange &dr)
+{
+    const double a0 = fabs(ee0), a1 = fabs(ee1), a2 = fabs(ee2), a3 = fabs(ee3), a4 = fabs(ee4);
+    double t1 = fmax(fmax(fmax(a0, a1), fmax(a2, a3)), a4);
+    if (t1 < 1.0e-40) t1 = 1.0;
+    if (EXACT) {
+        e[0] = ee0 / t1;
+        e[1] = ee1 / t1;
+        e[2] = ee2 / t1;
+        e[3] = ee3 / t1;
+        e[4] = ee4 / t1;
+    } else {
+        dr.see(fmin(fmin(fmin(a0, a1), fmin(a2, a3)), a4));
+        dr.see(t1);
+        const double r = bh_rcp_refined(t1);
+        e[0] = bh_quot(ee0, t1, r);
+        e[1] = bh_quot(ee1, t1, r);
+        e[2] = bh_quot(ee2, t1, r);
+        e[3] = bh_quot(ee3, t1, r);
+        e[4] = bh_quot(ee4, t1, r);
+    }
+}
+
+// e <- normalise(e * CA): ee(i) = sum_j e(j)*ca(j,i) accumulated from 0.0 in j order
+// (surfdisp96.f:836-842), then normc (:995-1020; its log() result is never used).
+template <bool EXACT>
+__device__ __forceinline__ void rayleigh_apply(double e[5], const double *c, DivRange &dr)
+{
+    const double ca11 = c[0], ca12 = c[1], ca13 = c[2], ca14 = c[3], ca15 = c[4];
+    const double ca21 = c[5], ca23 = c[6], ca24 = c[7], ca22 = c[8];
+    const double ca41 = c[9], ca42 = c[10], ca43 = c[11], ca51 = c[12], ca53 = c[13];
+    const double ca31 = c[14], ca32 = c[15], ca33 = c[16], ca34 = c[17], ca35 = c[18];
+    const double ca25 = ca14, ca44 = ca22, ca45 = ca12, ca52 = ca41, ca54 = ca21, ca55 = ca11;
     double ee0 = 0.0, ee1 = 0.0, ee2 = 0.0, ee3 = 0.0, ee4 = 0.0;
     ee0 = ee0 + e[0] * ca11; ee0 = ee0 + e[1] * ca21; ee0 = ee0 + e[2] * ca31; ee0 = ee0 + e[3] * ca41; ee0 = ee0 + e[4] * ca51;
     ee1 = ee1 + e[0] * ca12; ee1 = ee1 + e[1] * ca22; ee1 = ee1 + e[2] * ca32; ee1 = ee1 + e[3] * ca42; ee1 = ee1 + e[4] * ca52;
     ee2 = ee2 + e[0] * ca13; ee2 = ee2 + e[1] * ca23; ee2 = ee2 + e[2] * ca33; ee2 = ee2 + e[3] * ca43; ee2 = ee2 + e[4] * ca53;
     ee3 = ee3 + e[0] * ca14; ee3 = ee3 + e[1] * ca24; ee3 = ee3 + e[2] * ca34; ee3 = ee3 + e[3] * ca44; ee3 = ee3 + e[4] * ca54;
     ee4 = ee4 + e[0] * ca15; ee4 = ee4 + e[1] * ca25; ee4 = ee4 + e[2] * ca35; ee4 = ee4 + e[3] * ca45; ee4 = ee4 + e[4] * ca55;
-    // normc (surfdisp96.f:995-1020): max-norm rescale; its log() result is never used.
-    double t1 = 0.0;
-    if (fabs(ee0) > t1) t1 = fabs(ee0);
-    if (fabs(ee1) > t1) t1 = fabs(ee1);
-    if (fabs(ee2) > t1) t1 = fabs(ee2);
-    if (fabs(ee3) > t1) t1 = fabs(ee3);
-    if (fabs(ee4) > t1) t1 = fabs(ee4);
-    if (t1 < 1.0e-40) t1 = 1.0;
-    e[0] = ee0 / t1;
-    e[1] = ee1 / t1;
-    e[2] = ee2 / t1;
-    e[3] = ee3 / t1;
-    e[4] = ee4 / t1;
+    normalize5<EXACT>(ee0, ee1, ee2, ee3, ee4, e, dr);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void rayleigh_layer(double e[5], double wvno2, double gam, double gammk,
+                                               double rho, const LayerTerms &v, DivRange &dr)
+{
+    Ca19 ca;
+    rayleigh_ca19(ca, wvno2, gam, gammk, rho, v);
+    rayleigh_apply<EXACT>(e, ca.c, dr);
 }
 
 // ---- Rayleigh: Dunkin compound-matrix secular function (surfdisp96.f:773-871) -----------------
+template <bool EXACT>
 __device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md, int mmax, int llw,
-                                   int mtop)
+                                   int mtop, DivRange &dr)
 {
     double e[5];
     LayerTerms v;
@@ -277,7 +383,7 @@ __device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md,
             const double p = ra * dpth;
             const double q = rb * dpth;
             layer_products(p, q, ra, rb, wvno, xka, xkb, dpth, v);
-            rayleigh_layer(e, wvno2, gam, gammk, rho1, v);
+            rayleigh_layer<EXACT>(e, wvno2, gam, gammk, rho1, v, dr);
         }
     }
     double result = e[0];
@@ -328,100 +434,32 @@ enum : int {
     ST_NEVF = 4   // forced midpoint after the estimate left the bracket (:594-598)
 };
 
-template <int IFUNC>
-__global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int ib = blockIdx.x * BH_WAVE + lane;
-    const bool valid = ib < A.B;
-    const int Lmax = A.Lmax;
-    const int K = A.K;
+// ---- the per-model search state machine -------------------------------------------------------
+// Everything the reference's driver (surfdisp96.f:172-357), getsol (:390-482) and nevill
+// (:557-686) keep between two secular-function evaluations, for the fundamental mode.
+// `advance(del)` consumes the value of the secular function at `ceval` and either finishes the
+// model or leaves the next phase velocity to evaluate in `ceval` (with `omega` current).
+template <int XSC> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+struct SearchT {
+    int XS = XSC;
+    // constants
+    double cc, cm, betmxd, dc, onea, one, twopi, pct;
+    bool group;
+    int K;
+    const double *per; // LDS
+    double *xl, *yl;   // LDS Neville tables, element j at [j*XS]
+    double *vel;       // this model's output row (global)
+    bool writer;       // this lane stores results (one lane per model)
+    // state
+    int k, root, st, ifirst, idir, nev, mnev, nctrl, errflag;
+    bool active;
+    double c1, c2, clow, del1, del2, del1st, c3, del3, ck, t1, omega, ceval;
+    float t1a, t1b;
+    unsigned int evals;
 
-    float *mdl = reinterpret_cast<float *>(smem);                       // [4][Lmax][64]
-    double *xs = reinterpret_cast<double *>(smem + (size_t)4 * Lmax * BH_WAVE * sizeof(float));
-    double *ys = xs + NEV_MAX * BH_WAVE;                                 // [11][64] each
-    double *per = ys + NEV_MAX * BH_WAVE;                                // [K]
-
-    for (int k = lane; k < K; k += BH_WAVE) per[k] = A.periods[k];
-
-    // ---- stage the model through LDS, rounding to binary32 like the f2py boundary -----------
-    const int mmax = valid ? A.nlay[ib] : 2;
-    int mtop = mmax; // wave-wide maximum layer count = loop bound of the secular functions
-    for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    __device__ __forceinline__ void set_period(int kk)
     {
-        const ptrdiff_t base = (ptrdiff_t)ib * A.sb;
-        for (int l = 0; l < Lmax; ++l) {
-            float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
-            if (valid && l < mmax) {
-                const ptrdiff_t o = base + (ptrdiff_t)l * A.sl;
-                fd = (float)A.h[o];
-                fa = (float)A.vp[o];
-                fb = (float)A.vs[o];
-                fr = (float)A.rho[o];
-            }
-            mdl[(0 * Lmax + l) * BH_WAVE + lane] = fd;
-            mdl[(1 * Lmax + l) * BH_WAVE + lane] = fa;
-            mdl[(2 * Lmax + l) * BH_WAVE + lane] = fb;
-            mdl[(3 * Lmax + l) * BH_WAVE + lane] = fr;
-        }
-    }
-    __syncthreads();
-    ModelLds md;
-    md.d = mdl + 0 * Lmax * BH_WAVE + lane;
-    md.a = mdl + 1 * Lmax * BH_WAVE + lane;
-    md.b = mdl + 2 * Lmax * BH_WAVE + lane;
-    md.rho = mdl + 3 * Lmax * BH_WAVE + lane;
-    double *xl = xs + lane; // element j at xl[j*64]
-    double *yl = ys + lane;
-
-    // ---- driver set-up (surfdisp96.f:124-217) ------------------------------------------------
-    const float b0 = md.b[0];
-    const int llw = (b0 <= 0.0f) ? 2 : 1;
-    float betmx = -1.e20f, betmn = 1.e20f;
-    int jmn = 0, jsol = 1;
-    for (int i = 0; i < mmax; ++i) {
-        const float bi = md.b[i * BH_WAVE], ai = md.a[i * BH_WAVE];
-        if (bi > 0.01f && bi < betmn) {
-            betmn = bi;
-            jmn = i;
-            jsol = 1;
-        } else if (bi <= 0.01f && ai < betmn) {
-            betmn = ai;
-            jmn = i;
-            jsol = 0;
-        }
-        if (bi > betmx) betmx = bi;
-    }
-    const float h32 = 0.005f;
-    const double one = 1.0e-2;
-    const double onea = (double)1.5f;
-    const double dc = fabs((double)0.005f);
-    const double twopi = 2.0 * 3.141592653589793;
-    const double pct = (double)0.01f; // `0.01*ss1` with a default-real literal (:623-626)
-    float cc1 = (jsol == 0) ? betmn : gtsolh_f32(md.a[jmn * BH_WAVE], md.b[jmn * BH_WAVE]);
-    cc1 = 0.95f * cc1;
-    cc1 = 0.90f * cc1;
-    const double cc = (double)cc1;
-    const double cm = cc;
-    const double betmxd = (double)betmx;
-    const bool group = A.igr > 0;
-
-    // ---- per-lane search state ----------------------------------------------------------------
-    int k = 0;        // period index
-    int root = 0;     // 0: root at t (or t/(1+h)), 1: second root at t/(1-h) for group velocity
-    int st = ST_FIRST;
-    int ifirst = 1;
-    bool active = valid && K > 0;
-    int errflag = 0;
-    double c1 = cc, c2 = 0.0, clow = cc, del1 = 0.0, del2 = 0.0, del1st = 0.0;
-    double c3 = 0.0, del3 = 0.0, ck = 0.0;
-    int idir = 1, nev = 1, mnev = 1, nctrl = 1;
-    float t1a = 0.f, t1b = 0.f;
-    double t1 = 1.0, omega = 1.0;
-    unsigned int myevals = 0;
-
-    auto set_period = [&](int kk) {
+        const float h32 = 0.005f;
         double tt = per[kk];
         if (group) {
             t1a = (float)(tt / (double)(1.0f + h32));
@@ -432,25 +470,65 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
         }
         t1 = tt;
         omega = twopi / t1;
-    };
-    if (active) set_period(0);
-    double ceval = c1; // phase velocity the pending evaluation is for
+    }
 
-    while (__ballot(active) != 0ull) {
-        double del = 0.0;
-        if (active) {
-            const double wvno = omega / ceval;
-            if (IFUNC == 1)
-                del = love_secular(wvno, omega, md, mmax, llw, mtop);
-            else
-                del = rayleigh_secular(wvno, omega, md, mmax, llw, mtop);
-            ++myevals;
+    // driver set-up (surfdisp96.f:124-217): extremal velocities, start value
+    template <class MD>
+    __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
+                         double *xl_, double *yl_, double *vel_, bool writer_)
+    {
+        float betmx = -1.e20f, betmn = 1.e20f;
+        int jmn = 0, jsol = 1;
+        for (int i = 0; i < mmax; ++i) {
+            const float bi = md.Bf(i), ai = md.Af(i);
+            if (bi > 0.01f && bi < betmn) {
+                betmn = bi;
+                jmn = i;
+                jsol = 1;
+            } else if (bi <= 0.01f && ai < betmn) {
+                betmn = ai;
+                jmn = i;
+                jsol = 0;
+            }
+            if (bi > betmx) betmx = bi;
         }
-        if (!active) continue;
+        one = 1.0e-2;
+        onea = (double)1.5f;
+        dc = fabs((double)0.005f);
+        twopi = 2.0 * 3.141592653589793;
+        pct = (double)0.01f; // `0.01*ss1` with a default-real literal (:623-626)
+        float cc1 = (jsol == 0) ? betmn : gtsolh_f32(md.Af(jmn), md.Bf(jmn));
+        cc1 = 0.95f * cc1;
+        cc1 = 0.90f * cc1;
+        cc = (double)cc1;
+        cm = cc;
+        betmxd = (double)betmx;
+        group = igr > 0;
+        K = K_;
+        per = per_;
+        xl = xl_;
+        yl = yl_;
+        vel = vel_;
+        writer = writer_;
+        k = 0; root = 0; st = ST_FIRST; ifirst = 1;
+        active = valid && K > 0;
+        errflag = 0;
+        c1 = cc; c2 = 0.0; clow = cc; del1 = del2 = del1st = 0.0;
+        c3 = del3 = ck = 0.0;
+        idir = 1; nev = 1; mnev = 1; nctrl = 1;
+        t1a = t1b = 0.f;
+        t1 = 1.0; omega = 1.0;
+        evals = 0;
+        if (active) set_period(0);
+        ceval = c1;
+    }
 
-        // ---- state transition.  `todo`: 0 nothing, 1 prepare next bracket step, 2 root search
-        //      failed (iret = -1), 3 refinement finished with c3, 4 nevill top-of-loop,
-        //      5 nevill post-bracket section ---------------------------------------------------
+    __device__ void advance(double del)
+    {
+        ++evals;
+        // `todo`: 0 nothing, 1 prepare next bracket step, 2 root search failed (iret = -1),
+        // 3 refinement finished with c3, 4 nevill top-of-loop, 5 nevill post-bracket section,
+        // 6 root found
         int todo = 0;
         switch (st) {
         case ST_FIRST:
@@ -521,25 +599,25 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
                 bool halve = (s1 > ss2 || s2 > ss1 || nev == 0);
                 if (!halve) {
                     if (nev == 2) {
-                        xl[mnev * BH_WAVE] = c3;
-                        yl[mnev * BH_WAVE] = del3;
+                        xl[mnev * XS] = c3;
+                        yl[mnev * XS] = del3;
                     } else {
                         xl[0] = c1;
                         yl[0] = del1;
-                        xl[BH_WAVE] = c2;
-                        yl[BH_WAVE] = del2;
+                        xl[XS] = c2;
+                        yl[XS] = del2;
                         mnev = 1;
                     }
-                    const double ym = yl[mnev * BH_WAVE];
+                    const double ym = yl[mnev * XS];
                     for (int kk = 1; kk <= mnev; ++kk) {
                         const int j = mnev - kk;
-                        const double yj = yl[j * BH_WAVE];
+                        const double yj = yl[j * XS];
                         const double denom = ym - yj;
                         if (fabs(denom) < 1.0e-10 * fabs(ym)) {
                             halve = true;
                             break;
                         }
-                        xl[j * BH_WAVE] = (-yj * xl[(j + 1) * BH_WAVE] + ym * xl[j * BH_WAVE]) / denom;
+                        xl[j * XS] = (-yj * xl[(j + 1) * XS] + ym * xl[j * XS]) / denom;
                     }
                     if (!halve) {
                         c3 = xl[0];
@@ -568,7 +646,8 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
             if (root == 0) {
                 if (todo == 2) { // no root in the fundamental mode: err, zero-fill, stop (:313-354)
                     errflag = 1;
-                    for (int i = k; i < K; ++i) A.vel[(size_t)ib * A.ldv + i] = 0.0;
+                    if (writer)
+                        for (int i = k; i < K; ++i) vel[i] = 0.0;
                     active = false;
                 } else {
                     ck = c1;
@@ -600,7 +679,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
                         (1.0f / t1a - 1.0f / t1b) / (1.0f / (t1a * cc0) - 1.0f / (t1b * cc1s));
                     out = (double)gvel;
                 }
-                A.vel[(size_t)ib * A.ldv + k] = out;
+                if (writer) vel[k] = out;
                 k = k + 1;
                 if (k >= K) {
                     active = false;
@@ -628,12 +707,451 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
             st = ST_STEP;
         }
     }
-    if (valid) A.err[ib] = errflag;
+};
+using SearchRt = SearchT<0>;
+
+// =================================================================================================
+// Kernel 1: one lane = one model (G = 1).  Best when the batch alone fills the chip
+// (B*targets/64 >> 1024 waves); everything per-layer stays in registers.
+// =================================================================================================
+template <int IFUNC>
+__global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int ib = blockIdx.x * BH_WAVE + lane;
+    const bool valid = ib < A.B;
+    const int Lmax = A.Lmax;
+    const int K = A.K;
+
+    float *mdl = reinterpret_cast<float *>(smem);                       // [4][Lmax][64]
+    double *xs = reinterpret_cast<double *>(smem + (size_t)4 * Lmax * BH_WAVE * sizeof(float));
+    double *ys = xs + NEV_MAX * BH_WAVE;                                 // [11][64] each
+    double *per = ys + NEV_MAX * BH_WAVE;                                // [K]
+
+    for (int k = lane; k < K; k += BH_WAVE) per[k] = A.periods[k];
+
+    // ---- stage the model through LDS, rounding to binary32 like the f2py boundary -----------
+    const int mmax = valid ? A.nlay[ib] : 2;
+    int mtop = mmax; // wave-wide maximum layer count = loop bound of the secular functions
+    for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    {
+        const ptrdiff_t base = (ptrdiff_t)ib * A.sb;
+        for (int l = 0; l < Lmax; ++l) {
+            float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
+            if (valid && l < mmax) {
+                const ptrdiff_t o = base + (ptrdiff_t)l * A.sl;
+                fd = (float)A.h[o];
+                fa = (float)A.vp[o];
+                fb = (float)A.vs[o];
+                fr = (float)A.rho[o];
+            }
+            mdl[(0 * Lmax + l) * BH_WAVE + lane] = fd;
+            mdl[(1 * Lmax + l) * BH_WAVE + lane] = fa;
+            mdl[(2 * Lmax + l) * BH_WAVE + lane] = fb;
+            mdl[(3 * Lmax + l) * BH_WAVE + lane] = fr;
+        }
+    }
+    __syncthreads();
+    ModelLds md;
+    md.d = mdl + 0 * Lmax * BH_WAVE + lane;
+    md.a = mdl + 1 * Lmax * BH_WAVE + lane;
+    md.b = mdl + 2 * Lmax * BH_WAVE + lane;
+    md.rho = mdl + 3 * Lmax * BH_WAVE + lane;
+    const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
+
+    SearchT<BH_WAVE> S;
+    S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, true);
+
+    while (__ballot(S.active) != 0ull) {
+        if (!S.active) continue;
+        const double wvno = S.omega / S.ceval;
+        double del;
+        DivRange dr;
+        dr.reset();
+        if (IFUNC == 1)
+            del = love_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr);
+        else
+            del = rayleigh_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr);
+        if (!dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
+            if (IFUNC == 1)
+                del = love_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr);
+            else
+                del = rayleigh_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr);
+        }
+        S.advance(del);
+    }
+    if (valid) A.err[ib] = S.errflag;
     if (A.neval != nullptr) {
-        unsigned long long tot = myevals;
+        unsigned long long tot = S.evals;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
         if (lane == 0) atomicAdd(A.neval, tot);
     }
+}
+
+// =================================================================================================
+// Kernel 2: G lanes = one model (64/G models per wavefront), G chosen at launch time.
+// For batches that cannot fill the chip with one lane per model (B = 4096 gives only 64
+// wavefronts for 1024 SIMDs) the work of ONE secular evaluation is spread over the G lanes of
+// the model's group:
+//   phase A  lane li computes the layer terms of layers li, li+G, ... (the transcendental-heavy
+//            part: sqrt, sin/cos or exp, the compound-matrix entries) and parks them in LDS;
+//   phase B  the strictly sequential bottom-up recursion over the parked layers.
+//            Rayleigh, G >= 5: lane li owns component (li mod 5) of the 5-vector: it forms
+//            ee(i) = sum_j e(j)*ca(j,i) from column i of the parked matrix, the five values are
+//            exchanged through LDS, every lane takes the max-norm, divides its own component and
+//            the normalised vector is exchanged again.  Otherwise (Love, or G < 5) every lane of
+//            the group runs the whole recursion redundantly.
+//            Either way all lanes of a group end up with the same secular value and step the
+//            same search state; no broadcast is needed.
+// Every floating-point operation and its order are those of kernel 1: the kernels return
+// identical bits.  All dispersion targets of a call go into one launch (blockIdx.y = target),
+// so Rayleigh and Love wavefronts share the chip.
+// The workgroup is ONE wavefront: LDS operations of a wavefront execute in order, so the
+// __syncthreads() below only pin the compiler's ordering (the barrier instruction itself is
+// elided for a single-wave workgroup).
+// =================================================================================================
+constexpr int CA_STRIDE = 26;
+
+// Phase B of the group kernel, Rayleigh.  `cam` = this model's parked layers (column-major
+// 5x5 each), e = half-space vector on entry / surface vector on exit.
+//   PAR5   lane owns component `col`: one dot product per layer, the five results are exchanged
+//          with ds_bpermute (faster than an LDS write/read round trip: 56 vs 116 cycles) and every
+//          lane normalises all five itself -- one exchange per layer, no branch.
+//   !PAR5  every lane runs the full 5x5 product (used for G < 5 and for the exact re-run).
+//   RAGGED the wavefront holds models with different layer counts (or a water layer): layers a
+//          model does not have are masked with selects; the uniform case has no masking at all.
+template <bool PAR5, bool RAGGED, bool EXACT>
+__device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *cam, int col,
+                                                     int gbase, int mtop, int mmax, int llw,
+                                                     DivRange &dr)
+{
+    for (int m = (RAGGED ? mtop : mmax) - 2; m >= 0; --m) {
+        const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+        double en[5];
+        if (PAR5) {
+            const double *cc = cam + (size_t)m * CA_STRIDE + 5 * col;
+            double ee = 0.0;
+            ee = ee + e[0] * cc[0];
+            ee = ee + e[1] * cc[1];
+            ee = ee + e[2] * cc[2];
+            ee = ee + e[3] * cc[3];
+            ee = ee + e[4] * cc[4];
+            const double v0 = __shfl(ee, gbase + 0), v1 = __shfl(ee, gbase + 1), v2 = __shfl(ee, gbase + 2),
+                         v3 = __shfl(ee, gbase + 3), v4 = __shfl(ee, gbase + 4);
+            DivRange d2 = dr;
+            normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);
+            if (on) dr = d2;
+        } else {
+            const double *cc = cam + (size_t)m * CA_STRIDE;
+            double ee[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc = acc + e[j] * cc[5 * i + j];
+                ee[i] = acc;
+            }
+            DivRange d2 = dr;
+            normalize5<EXACT>(ee[0], ee[1], ee[2], ee[3], ee[4], en, d2);
+            if (on) dr = d2;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+    }
+}
+
+// Phase B of the group kernel, Love: parked per layer (cosq, y, z, xmu, rcp(xmu)).
+template <bool RAGGED, bool EXACT>
+__device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
+                                                 int mmax, int llw, DivRange &dr)
+{
+    for (int m = (RAGGED ? mtop : mmax) - 2; m >= 0; --m) {
+        const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+        const double2 *src = reinterpret_cast<const double2 *>(cam + (size_t)m * CA_STRIDE);
+        const double2 p0 = src[0], p1 = src[1], p2 = src[2];
+        double n1 = e1, n2 = e2;
+        DivRange d2 = dr;
+        love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
+        if (on) {
+            e1 = n1;
+            e2 = n2;
+            dr = d2;
+        }
+    }
+}
+ // doubles per parked layer: 25 (Rayleigh, column-major 5x5) / 4 (Love)
+
+__device__ __forceinline__ void park_ca25(double *dst, const Ca19 &c)
+{
+    // column i (0-based) at dst[5*i + j] = ca(j+1, i+1)
+    const double ca11 = c.c[0], ca12 = c.c[1], ca13 = c.c[2], ca14 = c.c[3], ca15 = c.c[4];
+    const double ca21 = c.c[5], ca23 = c.c[6], ca24 = c.c[7], ca22 = c.c[8];
+    const double ca41 = c.c[9], ca42 = c.c[10], ca43 = c.c[11], ca51 = c.c[12], ca53 = c.c[13];
+    const double ca31 = c.c[14], ca32 = c.c[15], ca33 = c.c[16], ca34 = c.c[17], ca35 = c.c[18];
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    d2[0] = make_double2(ca11, ca21);  d2[1] = make_double2(ca31, ca41);   // col 1: 11 21 31 41 51
+    d2[2] = make_double2(ca51, ca12);  d2[3] = make_double2(ca22, ca32);   // col 2: 12 22 32 42 52
+    d2[4] = make_double2(ca42, ca41);  d2[5] = make_double2(ca13, ca23);   // (ca52 = ca41) col 3: 13 23 33 43 53
+    d2[6] = make_double2(ca33, ca43);  d2[7] = make_double2(ca53, ca14);   // col 4: 14 24 34 44 54
+    d2[8] = make_double2(ca24, ca34);  d2[9] = make_double2(ca22, ca21);   // (ca44 = ca22, ca54 = ca21)
+    d2[10] = make_double2(ca15, ca14); d2[11] = make_double2(ca35, ca12);  // col 5: 15 25 35 45 55
+    d2[12] = make_double2(ca11, 0.0);                                      // (ca25=ca14, ca45=ca12, ca55=ca11)
+}
+
+__global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int Gflags)
+{
+    const int G = Gflags & 0xff;
+    const int MPW = BH_WAVE / G; // models per wavefront (lanes >= MPW*G idle along as clones of slot 0)
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const bool spare = lane >= MPW * G;
+    const int g = spare ? 0 : lane / G;  // model slot inside the wave
+    const int li = spare ? 0 : lane % G; // this lane's index inside the model's group
+    const int ib = blockIdx.x * MPW + g;
+    const bool valid = ib < A.B;
+    const int Lmax = A.Lmax;
+    const SwdTarget T = A.t[blockIdx.y];
+    const int K = T.K;
+    const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per workgroup
+
+    // LDS carve-up (all offsets multiples of 16 B)
+    double *ca = reinterpret_cast<double *>(smem);                 // [MPW][Lmax][CA_STRIDE]
+    double *xs = ca + (size_t)MPW * Lmax * CA_STRIDE;              // [11][MPW]
+    double *ys = xs + NEV_MAX * MPW;
+    double *per = ys + NEV_MAX * MPW;                              // [K]
+    float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
+
+    for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
+    // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
+    // layer-major input), binary32 rounding like the f2py boundary
+    for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
+        const int l = idx / MPW, mg = idx % MPW;
+        const int b = blockIdx.x * MPW + mg;
+        float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
+        if (b < A.B && l < A.nlay[b]) {
+            const ptrdiff_t o = (ptrdiff_t)b * A.sb + (ptrdiff_t)l * A.sl;
+            fd = (float)A.h[o];
+            fa = (float)A.vp[o];
+            fb = (float)A.vs[o];
+            fr = (float)A.rho[o];
+        }
+        mdl[(0 * Lmax + l) * MPW + mg] = fd;
+        mdl[(1 * Lmax + l) * MPW + mg] = fa;
+        mdl[(2 * Lmax + l) * MPW + mg] = fb;
+        mdl[(3 * Lmax + l) * MPW + mg] = fr;
+    }
+    const int mmax = valid ? A.nlay[ib] : 2;
+    int mtop = mmax;
+    for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    __syncthreads();
+    ModelLdsRt md;
+    md.S = MPW;
+    md.d = mdl + 0 * Lmax * MPW + g;
+    md.a = mdl + 1 * Lmax * MPW + g;
+    md.b = mdl + 2 * Lmax * MPW + g;
+    md.rho = mdl + 3 * Lmax * MPW + g;
+    const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
+    double *cam = ca + (size_t)g * Lmax * CA_STRIDE; // this model's parked layers
+    const bool par5 = (G >= 5) && !(Gflags & 0x100);
+    const int gbase = g * G; // first lane of this model's group
+    // one layer count for the whole wavefront and no water layer: the recursion needs no masking
+    const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
+    const int col = li % 5;                          // the 5-vector component this lane owns
+
+    SearchRt S;
+    S.XS = MPW;
+    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && !spare);
+
+    const bool prof = (A.neval != nullptr);
+    long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
+    while (__ballot(S.active) != 0ull) {
+        // All lanes take part in the evaluation (finished models compute on stale values).
+        if (prof) t0 = clock64();
+        const double omg = S.omega;
+        const double wvno = omg / S.ceval;
+        double del;
+        if (ifunc == 2) {
+            double omega = omg;
+            if (omega < 1.0e-4) omega = 1.0e-4;
+            const double wvno2 = wvno * wvno;
+            // ---- phase A: layer terms, one layer per lane (strided by G) -----------------------
+            for (int m = li; m <= mmax - 2; m += G) {
+                if (m >= llw - 1) {
+                    const double am = md.A(m), bm = md.Bv(m);
+                    const double xka = omega / am;
+                    const double xkb = omega / bm;
+                    const double t = bm / omega;
+                    const double gammk = 2.0 * t * t;
+                    const double gam = gammk * wvno2;
+                    double wvnop = wvno + xka;
+                    double wvnom = fabs(wvno - xka);
+                    const double ra = sqrt(wvnop * wvnom);
+                    wvnop = wvno + xkb;
+                    wvnom = fabs(wvno - xkb);
+                    const double rb = sqrt(wvnop * wvnom);
+                    const double dpth = md.D(m);
+                    const double rho1 = md.R(m);
+                    LayerTerms v;
+                    layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v);
+                    Ca19 c;
+                    rayleigh_ca19(c, wvno2, gam, gammk, rho1, v);
+                    park_ca25(cam + (size_t)m * CA_STRIDE, c);
+                }
+            }
+            // half-space E vector (surfdisp96.f:800-808), redundantly in every lane
+            double e[5];
+            {
+                const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
+                const double xka = omega / ah;
+                const double xkb = omega / bh;
+                double wvnop = wvno + xka;
+                double wvnom = fabs(wvno - xka);
+                const double ra = sqrt(wvnop * wvnom);
+                wvnop = wvno + xkb;
+                wvnom = fabs(wvno - xkb);
+                const double rb = sqrt(wvnop * wvnom);
+                const double t = bh / omega;
+                const double gammk = 2.0 * t * t;
+                const double gam = gammk * wvno2;
+                const double gamm1 = gam - 1.0;
+                const double rho1 = md.R(mmax - 1);
+                e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+                e[1] = -rho1 * ra;
+                e[2] = rho1 * (gamm1 - gammk * ra * rb);
+                e[3] = rho1 * rb;
+                e[4] = wvno2 - ra * rb;
+            }
+            __syncthreads();
+            if (prof) t1c = clock64();
+            // ---- phase B: the sequential recursion, bottom-up over the parked layers -----------
+            {
+                double e0[5] = {e[0], e[1], e[2], e[3], e[4]};
+                DivRange dr;
+                dr.reset();
+                if (par5) {
+                    if (ragged) rayleigh_chain_group<true, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<true, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                } else {
+                    if (ragged) rayleigh_chain_group<false, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<false, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                }
+                if (!dr.ok() && S.active) { // out-of-range operand somewhere: verbatim re-run (whole groups agree)
+                    e[0] = e0[0]; e[1] = e0[1]; e[2] = e0[2]; e[3] = e0[3]; e[4] = e0[4];
+                    rayleigh_chain_group<false, true, true>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                }
+            }
+            del = e[0];
+            if (llw != 1) { // water layer on top (surfdisp96.f:850-866)
+                const double xka = omega / md.A(0);
+                const double wvnop = wvno + xka;
+                const double wvnom = fabs(wvno - xka);
+                const double ra = sqrt(wvnop * wvnom);
+                const double dpth = md.D(0);
+                const double rho1 = md.R(0);
+                const double znul = 1.0e-5;
+                LayerTerms v;
+                layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v);
+                const double w0 = -rho1 * v.w;
+                del = v.cosp * e[0] + w0 * e[1];
+            }
+            __syncthreads();
+        } else {
+            const double omega = omg;
+            // ---- phase A (Love): cosq, y, z, xmu per layer ----------------------------------------
+            for (int m = li; m <= mmax - 2; m += G) {
+                if (m >= llw - 1) {
+                    const double beta1 = md.Bv(m);
+                    const double rho1 = md.R(m);
+                    const double dm = md.D(m);
+                    const double xmu = rho1 * beta1 * beta1;
+                    const double xkb = omega / beta1;
+                    const double wvnop = wvno + xkb;
+                    const double wvnom = fabs(wvno - xkb);
+                    const double rb = sqrt(wvnop * wvnom);
+                    const double q = dm * rb;
+                    double cosq, y, z;
+                    if (wvno < xkb) {
+                        double sinq;
+                        sincos(q, &sinq, &cosq);
+                        y = sinq / rb;
+                        z = -rb * sinq;
+                    } else if (wvno == xkb) {
+                        cosq = 1.0;
+                        y = dm;
+                        z = 0.0;
+                    } else {
+                        double fac = 0.0;
+                        if (q < 16.0) fac = exp(-2.0 * q);
+                        cosq = (1.0 + fac) * 0.5;
+                        const double sinq = (1.0 - fac) * 0.5;
+                        y = sinq / rb;
+                        z = rb * sinq;
+                    }
+                    double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE);
+                    dst[0] = make_double2(cosq, y);
+                    dst[1] = make_double2(z, xmu);
+                    dst[2] = make_double2(bh_rcp_refined(xmu), 0.0);
+                }
+            }
+            double e1, e2;
+            {
+                const double beta1 = md.Bv(mmax - 1);
+                const double rho1 = md.R(mmax - 1);
+                const double xkb = omega / beta1;
+                const double wvnop = wvno + xkb;
+                const double wvnom = fabs(wvno - xkb);
+                const double rb = sqrt(wvnop * wvnom);
+                e1 = rho1 * rb;
+                e2 = 1.0 / (beta1 * beta1);
+            }
+            __syncthreads();
+            if (prof) t1c = clock64();
+            {
+                const double s1 = e1, s2 = e2;
+                DivRange dr;
+                dr.reset();
+                if (ragged) love_chain_group<true, false>(e1, e2, cam, mtop, mmax, llw, dr);
+                else love_chain_group<false, false>(e1, e2, cam, mtop, mmax, llw, dr);
+                if (!dr.ok() && S.active) {
+                    e1 = s1;
+                    e2 = s2;
+                    love_chain_group<true, true>(e1, e2, cam, mtop, mmax, llw, dr);
+                }
+            }
+            del = e1;
+            __syncthreads();
+        }
+        if (prof) t2c = clock64();
+        if (S.active) S.advance(del);
+        if (prof) {
+            const long long t3 = clock64();
+            tA += t1c - t0;
+            tB += t2c - t1c;
+            tS += t3 - t2c;
+        }
+    }
+    if (valid && li == 0 && !spare) T.err[ib] = S.errflag;
+    if (prof) {
+        unsigned long long tot = (li == 0 && !spare) ? S.evals : 0u;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) {
+            atomicAdd(A.neval, tot);
+            // development aid: wave-cycles per phase, [1..3] Rayleigh A/B/state, [4..6] Love
+            const int o = (ifunc == 2) ? 1 : 4;
+            atomicAdd(A.neval + o, (unsigned long long)tA);
+            atomicAdd(A.neval + o + 1, (unsigned long long)tB);
+            atomicAdd(A.neval + o + 2, (unsigned long long)tS);
+            atomicAdd(A.neval + 7, 1ull);
+        }
+    }
+}
+
+size_t group_lds_bytes(int G, int Lmax, int Kmax)
+{
+    const int MPW = BH_WAVE / G;
+    return ((size_t)MPW * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
+            (size_t)((Kmax + 1) & ~1)) * sizeof(double) + (size_t)4 * Lmax * MPW * sizeof(float);
 }
 
 } // namespace
@@ -652,4 +1170,29 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
         hipLaunchKernelGGL(swd_kernel<1>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
     else
         hipLaunchKernelGGL(swd_kernel<2>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
+}
+
+int bh_swd_pick_group(int B, int ntargets, int Lmax)
+{
+    // One lane per model when the batch alone gives every SIMD >= 2 wavefronts; otherwise one
+    // lane per finite layer (at least 5: the width of the Rayleigh vector recursion), capped
+    // at 16, so that phase A needs a single round.
+    if ((long)B * ntargets / BH_WAVE >= 2048) return 1;
+    int G = Lmax - 1;
+    if (G < 5) G = 5;
+    if (G > 16) G = 16;
+    return G;
+}
+
+size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax) { return group_lds_bytes(G, Lmax, Kmax); }
+
+void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream)
+{
+    int kmax = 0;
+    for (int t = 0; t < a.ntargets; ++t) kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
+    const int mpw = BH_WAVE / G;
+    const dim3 grid((a.B + mpw - 1) / mpw, a.ntargets);
+    const size_t lds = group_lds_bytes(G, a.Lmax, kmax);
+    static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
+    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE), lds, stream, a, G | redundant);
 }

@@ -75,9 +75,11 @@ def load_library():
     L.bh_engine_stream.restype = vp
     L.bh_engine_synchronize.argtypes = [vp]
     L.bh_engine_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
+    L.bh_engine_set_swd_group.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
     L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bh_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bh_swd_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_ssize_t,
                                C.c_ssize_t, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.bh_rf_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
@@ -88,8 +90,8 @@ def load_library():
                                     C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, vp]
     L.bh_loglike_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation",
-                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group",
+                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 1:
@@ -99,8 +101,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation",
-                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group",
+                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math")
 
 
@@ -168,6 +170,10 @@ class Engine(object):
     def set_instrumentation(self, timing=False, counting=False):
         self._check(self._L.bh_engine_set_instrumentation(self._h, int(timing), int(counting)))
 
+    def set_swd_group(self, lanes_per_model):
+        """0 = automatic; 1..32 lanes of a wavefront per model in the dispersion kernel."""
+        self._check(self._L.bh_engine_set_swd_group(self._h, int(lanes_per_model)))
+
     def timing_reset(self):
         self._check(self._L.bh_timing_reset(self._h))
 
@@ -185,6 +191,11 @@ class Engine(object):
         n, tot, fam = self.timing_collect()
         self.timing_reset()
         return tot, fam
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._L.bh_debug_counters(self._h, out))
+        return [int(v) for v in out]
 
     def last_neval(self):
         v = C.c_uint64(0)
@@ -306,8 +317,8 @@ class Engine(object):
 
     def probe_math(self, op, x):
         x = _f64(x).ravel()
-        out = np.zeros_like(x)
-        self._check(self._L.bh_probe_math(self._h, int(op), x.size, x.ctypes.data_as(_d), out.ctypes.data_as(_d)))
+        out = np.zeros(x.size // 2 if op in (6, 7) else x.size)
+        self._check(self._L.bh_probe_math(self._h, int(op), out.size, x.ctypes.data_as(_d), out.ctypes.data_as(_d)))
         return out
 
     # -- device API (raw pointers; asynchronous) ---------------------------------------------

@@ -74,6 +74,9 @@ int bh_abi_version(void);
 int bh_engine_create(int device, bh_engine **out);
 void bh_engine_destroy(bh_engine *e);
 const char *bh_engine_last_error(const bh_engine *e);
+/* Tuning knob: lanes of a wavefront that cooperate on ONE model in the dispersion kernel
+ * (1..32; 0 = choose from the batch size and layer count, the default).  Results do not depend on it. */
+int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
 /* The engine's own stream as a hipStream_t cast to void*. */
 void *bh_engine_stream(bh_engine *e);
 /* Block until everything enqueued on the engine's stream has finished. */
@@ -165,7 +168,8 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
 
 /* ---- diagnostics -------------------------------------------------------------------------
  * Evaluate one elementary function on the device for n float64 inputs (host pointers):
- * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x.  Used by the tests to document how far the
+ * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x; op 6 / 7: in holds n pairs (a, b), out[i] = a/b
+ * through the shared-reciprocal sequence of the kernels (6) or the plain operator (7).  Used by the tests to document how far the
  * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
 int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
 
@@ -183,6 +187,9 @@ int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
 int bh_timing_reset(bh_engine *e);
 int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3]);
 int bh_last_neval(bh_engine *e, uint64_t *neval);
+/* development aid: raw counter block of the last counted call ([0] evaluations, [1..3]
+ * Rayleigh wave-cycles in phase A / B / state update, [4..6] the same for Love, [7] wavefronts) */
+int bh_debug_counters(bh_engine *e, uint64_t out[8]);
 
 #ifdef __cplusplus
 }
