@@ -826,25 +826,36 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
                                                      int gbase, int mtop, int mmax, int llw,
                                                      DivRange &dr)
 {
-    for (int m = (RAGGED ? mtop : mmax) - 2; m >= 0; --m) {
-        const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
-        double en[5];
-        if (PAR5) {
-            const double *cc = cam + (size_t)m * CA_STRIDE + 5 * col;
+    const int mstart = (RAGGED ? mtop : mmax) - 2;
+    if (PAR5) {
+        // software-pipelined: the column of layer m-1 is fetched while layer m is exchanged
+        const double *cc = cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE + 5 * col;
+        double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4];
+        for (int m = mstart; m >= 0; --m) {
+            const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+            const double *cn = cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE + 5 * col;
+            const double n0 = cn[0], n1 = cn[1], n2 = cn[2], n3 = cn[3], n4 = cn[4];
             double ee = 0.0;
-            ee = ee + e[0] * cc[0];
-            ee = ee + e[1] * cc[1];
-            ee = ee + e[2] * cc[2];
-            ee = ee + e[3] * cc[3];
-            ee = ee + e[4] * cc[4];
+            ee = ee + e[0] * c0;
+            ee = ee + e[1] * c1;
+            ee = ee + e[2] * c2;
+            ee = ee + e[3] * c3;
+            ee = ee + e[4] * c4;
             const double v0 = __shfl(ee, gbase + 0), v1 = __shfl(ee, gbase + 1), v2 = __shfl(ee, gbase + 2),
                          v3 = __shfl(ee, gbase + 3), v4 = __shfl(ee, gbase + 4);
+            double en[5];
             DivRange d2 = dr;
             normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);
             if (on) dr = d2;
-        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+        }
+    } else {
+        for (int m = mstart; m >= 0; --m) {
+            const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
             const double *cc = cam + (size_t)m * CA_STRIDE;
-            double ee[5];
+            double ee[5], en[5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 double acc = 0.0;
@@ -855,9 +866,9 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
             DivRange d2 = dr;
             normalize5<EXACT>(ee[0], ee[1], ee[2], ee[3], ee[4], en, d2);
             if (on) dr = d2;
-        }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+            for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+        }
     }
 }
 
@@ -866,10 +877,14 @@ template <bool RAGGED, bool EXACT>
 __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
                                                  int mmax, int llw, DivRange &dr)
 {
-    for (int m = (RAGGED ? mtop : mmax) - 2; m >= 0; --m) {
+    const int mstart = (RAGGED ? mtop : mmax) - 2;
+    // software-pipelined: the terms of layer m-1 are fetched while layer m is processed
+    const double2 *src = reinterpret_cast<const double2 *>(cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE);
+    double2 p0 = src[0], p1 = src[1], p2 = src[2];
+    for (int m = mstart; m >= 0; --m) {
         const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
-        const double2 *src = reinterpret_cast<const double2 *>(cam + (size_t)m * CA_STRIDE);
-        const double2 p0 = src[0], p1 = src[1], p2 = src[2];
+        const double2 *nx = reinterpret_cast<const double2 *>(cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE);
+        const double2 q0 = nx[0], q1 = nx[1], q2 = nx[2];
         double n1 = e1, n2 = e2;
         DivRange d2 = dr;
         love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
@@ -878,6 +893,7 @@ __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const d
             e2 = n2;
             dr = d2;
         }
+        p0 = q0; p1 = q1; p2 = q2;
     }
 }
  // doubles per parked layer: 25 (Rayleigh, column-major 5x5) / 4 (Love)
@@ -963,6 +979,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && !spare);
 
+    // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
+    // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
+    double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
     const bool prof = (A.neval != nullptr);
     long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
     while (__ballot(S.active) != 0ull) {
@@ -975,14 +994,36 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
             double omega = omg;
             if (omega < 1.0e-4) omega = 1.0e-4;
             const double wvno2 = wvno * wvno;
+            if (omega != c_omega) {
+                c_omega = omega;
+                if (li <= mmax - 2) {
+                    const double am = md.A(li), bm = md.Bv(li);
+                    c_xka = omega / am;
+                    c_xkb = omega / bm;
+                    const double t = bm / omega;
+                    c_gammk = 2.0 * t * t;
+                }
+                const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
+                h_xka = omega / ah;
+                h_xkb = omega / bh;
+                const double t = bh / omega;
+                h_gammk = 2.0 * t * t;
+            }
             // ---- phase A: layer terms, one layer per lane (strided by G) -----------------------
             for (int m = li; m <= mmax - 2; m += G) {
                 if (m >= llw - 1) {
-                    const double am = md.A(m), bm = md.Bv(m);
-                    const double xka = omega / am;
-                    const double xkb = omega / bm;
-                    const double t = bm / omega;
-                    const double gammk = 2.0 * t * t;
+                    double xka, xkb, gammk;
+                    if (m == li) {
+                        xka = c_xka;
+                        xkb = c_xkb;
+                        gammk = c_gammk;
+                    } else { // deep models: further rounds are computed on the fly
+                        const double am = md.A(m), bm = md.Bv(m);
+                        xka = omega / am;
+                        xkb = omega / bm;
+                        const double t = bm / omega;
+                        gammk = 2.0 * t * t;
+                    }
                     const double gam = gammk * wvno2;
                     double wvnop = wvno + xka;
                     double wvnom = fabs(wvno - xka);
@@ -1002,17 +1043,13 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
             // half-space E vector (surfdisp96.f:800-808), redundantly in every lane
             double e[5];
             {
-                const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
-                const double xka = omega / ah;
-                const double xkb = omega / bh;
+                const double xka = h_xka, xkb = h_xkb, gammk = h_gammk;
                 double wvnop = wvno + xka;
                 double wvnom = fabs(wvno - xka);
                 const double ra = sqrt(wvnop * wvnom);
                 wvnop = wvno + xkb;
                 wvnom = fabs(wvno - xkb);
                 const double rb = sqrt(wvnop * wvnom);
-                const double t = bh / omega;
-                const double gammk = 2.0 * t * t;
                 const double gam = gammk * wvno2;
                 const double gamm1 = gam - 1.0;
                 const double rho1 = md.R(mmax - 1);
@@ -1058,6 +1095,13 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
             __syncthreads();
         } else {
             const double omega = omg;
+            if (omega != c_omega) {
+                c_omega = omega;
+                if (li <= mmax - 2) c_xkb = omega / md.Bv(li);
+                const double beta1 = md.Bv(mmax - 1);
+                h_xkb = omega / beta1;
+                h_gammk = 1.0 / (beta1 * beta1); // e2 of the half-space (surfdisp96.f:731)
+            }
             // ---- phase A (Love): cosq, y, z, xmu per layer ----------------------------------------
             for (int m = li; m <= mmax - 2; m += G) {
                 if (m >= llw - 1) {
@@ -1065,7 +1109,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                     const double rho1 = md.R(m);
                     const double dm = md.D(m);
                     const double xmu = rho1 * beta1 * beta1;
-                    const double xkb = omega / beta1;
+                    const double xkb = (m == li) ? c_xkb : omega / beta1;
                     const double wvnop = wvno + xkb;
                     const double wvnom = fabs(wvno - xkb);
                     const double rb = sqrt(wvnop * wvnom);
@@ -1096,14 +1140,13 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
             }
             double e1, e2;
             {
-                const double beta1 = md.Bv(mmax - 1);
                 const double rho1 = md.R(mmax - 1);
-                const double xkb = omega / beta1;
+                const double xkb = h_xkb;
                 const double wvnop = wvno + xkb;
                 const double wvnom = fabs(wvno - xkb);
                 const double rb = sqrt(wvnop * wvnom);
                 e1 = rho1 * rb;
-                e2 = 1.0 / (beta1 * beta1);
+                e2 = h_gammk;
             }
             __syncthreads();
             if (prof) t1c = clock64();

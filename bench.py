@@ -17,7 +17,7 @@ N > 1: one process per GPU (torchrun), independent batches per rank, no data-pat
 (the path shards by model) -> "scaling": "weak"; barrier + max-over-ranks timing.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the Rayleigh dispersion
-kernel `swd_kernel<2>`): achieved = algorithmic bytes per launch / its average launch duration
+kernel `swd_group_kernel`, Rayleigh + Love wavefronts in one launch): achieved = algorithmic bytes per launch / its average launch duration
 measured with HIP events on the launch stream during the timed region.  `cpu_baseline` is the
 oracle (the bit-exact CPU restatement of the reference, kind "port") timed on this box's host
 cores on a bounded sample of the same workload.
@@ -186,8 +186,10 @@ def main():
         # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model
         K = spec[0]["n"]
         nswd = sum(1 for s in spec if s["kind"] == E.TARGET_SWD)
-        bytes_per_launch = B * (4 * L * 8 + K * 8 + 4)
-        swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls) / max(1, nswd)
+        # One launch of the group kernel covers all dispersion targets of the step (each target's
+        # wavefronts read the model and write K velocities + an error flag per model).
+        bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
+        swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
         achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
         out = {
             "metric": "forward-model+logL evals/sec (batched 10-layer models)",
@@ -200,7 +202,7 @@ def main():
                        "parallelism": "models sharded one batch per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "swd_kernel (Rayleigh+Love dispersion, avg per launch)",
+                         "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
                          "kernel_ms_per_launch": swd_ms_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "scalar FP64 recurrence: HBM is not the binding roof (SURVEY.md 8(d)); see fp64_valu"},
