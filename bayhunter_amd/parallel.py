@@ -1,0 +1,78 @@
+"""Multi-GPU plumbing: one process per GPU, models / chains sharded by rank.
+
+The hot path shards by model with no data-path collective: every rank evaluates
+its own slice.  The only exchanges are (1) gathering per-chain summaries at checkpoints and
+(2) the replica-exchange (parallel-tempering) swap of BASELINE.json config 5 -- an all-gather of
+a few floats per replica (RCCL over xGMI on GPUs, gloo in the CPU tests), after which every rank
+computes the same swap permutation from a shared seed.  Parallel tempering has no counterpart in
+the reference: "parity unpinned"; it is checked through invariants (permutation validity, detailed
+balance of the acceptance rule, identical decisions on every rank).
+"""
+import numpy as np
+
+
+def shard_slice(n_items, rank, world):
+    """Contiguous block partition of `n_items` units over `world` ranks (sizes differ by <= 1)."""
+    base, extra = divmod(int(n_items), int(world))
+    start = rank * base + min(rank, extra)
+    return slice(start, start + base + (1 if rank < extra else 0))
+
+
+def chain_owner(chain, n_chains, world):
+    """Rank that owns global chain index `chain` under shard_slice."""
+    for r in range(world):
+        s = shard_slice(n_chains, r, world)
+        if s.start <= chain < s.stop:
+            return r
+    raise IndexError(chain)
+
+
+def all_gather_rows(local, dist=None):
+    """Concatenate per-rank row blocks [n_r, m] (n_r may differ by rank) on every rank."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    nmax = int(max(c.item() for c in counts))
+    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:int(c.item())] for b, c in zip(bufs, counts)], dim=0)
+
+
+def swap_decisions(logL, beta, sweep, seed):
+    """Replica-exchange decisions for one sweep.  `logL[r]`, `beta[r]` for all replicas ordered by
+    temperature rung; neighbours (r, r+1) with r of parity `sweep % 2` are proposed; accept with
+    probability min(1, exp((beta_r - beta_{r+1}) * (logL_{r+1} - logL_r))).  Deterministic in
+    (seed, sweep): every rank computes the identical answer from the gathered values.
+    Returns the permutation `perm` such that rung r continues with the state of rung perm[r]."""
+    logL = np.asarray(logL, dtype=float)
+    beta = np.asarray(beta, dtype=float)
+    n = logL.size
+    perm = np.arange(n)
+    rs = np.random.RandomState((int(seed) * 1000003 + int(sweep)) % (2 ** 32))
+    u = rs.uniform(size=n)
+    for r in range(sweep % 2, n - 1, 2):
+        log_alpha = (beta[r] - beta[r + 1]) * (logL[r + 1] - logL[r])
+        if np.log(u[r]) < log_alpha:
+            perm[r], perm[r + 1] = perm[r + 1], perm[r]
+    return perm
+
+
+def tempering_swap(local_logL, local_beta, sweep, seed, dist=None):
+    """All-gather (logL, beta) of the local replicas (rank-major rung order), decide the swaps.
+    Returns (perm over all replicas, slice of the global arrays owned by this rank)."""
+    import torch
+    local = torch.stack((torch.as_tensor(local_logL, dtype=torch.float64),
+                         torch.as_tensor(local_beta, dtype=torch.float64)), dim=1)
+    if dist is not None and dist.is_initialized() and dist.get_backend() == "nccl":
+        local = local.cuda()
+    allv = all_gather_rows(local, dist).cpu().numpy()
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    perm = swap_decisions(allv[:, 0], allv[:, 1], sweep, seed)
+    return perm, shard_slice(allv.shape[0], rank, world) if world > 1 else slice(0, allv.shape[0])

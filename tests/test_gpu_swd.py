@@ -149,3 +149,42 @@ def test_device_math_is_close_to_host_libm(engine):
     for op, f, arg in ((1, np.sin, x), (2, np.cos, x), (3, np.exp, -x)):
         g, r = engine.probe_math(op, arg), f(arg)
         assert np.max(np.abs(g - r) / np.spacing(np.abs(r))) <= 1.0
+
+
+def test_shared_reciprocal_division_is_exact(engine):
+    """bh_quot(a, b, bh_rcp_refined(b)) == a / b bit for bit over the range the kernels use it in
+    ([2^-400, 2^400], see csrc/bh_device.h), and the device's plain division is IEEE."""
+    rs = np.random.RandomState(77)
+    for rep in range(8):
+        n = 1 << 18
+        ea = rs.uniform(-400, 400, n); eb = rs.uniform(-400, 400, n)
+        if rep % 4 == 1:
+            ea = eb + rs.uniform(-60, 0.0, n)            # |a| <= |b|: the max-norm rescale
+        if rep % 4 == 2:
+            ea = np.clip(eb + rs.uniform(-3, 3, n), -400, 400)
+        a = np.ldexp(rs.uniform(1, 2, n), ea.astype(int)) * rs.choice([-1, 1], n)
+        b = np.ldexp(rs.uniform(1, 2, n), eb.astype(int)) * rs.choice([-1, 1], n)
+        if rep % 4 == 3:                                  # mantissas next to 1 and 2
+            a = np.ldexp(1 + rs.randint(0, 8, n) * 2.0 ** -52, ea.astype(int))
+            b = np.ldexp(2 - rs.randint(1, 8, n) * 2.0 ** -52, eb.astype(int))
+        pairs = np.column_stack((a, b)).ravel()
+        fast, plain = engine.probe_math(6, pairs), engine.probe_math(7, pairs)
+        assert np.array_equal(plain, a / b)
+        assert np.array_equal(fast.view(np.int64), plain.view(np.int64))
+
+
+@pytest.mark.parametrize("G", [1, 2, 5, 9, 16, 21])
+def test_lane_mappings_return_identical_bits(engine, G):
+    """One lane per model, or G lanes per model (any G): same velocities, same error flags."""
+    rs = np.random.RandomState(31)
+    nlay, h, vp, vs, rho = synth_models(rs, 300, 14, lvz_frac=0.3, ragged=True)
+    per = np.linspace(2, 60, 30)
+    try:
+        for iwave, igr in REFS.values():
+            engine.set_swd_group(1)
+            v1, e1 = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+            engine.set_swd_group(G)
+            v2, e2 = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+            assert np.array_equal(v1, v2) and np.array_equal(e1, e2)
+    finally:
+        engine.set_swd_group(0)
