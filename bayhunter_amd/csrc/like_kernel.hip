@@ -13,6 +13,9 @@
 // One 256-thread workgroup per model loops over the targets; wave-level shuffles + LDS for the
 // reductions.  HBM traffic: the ymod row of the model (n * 8 B per target).
 #include "bh_device.h"
+#define BH_HD __device__ __forceinline__
+#define BH_TAB static __device__ const
+#include "bh_libm.h"
 
 namespace {
 
@@ -105,11 +108,22 @@ __global__ void probe_kernel(int op, int n, const double *in, double *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double x = (op < 6) ? in[i] : 0.0;
+    const double x = (op < 6) ? in[i] : 0.0; // ops >= 6 read their own operands
     double r;
     if (op == 6 || op == 7) { // division probes: in = pairs (a, b)
         const double a = in[2 * i], b = in[2 * i + 1];
         out[i] = (op == 6) ? bh_quot(a, b, bh_rcp_refined(b)) : a / b;
+        return;
+    }
+    if (op >= 8 && op <= 10) { // the glibc-exact exp / sincos of bh_libm.h (tables read from global memory)
+        const double v = in[i];
+        double sn = 0.0, cs = 0.0;
+        if (op == 10) {
+            out[i] = bhp_exp_in_domain(v) ? bhp_exp_core(v, bhp_exp_tab) : exp(v);
+        } else {
+            if (!bhp_sincos_bl(v, &sn, &cs, reinterpret_cast<const double *>(bhp_sincos_tab_bits))) sincos(v, &sn, &cs);
+            out[i] = (op == 8) ? sn : cs;
+        }
         return;
     }
     switch (op) {

@@ -29,7 +29,41 @@
 #include "bh_device.h"
 #include <cstdlib>
 
+// glibc-exact exp / sincos (see bh_libm.h): with these the device's secular function is the
+// reference's bit for bit -- sqrt and division are correctly rounded on gfx950, and exp / sincos
+// were the only operations where the device library (ocml, <= 1 ulp) and the host libm differed.
+#define BH_HD __device__ __forceinline__
+#define BH_TAB static __device__ const
+#include "bh_libm.h"
+
 namespace {
+
+struct LibmTabs {
+    const uint64_t *exp_tab; // [256]  in LDS
+    const double *sc_tab;    // [440]  in LDS
+};
+constexpr int LIBM_TAB_BYTES = 256 * 8 + 440 * 8;
+
+__device__ __forceinline__ LibmTabs stage_libm_tables(unsigned char *lds, int lane)
+{
+    uint64_t *et = reinterpret_cast<uint64_t *>(lds);
+    uint64_t *st = et + 256;
+    for (int i = lane; i < 256; i += BH_WAVE) et[i] = bhp_exp_tab[i];
+    for (int i = lane; i < 440; i += BH_WAVE) st[i] = bhp_sincos_tab_bits[i];
+    return LibmTabs{et, reinterpret_cast<const double *>(st)};
+}
+__device__ __forceinline__ void bh_sincos(double x, double *sn, double *cs, const LibmTabs &T)
+{
+    if (!bhp_sincos_bl(x, sn, cs, T.sc_tab)) sincos(x, sn, cs); // |x| >= 1.05e8, inf, nan: device library
+}
+__device__ __forceinline__ double bh_exp(double x, const LibmTabs &T)
+{
+    double r = bhp_exp_core(x, T.exp_tab); // branch-free main path; meaningless outside its domain
+    if (!bhp_exp_in_domain(x))             // rare: |x| < 2^-54 -> 1 + x like glibc; |x| >= 512, nan -> device library
+        r = ((((unsigned)__double2hiint(x) >> 20) & 0x7ffu) < 0x3c9u) ? 1.0 + x : exp(x);
+    return r;
+}
+
 
 constexpr int NEV_MAX = 11; // Neville table entries: order grows to m <= 10 (surfdisp96.f:655)
 
@@ -116,7 +150,7 @@ __device__ __forceinline__ void love_step(double &e1, double &e2, double cosq, d
 // ---- Love: SH Thomson-Haskell (surfdisp96.f:710-769) ----------------------------------------
 template <bool EXACT>
 __device__ double love_secular(double wvno, double omega, const ModelLds &md, int mmax, int llw,
-                               int mtop, DivRange &dr)
+                               int mtop, DivRange &dr, const LibmTabs &LT)
 {
     double beta1 = md.Bv(mmax - 1);
     double rho1 = md.R(mmax - 1);
@@ -140,7 +174,7 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
             double cosq, y, z;
             if (wvno < xkb) {
                 double sinq;
-                sincos(q, &sinq, &cosq);
+                bh_sincos(q, &sinq, &cosq, LT);
                 y = sinq / rb;
                 z = -rb * sinq;
             } else if (wvno == xkb) {
@@ -149,7 +183,7 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
                 z = 0.0;
             } else {
                 double fac = 0.0;
-                if (q < 16.0) fac = exp(-2.0 * q);
+                if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
                 cosq = (1.0 + fac) * 0.5;
                 const double sinq = (1.0 - fac) * 0.5;
                 y = sinq / rb;
@@ -168,49 +202,48 @@ struct LayerTerms {
 
 __device__ __forceinline__ void layer_products(double p, double q, double ra, double rb,
                                                double wvno, double xka, double xkb, double dpth,
-                                               LayerTerms &o)
+                                               LayerTerms &o, const LibmTabs &LT)
 {
+    // Two exec-mask regions per wave type (propagating: sincos; evanescent: exp) instead of the
+    // Fortran's three-way ifs -- branches are the expensive thing on this chip.  The measure-zero
+    // case wvno == xk? takes the evanescent arithmetic (p = 0, exp(-0) = 1 gives cos = 1 exactly)
+    // and has w/x resp. y/z overridden by selects, which are the values of surfdisp96.f:938-940.
     double cosp, cosq, w, x, y, z;
     double pex = 0.0, sex = 0.0;
     if (wvno < xka) {
         double sinp;
-        sincos(p, &sinp, &cosp);
+        bh_sincos(p, &sinp, &cosp, LT);
         w = sinp / ra;
         x = -ra * sinp;
-    } else if (wvno == xka) {
-        cosp = 1.0;
-        w = dpth;
-        x = 0.0;
     } else {
         pex = p;
-        double fac = 0.0;
-        if (p < 16.0) fac = exp(-2.0 * p);
+        const double fac = (p < 16.0) ? bh_exp((p < 16.0) ? -2.0 * p : -32.0, LT) : 0.0;
         cosp = (1.0 + fac) * 0.5;
         const double sinp = (1.0 - fac) * 0.5;
-        w = sinp / ra;
-        x = ra * sinp;
+        const bool eq = (wvno == xka);
+        w = eq ? dpth : sinp / ra;
+        x = eq ? 0.0 : ra * sinp;
+        cosp = eq ? 1.0 : cosp;
+        pex = eq ? 0.0 : pex;
     }
     if (wvno < xkb) {
         double sinq;
-        sincos(q, &sinq, &cosq);
+        bh_sincos(q, &sinq, &cosq, LT);
         y = sinq / rb;
         z = -rb * sinq;
-    } else if (wvno == xkb) {
-        cosq = 1.0;
-        y = dpth;
-        z = 0.0;
     } else {
         sex = q;
-        double fac = 0.0;
-        if (q < 16.0) fac = exp(-2.0 * q);
+        const double fac = (q < 16.0) ? bh_exp((q < 16.0) ? -2.0 * q : -32.0, LT) : 0.0;
         cosq = (1.0 + fac) * 0.5;
         const double sinq = (1.0 - fac) * 0.5;
-        y = sinq / rb;
-        z = rb * sinq;
+        const bool eq = (wvno == xkb);
+        y = eq ? dpth : sinq / rb;
+        z = eq ? 0.0 : rb * sinq;
+        cosq = eq ? 1.0 : cosq;
+        sex = eq ? 0.0 : sex;
     }
     const double exa = pex + sex;
-    double a0 = 0.0;
-    if (exa < 60.0) a0 = exp(-exa);
+    const double a0 = (exa < 60.0) ? bh_exp((exa < 60.0) ? -exa : -60.0, LT) : 0.0;
     o.a0 = a0;
     o.cpcq = cosp * cosq;
     o.cpy = cosp * y;
@@ -336,7 +369,7 @@ __device__ __forceinline__ void rayleigh_layer(double e[5], double wvno2, double
 // ---- Rayleigh: Dunkin compound-matrix secular function (surfdisp96.f:773-871) -----------------
 template <bool EXACT>
 __device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md, int mmax, int llw,
-                                   int mtop, DivRange &dr)
+                                   int mtop, DivRange &dr, const LibmTabs &LT)
 {
     double e[5];
     LayerTerms v;
@@ -382,7 +415,7 @@ __device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md,
             const double rho1 = md.R(m);
             const double p = ra * dpth;
             const double q = rb * dpth;
-            layer_products(p, q, ra, rb, wvno, xka, xkb, dpth, v);
+            layer_products(p, q, ra, rb, wvno, xka, xkb, dpth, v, LT);
             rayleigh_layer<EXACT>(e, wvno2, gam, gammk, rho1, v, dr);
         }
     }
@@ -396,7 +429,7 @@ __device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md,
         const double rho1 = md.R(0);
         const double p = ra * dpth;
         const double znul = 1.0e-5;
-        layer_products(p, znul, ra, znul, wvno, xka, znul, dpth, v);
+        layer_products(p, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
         const double w0 = -rho1 * v.w;
         result = v.cosp * e[0] + w0 * e[1];
     }
@@ -728,6 +761,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     double *xs = reinterpret_cast<double *>(smem + (size_t)4 * Lmax * BH_WAVE * sizeof(float));
     double *ys = xs + NEV_MAX * BH_WAVE;                                 // [11][64] each
     double *per = ys + NEV_MAX * BH_WAVE;                                // [K]
+    const LibmTabs LT = stage_libm_tables(reinterpret_cast<unsigned char *>(per + ((K + 1) & ~1)), lane);
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = A.periods[k];
 
@@ -770,14 +804,14 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
         DivRange dr;
         dr.reset();
         if (IFUNC == 1)
-            del = love_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr);
+            del = love_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
         else
-            del = rayleigh_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr);
+            del = rayleigh_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
         if (!dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
             if (IFUNC == 1)
-                del = love_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr);
+                del = love_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
             else
-                del = rayleigh_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr);
+                del = rayleigh_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
         }
         S.advance(del);
     }
@@ -826,11 +860,13 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
                                                      int gbase, int mtop, int mmax, int llw,
                                                      DivRange &dr)
 {
-    const int mstart = (RAGGED ? mtop : mmax) - 2;
+    // uniform wavefronts: the layer count is the same in every lane -> scalar loop control
+    const int mstart = (RAGGED ? mtop : __builtin_amdgcn_readfirstlane(mmax)) - 2;
     if (PAR5) {
         // software-pipelined: the column of layer m-1 is fetched while layer m is exchanged
         const double *cc = cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE + 5 * col;
         double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4];
+#pragma unroll 3
         for (int m = mstart; m >= 0; --m) {
             const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
             const double *cn = cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE + 5 * col;
@@ -877,10 +913,11 @@ template <bool RAGGED, bool EXACT>
 __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
                                                  int mmax, int llw, DivRange &dr)
 {
-    const int mstart = (RAGGED ? mtop : mmax) - 2;
+    const int mstart = (RAGGED ? mtop : __builtin_amdgcn_readfirstlane(mmax)) - 2;
     // software-pipelined: the terms of layer m-1 are fetched while layer m is processed
     const double2 *src = reinterpret_cast<const double2 *>(cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE);
     double2 p0 = src[0], p1 = src[1], p2 = src[2];
+#pragma unroll 3
     for (int m = mstart; m >= 0; --m) {
         const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
         const double2 *nx = reinterpret_cast<const double2 *>(cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE);
@@ -937,6 +974,8 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     double *ys = xs + NEV_MAX * MPW;
     double *per = ys + NEV_MAX * MPW;                              // [K]
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
+    const LibmTabs LT = stage_libm_tables(
+        reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15), lane);
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
     // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
@@ -960,6 +999,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     const int mmax = valid ? A.nlay[ib] : 2;
     int mtop = mmax;
     for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    mtop = __builtin_amdgcn_readfirstlane(mtop);
     __syncthreads();
     ModelLdsRt md;
     md.S = MPW;
@@ -1034,7 +1074,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                     const double dpth = md.D(m);
                     const double rho1 = md.R(m);
                     LayerTerms v;
-                    layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v);
+                    layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v, LT);
                     Ca19 c;
                     rayleigh_ca19(c, wvno2, gam, gammk, rho1, v);
                     park_ca25(cam + (size_t)m * CA_STRIDE, c);
@@ -1088,7 +1128,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                 const double rho1 = md.R(0);
                 const double znul = 1.0e-5;
                 LayerTerms v;
-                layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v);
+                layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
                 const double w0 = -rho1 * v.w;
                 del = v.cosp * e[0] + w0 * e[1];
             }
@@ -1117,7 +1157,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                     double cosq, y, z;
                     if (wvno < xkb) {
                         double sinq;
-                        sincos(q, &sinq, &cosq);
+                        bh_sincos(q, &sinq, &cosq, LT);
                         y = sinq / rb;
                         z = -rb * sinq;
                     } else if (wvno == xkb) {
@@ -1126,7 +1166,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                         z = 0.0;
                     } else {
                         double fac = 0.0;
-                        if (q < 16.0) fac = exp(-2.0 * q);
+                        if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
                         cosq = (1.0 + fac) * 0.5;
                         const double sinq = (1.0 - fac) * 0.5;
                         y = sinq / rb;
@@ -1194,7 +1234,8 @@ size_t group_lds_bytes(int G, int Lmax, int Kmax)
 {
     const int MPW = BH_WAVE / G;
     return ((size_t)MPW * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
-            (size_t)((Kmax + 1) & ~1)) * sizeof(double) + (size_t)4 * Lmax * MPW * sizeof(float);
+            (size_t)((Kmax + 1) & ~1)) * sizeof(double) +
+           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) + LIBM_TAB_BYTES;
 }
 
 } // namespace
@@ -1202,7 +1243,7 @@ size_t group_lds_bytes(int G, int Lmax, int Kmax)
 size_t bh_swd_lds_bytes(int Lmax, int K)
 {
     return (size_t)4 * Lmax * BH_WAVE * sizeof(float) + (size_t)2 * NEV_MAX * BH_WAVE * sizeof(double) +
-           (size_t)K * sizeof(double);
+           (size_t)((K + 1) & ~1) * sizeof(double) + LIBM_TAB_BYTES;
 }
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)

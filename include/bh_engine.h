@@ -169,7 +169,8 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
 /* ---- diagnostics -------------------------------------------------------------------------
  * Evaluate one elementary function on the device for n float64 inputs (host pointers):
  * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x; op 6 / 7: in holds n pairs (a, b), out[i] = a/b
- * through the shared-reciprocal sequence of the kernels (6) or the plain operator (7).  Used by the tests to document how far the
+ * through the shared-reciprocal sequence of the kernels (6) or the plain operator (7); op 8 / 9 / 10:
+ * sin / cos / exp through the kernels' glibc-exact restatement (csrc/bh_libm.h).  Used by the tests to document how far the
  * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
 int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
 

@@ -6,6 +6,7 @@
  * covariance (Targets.py:105-173), then  madist = (d^T C^-1) d  (Targets.py:339-342) -- so
  * that it is an independent check of the O(n) closed forms the engine evaluates on the GPU.
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -144,5 +145,24 @@ void bho_joint_batch(int B, int Lmax, const int32_t *nlay, const double *h, cons
         }
         free(ymod);
         free(zz);
+    }
+}
+
+/* The host libm itself, vectorised: what the reference's Fortran / C++ call (sincos, exp).
+ * Used by the tests to show that the device's restatement (csrc/bh_libm.h) returns the same bits. */
+void bho_libm_probe(int op, int n, const double *in, double *out)
+{
+    /* through volatile pointers: the compiler must really call sincos() (what the reference's
+     * compiled Fortran calls) and not narrow it to sin()/cos(), which are different (FMA ifunc)
+     * implementations in glibc and differ from sincos() in the last bit for ~0.1 % of arguments */
+    void (*volatile p_sincos)(double, double *, double *) = sincos;
+    double (*volatile p_exp)(double) = exp;
+    for (int i = 0; i < n; ++i) {
+        double s, c;
+        switch (op) {
+        case 0: p_sincos(in[i], &s, &c); out[i] = s; break;
+        case 1: p_sincos(in[i], &s, &c); out[i] = c; break;
+        default: out[i] = p_exp(in[i]); break;
+        }
     }
 }

@@ -100,6 +100,9 @@ void bho_joint_batch(int B, int Lmax, const int32_t *nlay, const double *h, cons
                      const double *vs, const double *rho, int nt, const bho_target *targets,
                      const double *noise, double *logL, double *misfits, int nthreads);
 
+/* host libm (sincos / exp) on arrays: op 0 sin, 1 cos (both through sincos()), 2 exp */
+void bho_libm_probe(int op, int n, const double *in, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,17 @@ def joint_batch(nlay, h, vp, vs, rho, targets, noise, nthreads=0):
     return logL, misf
 
 
+def libm_probe(op, x):
+    """op 0 sin, 1 cos (via sincos(), like the reference's compiled code), 2 exp -- the host libm."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.zeros_like(x)
+    fn = lib().bho_libm_probe
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, _d, _d]
+    fn(int(op), x.size, _pd(x), _pd(out))
+    return out
+
+
 def rms(ymod, yobs):
     ymod = np.ascontiguousarray(ymod, dtype=np.float64)
     yobs = np.ascontiguousarray(yobs, dtype=np.float64)

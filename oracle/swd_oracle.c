@@ -13,6 +13,8 @@
  *   - the order of secular-function evaluations in the bracket search and in the hybrid
  *     bisection / inverse-Neville refinement, including which point is returned.
  */
+#define _GNU_SOURCE /* sincos(): what the reference's compiled Fortran calls (not sin()+cos(), which are
+                       different glibc implementations and differ in the last bit for ~0.1 % of arguments) */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,10 +53,10 @@ double bho_dltar1(double wvno, double omega, const float *d, const float *b, con
         rb = sqrt(wvnop * wvnom);
         double q = (double)d[m] * rb;
         if (wvno < xkb) { /* propagating */
-            double sinq = sin(q);
+            double sinq;
+            sincos(q, &sinq, &cosq);
             y = sinq / rb;
             z = -rb * sinq;
-            cosq = cos(q);
         } else if (wvno == xkb) {
             cosq = 1.0;
             y = (double)d[m];
@@ -93,10 +95,10 @@ static void layer_products(double p, double q, double ra, double rb, double wvno
     double cosp, cosq, w, x, y, z;
     double pex = 0.0, sex = 0.0;
     if (wvno < xka) {
-        double sinp = sin(p);
+        double sinp;
+        sincos(p, &sinp, &cosp);
         w = sinp / ra;
         x = -ra * sinp;
-        cosp = cos(p);
     } else if (wvno == xka) {
         cosp = 1.0;
         w = dpth;
@@ -111,10 +113,10 @@ static void layer_products(double p, double q, double ra, double rb, double wvno
         x = ra * sinp;
     }
     if (wvno < xkb) {
-        double sinq = sin(q);
+        double sinq;
+        sincos(q, &sinq, &cosq);
         y = sinq / rb;
         z = -rb * sinq;
-        cosq = cos(q);
     } else if (wvno == xkb) {
         cosq = 1.0;
         y = dpth;

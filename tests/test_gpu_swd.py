@@ -139,9 +139,22 @@ def test_unsupported_options_fail_loudly(engine):
         engine.swd_batch(nlay, h, vp, vs, rho, np.linspace(1, 100, 61), 2, 0)  # > 60 periods
 
 
+def test_device_libm_restatement_is_bit_identical_to_host_libm(engine, oracle):
+    """csrc/bh_libm.h (what the dispersion kernels call) against the host's libm sincos()/exp(),
+    which is what the reference's compiled Fortran calls: identical bits, all argument ranges."""
+    rs = np.random.RandomState(3)
+    for lo, hi in ((0, 1e-8), (0, 0.126), (0.1, 0.9), (0.8, 2.5), (2.4, 10), (0, 40), (0, 1e3), (1e3, 1e5), (1e5, 1.05e8)):
+        x = rs.uniform(lo, hi, 400000) * rs.choice([-1, 1], 400000)
+        assert np.array_equal(engine.probe_math(8, x).view(np.int64), oracle.libm_probe(0, x).view(np.int64))
+        assert np.array_equal(engine.probe_math(9, x).view(np.int64), oracle.libm_probe(1, x).view(np.int64))
+    for lo, hi in ((-1e-10, 0), (-1, 0), (-40, 0), (-130, 0), (-500, 500)):
+        x = rs.uniform(lo, hi, 400000)
+        assert np.array_equal(engine.probe_math(10, x).view(np.int64), oracle.libm_probe(2, x).view(np.int64))
+
+
 def test_device_math_is_close_to_host_libm(engine):
-    """Documents SURVEY.md 7 'device libm': sqrt and 1/x are correctly rounded, sin/cos/exp
-    within 1 ulp of glibc."""
+    """Documents SURVEY.md 7 'device libm' (ocml, used outside the dispersion kernels): sqrt and 1/x
+    are correctly rounded, sin/cos/exp within 1 ulp of glibc."""
     rs = np.random.RandomState(0)
     x = rs.uniform(0.01, 40, 50000)
     assert np.array_equal(engine.probe_math(0, x), np.sqrt(x))
