@@ -95,7 +95,12 @@ struct LikeTargetDev {
     int law, n, off; // off: column offset of this target's samples inside a ymod row
     const double *yobs, *yerr_scaled, *rinv; // device; yerr_scaled = yerr/min(yerr) (law 1)
     double logdet_extra;                     // ln prod(scaled err) (law 1) or ln|R| (law 3)
+    const double *quad;                      // law 3: [B][nsplit] column-slab partial sums of d^T R^-1 d
+    int nsplit;                              //        (gauss_kernel.hip); null -> in-kernel mat-vec
 };
+int bh_gauss_nsplit(int B, int n);
+void bh_launch_gauss_quad(int B, int n, int ldy, const double *ymod, const double *yobs,
+                          const double *rinv, int nsplit, double *partial, hipStream_t stream);
 struct LikeKernelArgs {
     int B, nt, ldy;
     const double *ymod; // [B][ldy]

@@ -25,7 +25,7 @@ struct DevBuf {
 struct TargetHost {
     bh_target_desc d{};
     int off = 0; // column offset in a ymod row
-    DevBuf x, yobs, yerr_scaled, rinv;
+    DevBuf x, yobs, yerr_scaled, rinv, quad;
     double logdet_extra = 0.0;
 };
 
@@ -44,6 +44,7 @@ struct bh_engine {
     std::vector<TargetHost> targets;
     // instrumentation
     bool timing = false, counting = false;
+    bool no_mfma = false; // BH_NO_MFMA env: Gauss law through the in-kernel mat-vec (A/B testing)
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -309,6 +310,29 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     return BH_OK;
 }
 
+// Fill the likelihood descriptor of target t; for the Gauss law run the MFMA contraction first.
+int prepare_like_target(bh_engine *e, hipStream_t st, int B, int ldy, const double *ymod_d, TargetHost &T,
+                        LikeTargetDev &L)
+{
+    L.law = T.d.law; L.n = T.d.n; L.off = T.off;
+    L.yobs = (const double *)T.yobs.p;
+    L.yerr_scaled = (const double *)T.yerr_scaled.p;
+    L.rinv = (const double *)T.rinv.p;
+    L.logdet_extra = T.logdet_extra;
+    L.quad = nullptr;
+    L.nsplit = 0;
+    if (T.d.law == BH_LAW_GAUSS && !e->no_mfma) {
+        const int nsplit = bh_gauss_nsplit(B, T.d.n);
+        int rc = ensure(e, T.quad, (size_t)B * nsplit * sizeof(double));
+        if (rc) return rc;
+        ev_begin(e, 2, st);
+        bh_launch_gauss_quad(B, T.d.n, ldy, ymod_d + T.off, L.yobs, L.rinv, nsplit, (double *)T.quad.p, st);
+        L.quad = (const double *)T.quad.p;
+        L.nsplit = nsplit;
+    }
+    return BH_OK;
+}
+
 int rf_args_ok(bh_engine *e, int nsamp, int nkeep, double gauss, double fsamp, int waveno)
 {
     if (nsamp < 4 || (nsamp & (nsamp - 1)) != 0 || nsamp > 4096)
@@ -340,6 +364,7 @@ int bh_engine_create(int device, bh_engine **out)
         return BH_EHIP;
     }
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
+    if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
     *out = e;
     return BH_OK;
 }
@@ -363,7 +388,7 @@ void bh_engine_destroy(bh_engine *e)
                       &e->err_t, &e->probe_in, &e->probe_out, &e->counter})
         release(*b);
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv);
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad);
     }
     for (auto &s : e->evsets)
         for (auto &ev : s.ev)
@@ -522,7 +547,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv);
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad);
     }
     e->targets.clear();
     e->nt = 0;
@@ -579,7 +604,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
         }
         if (rc) {
             for (auto &u : tmp) {
-                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv);
+                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv); release(u.quad);
             }
             return rc;
         }
@@ -650,11 +675,6 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         if (d.kind == BH_TARGET_SWD)
             jobs[njobs++] = SwdJob{d.n, d.iwave, d.igr, ldy, (const double *)T.x.p, ymod_d + T.off,
                                    (int32_t *)e->err_t.p + (size_t)t * B};
-        la.t[t].law = d.law; la.t[t].n = d.n; la.t[t].off = T.off;
-        la.t[t].yobs = (const double *)T.yobs.p;
-        la.t[t].yerr_scaled = (const double *)T.yerr_scaled.p;
-        la.t[t].rinv = (const double *)T.rinv.p;
-        la.t[t].logdet_extra = T.logdet_extra;
     }
     if ((rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs))) return rc;
     for (int t = 0; t < nt; ++t) {
@@ -665,6 +685,8 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
                        d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
         if (rc) return rc;
     }
+    for (int t = 0; t < nt; ++t)
+        if ((rc = prepare_like_target(e, st, B, ldy, ymod_d, e->targets[(size_t)t], la.t[t]))) return rc;
     ev_begin(e, 2, st);
     bh_launch_like(la, st);
     ev_end(e, 2, st);
@@ -715,15 +737,9 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
         HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
         la.err_t = (const int32_t *)e->err_t.p;
     }
-    for (int t = 0; t < nt; ++t) {
-        TargetHost &T = e->targets[(size_t)t];
-        la.t[t].law = T.d.law; la.t[t].n = T.d.n; la.t[t].off = T.off;
-        la.t[t].yobs = (const double *)T.yobs.p;
-        la.t[t].yerr_scaled = (const double *)T.yerr_scaled.p;
-        la.t[t].rinv = (const double *)T.rinv.p;
-        la.t[t].logdet_extra = T.logdet_extra;
-    }
     call_begin(e, st);
+    for (int t = 0; t < nt; ++t)
+        if ((rc = prepare_like_target(e, st, B, ldy, la.ymod, e->targets[(size_t)t], la.t[t]))) return rc;
     ev_begin(e, 2, st);
     bh_launch_like(la, st);
     ev_end(e, 2, st);

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
             if (T.law == 2 && i + 1 < n) s1 += d * (ym[i + 1] - T.yobs[i + 1]);
             if (T.law == 1) sw += d * d / T.yerr_scaled[i];
         }
-        if (T.law == 3) { // (d^T R^-1) d with d staged in LDS; column access = coalesced over i
+        if (T.law == 3 && T.quad != nullptr) { // slab sums from the MFMA contraction, fixed order
+            if (tid == 0)
+                for (int sidx = 0; sidx < T.nsplit; ++sidx) sw += T.quad[(size_t)ib * T.nsplit + sidx];
+        } else if (T.law == 3) { // (d^T R^-1) d with d staged in LDS; column access = coalesced over i
             __syncthreads();
             for (int i = tid; i < n; i += 256) dl[i] = ym[i] - T.yobs[i];
             __syncthreads();
@@ -143,7 +146,8 @@ void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream)
 {
     size_t lds = 0;
     for (int t = 0; t < a.nt; ++t)
-        if (a.t[t].law == 3 && (size_t)a.t[t].n * sizeof(double) > lds) lds = (size_t)a.t[t].n * sizeof(double);
+        if (a.t[t].law == 3 && a.t[t].quad == nullptr && (size_t)a.t[t].n * sizeof(double) > lds)
+            lds = (size_t)a.t[t].n * sizeof(double);
     hipLaunchKernelGGL(like_kernel, dim3(a.B), dim3(256), lds, stream, a);
 }
 

@@ -86,3 +86,26 @@ def test_exponential_law_edge_sizes(engine, oracle):
                 o = -0.5 * (np.log(2 * np.pi) + 2 * np.log(s)) - 0.5 * (ymod[b, 0] - yobs[0]) ** 2 / (s * s * (1 - r * r))
             assert abs(logL[b] - o) <= 1e-10 * abs(o)
             assert abs(misf[b, 0] - oracle.rms(ymod[b], yobs)) <= 1e-12
+
+
+@pytest.mark.parametrize("n,B", [(1024, 300), (201, 4096), (70, 65), (16, 3)])
+def test_gauss_law_mfma_contraction(engine, n, B):
+    """d^T R^-1 d through the FP64-MFMA kernel (csrc/gauss_kernel.hip) against NumPy's dense form
+    (Targets.py:162-173, :339-342), including sizes that are not multiples of the 64x64 tiles."""
+    rs = np.random.RandomState(n)
+    idx = np.arange(n)
+    R = 0.9 ** ((idx[:, None] - idx[None, :]).astype(float) ** 2)
+    rinv = np.linalg.pinv(R, rcond=1e-6)
+    ld = np.linalg.slogdet(R)[1]
+    yobs = rs.normal(0, 0.1, n)
+    engine.set_targets([{"kind": E.TARGET_USER, "law": E.LAW_GAUSS, "n": n, "yobs": yobs, "rinv": rinv, "logdet_r": ld}])
+    ymod = yobs + rs.normal(0, 0.01, (B, n))
+    noise = np.column_stack((np.full(B, 0.9), rs.uniform(0.005, 0.05, B)))
+    logL, misf, err = engine.loglike_batch(ymod, noise)
+    d = ymod - yobs
+    phi = np.einsum("bi,ij,bj->b", d, rinv, d)
+    ref = -0.5 * (n * np.log(2 * np.pi) + 2 * n * np.log(noise[:, 1]) + ld) - 0.5 * phi / noise[:, 1] ** 2
+    assert np.max(np.abs(logL - ref) / np.abs(ref)) <= 1e-10
+    assert np.allclose(misf[:, 0], np.sqrt(np.mean(d * d, axis=1)), rtol=1e-12)
+    again = engine.loglike_batch(ymod, noise)[0]
+    assert np.array_equal(again, logL)  # fixed summation order: deterministic
