@@ -188,8 +188,6 @@ class SingleTarget(object):
             d["logdet_r"] = float(self.valuation.logcorr_det)
         p = self.moddata.plugin
         if isinstance(p, SurfDisp):
-            if p.obsx_int is not None:
-                raise NotImplementedError("more than 60 periods in a fused SWD target")
             d.update(kind=_engine.TARGET_SWD, iwave=p.wavetype, igr=p.veltype,
                      mode=p.modelparams["mode"], flsph=p.modelparams["flsph"],
                      x=np.asarray(self.obsdata.x, dtype=float))

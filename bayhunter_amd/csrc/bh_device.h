@@ -44,7 +44,7 @@ __device__ __forceinline__ bool bh_div_safe(double x)
 }
 
 struct SwdKernelArgs {
-    int B, Lmax, K, igr;
+    int B, Lmax, K, igr, mode;
     const int32_t *nlay;
     const double *h, *vp, *vs, *rho;
     ptrdiff_t sl, sb; // element strides: layer, model
@@ -56,11 +56,13 @@ struct SwdKernelArgs {
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
-size_t bh_swd_lds_bytes(int Lmax, int K);
+size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
 
 // group kernel: G lanes per model, all dispersion targets of a call in one launch
 struct SwdTarget {
-    int iwave, igr, K, ldv;
+    int iwave, igr, K, ldv, mode;
+    const double *h, *vp, *vs, *rho; // model arrays this target reads (earth-flattened copies when flsph = 1)
+    ptrdiff_t sl, sb;
     const double *periods;
     double *vel;  // [B][ldv] (+ column offset already applied)
     int32_t *err; // [B]
@@ -68,14 +70,20 @@ struct SwdTarget {
 struct SwdMultiArgs {
     int B, Lmax, ntargets;
     const int32_t *nlay;
-    const double *h, *vp, *vs, *rho;
-    ptrdiff_t sl, sb;
     unsigned long long *neval;
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
-size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax);
+size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax, int maxmode);
 void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
+// earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
+// (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
+void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                      const double *vs, const double *rho, ptrdiff_t sl, ptrdiff_t sb, double *oh,
+                      double *ovp, double *ovs, double *orho_love, double *orho_ray, hipStream_t stream);
+// np.interp of B rows from K0 to K1 abscissae (the > 60 periods path of surf96_modsw.py:119-122)
+void bh_launch_interp(int B, int K0, const double *x0, const double *y0, int ld0, int K1,
+                      const double *x1, double *y1, int ld1, hipStream_t stream);
 
 struct RfKernelArgs {
     int B, Lmax, nsamp, nkeep, waveno;

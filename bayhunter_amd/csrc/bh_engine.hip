@@ -26,6 +26,8 @@ struct TargetHost {
     bh_target_desc d{};
     int off = 0; // column offset in a ymod row
     DevBuf x, yobs, yerr_scaled, rinv, quad;
+    DevBuf x60, vel60; // > 60 periods: the 60-point grid the forward model runs on + its output
+    int kfwd = 0;      // periods the forward model computes (n, or 60 when n > 60)
     double logdet_extra = 0.0;
 };
 
@@ -37,7 +39,7 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, spec, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter;
+        misfits, err_t, probe_in, probe_out, counter, sph;
     // targets
     int nt = 0;
     int ldy = 0;
@@ -204,35 +206,8 @@ int swd_supported(bh_engine *e, int K, int iwave, int mode, int flsph)
 {
     if (K < 0 || K > BH_MAX_PERIODS) return fail(e, BH_EINVAL, "K must be 0..60 (surfdisp96.f:61-62)");
     if (iwave != BH_WAVE_LOVE && iwave != BH_WAVE_RAYLEIGH) return fail(e, BH_EINVAL, "iwave must be 1 (Love) or 2 (Rayleigh)");
-    if (mode != 1) return fail(e, BH_EUNSUPPORTED, "only the fundamental mode (mode=1) is implemented on the device");
-    if (flsph != 0) return fail(e, BH_EUNSUPPORTED, "earth-flattening (flsph=1) is not implemented on the device");
-    return BH_OK;
-}
-
-int launch_swd(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
-               ptrdiff_t sb, int K, const double *periods_dev, int iwave, int igr, double *vel,
-               int ldv, int32_t *err)
-{
-    if (B == 0 || K == 0) return BH_OK;
-    SwdKernelArgs a{};
-    a.B = B; a.Lmax = Lmax; a.K = K; a.igr = igr;
-    a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho;
-    a.sl = sl; a.sb = sb; a.periods = periods_dev; a.vel = vel; a.ldv = ldv; a.err = err;
-    a.neval = nullptr;
-    if (e->counting) {
-        int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
-        if (rc) return rc;
-        if (!e->neval_pending) {
-            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
-            e->neval_pending = true;
-        }
-        a.neval = (unsigned long long *)e->counter.p;
-    }
-    if (bh_swd_lds_bytes(Lmax, K) > 160 * 1024) return fail(e, BH_EINVAL, "model too deep for LDS");
-    ev_begin(e, 0, st);
-    bh_launch_swd(a, iwave, st);
-    ev_end(e, 0, st);
-    HIPCHK(e, hipGetLastError());
+    if (mode < 1 || mode > 16) return fail(e, BH_EINVAL, "mode must be 1..16");
+    if (flsph != 0 && flsph != 1) return fail(e, BH_EINVAL, "flsph must be 0 or 1");
     return BH_OK;
 }
 
@@ -241,7 +216,23 @@ struct SwdJob {
     const double *periods_dev;
     double *vel;
     int32_t *err;
+    int mode = 1;
+    int flsph = 0;
 };
+
+int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
+{
+    *out = nullptr;
+    if (!e->counting) return BH_OK;
+    int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
+    if (rc) return rc;
+    if (!e->neval_pending) {
+        HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
+        e->neval_pending = true;
+    }
+    *out = (unsigned long long *)e->counter.p;
+    return BH_OK;
+}
 
 // All dispersion targets of one call.  Small batches go to the group kernel (G lanes per model,
 // one launch for all targets); batches that fill the chip by themselves use one lane per model.
@@ -249,39 +240,68 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                     ptrdiff_t sb, int njobs, const SwdJob *jobs)
 {
     if (B == 0 || njobs == 0) return BH_OK;
-    int G = e->force_group > 0 ? e->force_group : bh_swd_pick_group(B, njobs, Lmax);
-    int kmax = 0;
-    for (int j = 0; j < njobs; ++j) kmax = jobs[j].K > kmax ? jobs[j].K : kmax;
-    while (G > 1 && bh_swd_group_lds_bytes(G, Lmax, kmax) > 64 * 1024) G += 1; // fewer models per wave
-    if (G > 32) G = 1;
+    int rc;
+    int kmax = 0, maxmode = 1, nlive = 0;
+    bool any_sphere = false;
+    for (int j = 0; j < njobs; ++j) {
+        if (jobs[j].K == 0) continue;
+        ++nlive;
+        kmax = jobs[j].K > kmax ? jobs[j].K : kmax;
+        maxmode = jobs[j].mode > maxmode ? jobs[j].mode : maxmode;
+        any_sphere = any_sphere || jobs[j].flsph == 1;
+    }
+    if (nlive == 0) return BH_OK;
+    // earth-flattened copies of the batch (layer-major), made once per call
+    const double *sh = nullptr, *svp = nullptr, *svs = nullptr, *srl = nullptr, *srr = nullptr;
+    if (any_sphere) {
+        const size_t nb = (size_t)Lmax * B * sizeof(double);
+        if ((rc = ensure(e, e->sph, 5 * nb))) return rc;
+        double *base = (double *)e->sph.p;
+        const size_t ne = (size_t)Lmax * B;
+        bh_launch_sphere(B, Lmax, m.nlay, m.h, m.vp, m.vs, m.rho, sl, sb, base, base + ne, base + 2 * ne,
+                         base + 3 * ne, base + 4 * ne, st);
+        sh = base; svp = base + ne; svs = base + 2 * ne; srl = base + 3 * ne; srr = base + 4 * ne;
+    }
+    int G = e->force_group > 0 ? e->force_group : bh_swd_pick_group(B, nlive, Lmax);
+    const size_t lds_cap = 64 * 1024;
+    if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
+    while (G > 1 && G < 64 && bh_swd_group_lds_bytes(G, Lmax, kmax, maxmode) > lds_cap) G += 1; // fewer models per wave
+    if (G > 1 && bh_swd_group_lds_bytes(G, Lmax, kmax, maxmode) > lds_cap) return fail(e, BH_EINVAL, "model too deep for LDS");
+    unsigned long long *counter = nullptr;
+    if ((rc = swd_counter(e, st, &counter))) return rc;
     if (G <= 1) {
         for (int j = 0; j < njobs; ++j) {
-            int rc = launch_swd(e, st, B, Lmax, m, sl, sb, jobs[j].K, jobs[j].periods_dev, jobs[j].iwave,
-                                jobs[j].igr, jobs[j].vel, jobs[j].ldv, jobs[j].err);
-            if (rc) return rc;
+            const SwdJob &J = jobs[j];
+            if (J.K == 0) continue;
+            SwdKernelArgs a{};
+            a.B = B; a.Lmax = Lmax; a.K = J.K; a.igr = J.igr; a.mode = J.mode;
+            a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.sl = sl; a.sb = sb;
+            if (J.flsph == 1) {
+                a.h = sh; a.vp = svp; a.vs = svs; a.rho = (J.iwave == BH_WAVE_LOVE) ? srl : srr;
+                a.sl = B; a.sb = 1;
+            }
+            a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
+            ev_begin(e, 0, st);
+            bh_launch_swd(a, J.iwave, st);
+            ev_end(e, 0, st);
         }
+        HIPCHK(e, hipGetLastError());
         return BH_OK;
     }
     SwdMultiArgs a{};
-    a.B = B; a.Lmax = Lmax; a.ntargets = 0;
-    a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.sl = sl; a.sb = sb;
-    a.neval = nullptr;
-    if (e->counting) {
-        int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
-        if (rc) return rc;
-        if (!e->neval_pending) {
-            HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
-            e->neval_pending = true;
-        }
-        a.neval = (unsigned long long *)e->counter.p;
-    }
+    a.B = B; a.Lmax = Lmax; a.ntargets = 0; a.nlay = m.nlay; a.neval = counter;
     for (int j = 0; j < njobs; ++j) {
-        if (jobs[j].K == 0) continue;
+        const SwdJob &J = jobs[j];
+        if (J.K == 0) continue;
         SwdTarget &t = a.t[a.ntargets++];
-        t.iwave = jobs[j].iwave; t.igr = jobs[j].igr; t.K = jobs[j].K; t.ldv = jobs[j].ldv;
-        t.periods = jobs[j].periods_dev; t.vel = jobs[j].vel; t.err = jobs[j].err;
+        t.iwave = J.iwave; t.igr = J.igr; t.K = J.K; t.ldv = J.ldv; t.mode = J.mode;
+        t.h = m.h; t.vp = m.vp; t.vs = m.vs; t.rho = m.rho; t.sl = sl; t.sb = sb;
+        if (J.flsph == 1) {
+            t.h = sh; t.vp = svp; t.vs = svs; t.rho = (J.iwave == BH_WAVE_LOVE) ? srl : srr;
+            t.sl = B; t.sb = 1;
+        }
+        t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
     }
-    if (a.ntargets == 0) return BH_OK;
     ev_begin(e, 0, st);
     bh_launch_swd_group(a, G, st);
     ev_end(e, 0, st);
@@ -385,10 +405,10 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->spec, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph})
         release(*b);
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad);
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);
     }
     for (auto &s : e->evsets)
         for (auto &ev : s.ev)
@@ -483,7 +503,7 @@ int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, cons
         hipStream_t st = stream ? (hipStream_t)stream : e->stream;
         Staged m{nlay, h, vp, vs, rho, nullptr, nullptr};
         call_begin(e, st);
-        SwdJob job{K, iwave, igr, K, periods, vel, err};
+        SwdJob job{K, iwave, igr, K, periods, vel, err, mode, flsph};
         rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, 1, &job);
         call_end(e, st);
         return rc;
@@ -496,7 +516,7 @@ int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, cons
     if ((rc = ensure(e, e->errb, (size_t)B * sizeof(int32_t)))) return rc;
     HIPCHK(e, hipMemcpyAsync(e->periods.p, periods, (size_t)K * sizeof(double), hipMemcpyHostToDevice, st));
     call_begin(e, st);
-    SwdJob job{K, iwave, igr, K, (const double *)e->periods.p, (double *)e->vel.p, (int32_t *)e->errb.p};
+    SwdJob job{K, iwave, igr, K, (const double *)e->periods.p, (double *)e->vel.p, (int32_t *)e->errb.p, mode, flsph};
     rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, 1, &job);
     call_end(e, st);
     if (rc) return rc;
@@ -547,7 +567,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad);
+        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);
     }
     e->targets.clear();
     e->nt = 0;
@@ -565,9 +585,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
             rc = fail(e, BH_EINVAL, "unknown covariance law");
         if (!rc && d.kind == BH_TARGET_SWD) {
             if (!d.x) rc = fail(e, BH_EINVAL, "SWD target needs periods x");
-            if (!rc && d.n > BH_MAX_PERIODS)
-                rc = fail(e, BH_EUNSUPPORTED, "more than 60 periods per SWD target is not implemented in bh_evaluate_batch");
-            if (!rc) rc = swd_supported(e, d.n, d.iwave, d.mode, d.flsph);
+            if (!rc) rc = swd_supported(e, d.n > BH_MAX_PERIODS ? BH_MAX_PERIODS : d.n, d.iwave, d.mode, d.flsph);
         } else if (!rc && d.kind == BH_TARGET_RF) {
             rc = rf_args_ok(e, d.nsamp, d.n, d.gauss, d.fsamp, d.waveno);
         } else if (!rc && d.kind == BH_TARGET_USER) {
@@ -583,6 +601,22 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
         if (!rc && d.kind == BH_TARGET_SWD) {
             rc = ensure(e, t.x, nb);
             if (!rc && hipMemcpy(t.x.p, d.x, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy x");
+            t.kfwd = d.n;
+            if (!rc && d.n > BH_MAX_PERIODS) {
+                // surf96_modsw.py:35-43: np.linspace(min, max, 60), velocities interpolated back (:119-122)
+                double lo = d.x[0], hi = d.x[0];
+                for (int k = 1; k < d.n; ++k) {
+                    lo = d.x[k] < lo ? d.x[k] : lo;
+                    hi = d.x[k] > hi ? d.x[k] : hi;
+                }
+                double g[BH_MAX_PERIODS];
+                const double step = (hi - lo) / (double)(BH_MAX_PERIODS - 1);
+                for (int k = 0; k < BH_MAX_PERIODS; ++k) g[k] = (double)k * step + lo; // numpy.linspace
+                g[BH_MAX_PERIODS - 1] = hi;
+                t.kfwd = BH_MAX_PERIODS;
+                rc = ensure(e, t.x60, sizeof(g));
+                if (!rc && hipMemcpy(t.x60.p, g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy x60");
+            }
         }
         if (!rc && d.law == BH_LAW_NOCORR_SCALED) { // Targets.py:124-128
             std::vector<double> se(d.yerr, d.yerr + d.n);
@@ -604,7 +638,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
         }
         if (rc) {
             for (auto &u : tmp) {
-                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv); release(u.quad);
+                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv); release(u.quad); release(u.x60); release(u.vel60);
             }
             return rc;
         }
@@ -672,14 +706,23 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];
         const bh_target_desc &d = T.d;
-        if (d.kind == BH_TARGET_SWD)
-            jobs[njobs++] = SwdJob{d.n, d.iwave, d.igr, ldy, (const double *)T.x.p, ymod_d + T.off,
-                                   (int32_t *)e->err_t.p + (size_t)t * B};
+        if (d.kind == BH_TARGET_SWD) {
+            int32_t *errp = (int32_t *)e->err_t.p + (size_t)t * B;
+            if (T.kfwd == d.n) {
+                jobs[njobs++] = SwdJob{d.n, d.iwave, d.igr, ldy, (const double *)T.x.p, ymod_d + T.off, errp, d.mode, d.flsph};
+            } else { // > 60 periods: run on the 60-point grid, interpolate afterwards
+                if ((rc = ensure(e, T.vel60, (size_t)B * T.kfwd * sizeof(double)))) return rc;
+                jobs[njobs++] = SwdJob{T.kfwd, d.iwave, d.igr, T.kfwd, (const double *)T.x60.p, (double *)T.vel60.p, errp, d.mode, d.flsph};
+            }
+        }
     }
     if ((rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs))) return rc;
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];
         const bh_target_desc &d = T.d;
+        if (d.kind == BH_TARGET_SWD && T.kfwd != d.n)
+            bh_launch_interp(B, T.kfwd, (const double *)T.x60.p, (const double *)T.vel60.p, T.kfwd, d.n,
+                             (const double *)T.x.p, ymod_d + T.off, ldy, st);
         if (d.kind != BH_TARGET_RF) continue;
         rc = launch_rf(e, st, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
                        d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);

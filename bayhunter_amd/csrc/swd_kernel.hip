@@ -479,12 +479,14 @@ struct SearchT {
     double cc, cm, betmxd, dc, onea, one, twopi, pct;
     bool group;
     int K;
+    int mode;            // highest mode wanted (1 = fundamental)
+    double *cper, *cbper; // LDS, only for mode > 1: c(k) / cb(k) of surfdisp96.f:85, element k at [k*XS]
     const double *per; // LDS
     double *xl, *yl;   // LDS Neville tables, element j at [j*XS]
     double *vel;       // this model's output row (global)
     bool writer;       // this lane stores results (one lane per model)
     // state
-    int k, root, st, ifirst, idir, nev, mnev, nctrl, errflag;
+    int k, root, st, ifirst, idir, nev, mnev, nctrl, errflag, iq, ift;
     bool active;
     double c1, c2, clow, del1, del2, del1st, c3, del3, ck, t1, omega, ceval;
     float t1a, t1b;
@@ -508,7 +510,8 @@ struct SearchT {
     // driver set-up (surfdisp96.f:124-217): extremal velocities, start value
     template <class MD>
     __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
-                         double *xl_, double *yl_, double *vel_, bool writer_)
+                         double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
+                         double *cper_ = nullptr, double *cbper_ = nullptr)
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
@@ -543,6 +546,16 @@ struct SearchT {
         yl = yl_;
         vel = vel_;
         writer = writer_;
+        mode = mode_;
+        cper = cper_;
+        cbper = cbper_;
+        if (mode > 1)
+            for (int i = 0; i < K; ++i) { // do 450: c() = cb() = 0 (every lane of the group writes the same)
+                cper[i * XS] = 0.0;
+                cbper[i * XS] = 0.0;
+            }
+        iq = 1;
+        ift = 999;
         k = 0; root = 0; st = ST_FIRST; ifirst = 1;
         active = valid && K > 0;
         errflag = 0;
@@ -553,6 +566,57 @@ struct SearchT {
         t1 = 1.0; omega = 1.0;
         evals = 0;
         if (active) set_period(0);
+        ceval = c1;
+    }
+
+    // label 1700/1750: the current mode found no root at period k
+    __device__ __forceinline__ void fail_mode()
+    {
+        if (iq == 1) errflag = 1; // higher modes fail silently (:313)
+        ift = k;
+        if (writer)
+            for (int i = k; i < K; ++i) vel[i] = 0.0;
+    }
+
+    // Set up the root search of period k of mode iq (initial guess logic, :253-272), moving on to
+    // the next mode when the period list is exhausted or a previous mode already failed here.
+    __device__ void next_search()
+    {
+        for (;;) {
+            bool over = (k >= K);
+            if (!over && k >= ift) { // `if(k.ge.ift) go to 1700`
+                fail_mode();
+                over = true;
+            }
+            if (!over) break;
+            if (iq >= mode) {
+                active = false;
+                return;
+            }
+            iq = iq + 1;
+            k = 0;
+        }
+        set_period(k);
+        root = 0;
+        if (mode == 1) { // fundamental mode only: c(k-1) is still in a register
+            ifirst = 0;
+            c1 = ck - onea * dc;
+            clow = cm;
+        } else if (k == 0) {
+            c1 = cper[0] + one * dc; // iq > 1 here (iq == 1, k == 0 is set up by init)
+            clow = c1;
+            ifirst = 1;
+        } else if (iq > 1) {
+            ifirst = 0;
+            clow = cper[k * XS] + one * dc;
+            c1 = cper[(k - 1) * XS];
+            if (c1 < clow) c1 = clow;
+        } else {
+            ifirst = 0;
+            c1 = cper[(k - 1) * XS] - onea * dc;
+            clow = cm;
+        }
+        st = ST_FIRST;
         ceval = c1;
     }
 
@@ -677,19 +741,24 @@ struct SearchT {
             bool period_done = false;
             double c1b = 0.0; // the "c1" the driver uses after the (optional) second search
             if (root == 0) {
-                if (todo == 2) { // no root in the fundamental mode: err, zero-fill, stop (:313-354)
-                    errflag = 1;
-                    if (writer)
-                        for (int i = k; i < K; ++i) vel[i] = 0.0;
-                    active = false;
+                if (todo == 2) { // no root: err (fundamental mode only), zero-fill, next mode (:313-354)
+                    fail_mode();
+                    if (iq >= mode) {
+                        active = false;
+                    } else {
+                        iq = iq + 1;
+                        k = 0;
+                        next_search();
+                    }
                 } else {
                     ck = c1;
+                    if (mode > 1) cper[k * XS] = c1;
                     if (group) { // second root at the slightly longer period (:282-287)
                         root = 1;
                         t1 = (double)t1b;
                         omega = twopi / t1;
                         ifirst = 0;
-                        clow = 0.0 + one * dc; // cb(k) is still 0 for the fundamental mode
+                        clow = ((mode > 1) ? cbper[k * XS] : 0.0) + one * dc; // cb(k) of the previous mode
                         c1 = c1 - onea * dc;
                         st = ST_FIRST;
                         ceval = c1;
@@ -699,6 +768,7 @@ struct SearchT {
                 }
             } else {
                 c1b = (todo == 2) ? ck : c1; // second root failed: reuse the first (:291-293)
+                if (mode > 1) cbper[k * XS] = c1b;
                 period_done = true;
             }
             if (period_done) {
@@ -714,17 +784,7 @@ struct SearchT {
                 }
                 if (writer) vel[k] = out;
                 k = k + 1;
-                if (k >= K) {
-                    active = false;
-                } else { // initial guess for the next period (:268-272)
-                    set_period(k);
-                    root = 0;
-                    ifirst = 0;
-                    c1 = ck - onea * dc;
-                    clow = cm;
-                    st = ST_FIRST;
-                    ceval = c1;
-                }
+                next_search();
             }
             todo = 0;
         }
@@ -761,7 +821,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     double *xs = reinterpret_cast<double *>(smem + (size_t)4 * Lmax * BH_WAVE * sizeof(float));
     double *ys = xs + NEV_MAX * BH_WAVE;                                 // [11][64] each
     double *per = ys + NEV_MAX * BH_WAVE;                                // [K]
-    const LibmTabs LT = stage_libm_tables(reinterpret_cast<unsigned char *>(per + ((K + 1) & ~1)), lane);
+    unsigned char *after = reinterpret_cast<unsigned char *>(per + ((K + 1) & ~1));
+    const LibmTabs LT = stage_libm_tables(after, lane);
+    double *cpl = reinterpret_cast<double *>(after + LIBM_TAB_BYTES); // [2][K][64], only if mode > 1
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = A.periods[k];
 
@@ -795,7 +857,8 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
 
     SearchT<BH_WAVE> S;
-    S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, true);
+    S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, true, A.mode,
+           cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
 
     while (__ballot(S.active) != 0ull) {
         if (!S.active) continue;
@@ -974,8 +1037,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     double *ys = xs + NEV_MAX * MPW;
     double *per = ys + NEV_MAX * MPW;                              // [K]
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
-    const LibmTabs LT = stage_libm_tables(
-        reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15), lane);
+    unsigned char *after = reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15);
+    const LibmTabs LT = stage_libm_tables(after, lane);
+    double *cpl = reinterpret_cast<double *>(after + LIBM_TAB_BYTES); // [2][Kmax][MPW], only if a target has mode > 1
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
     // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
@@ -985,11 +1049,11 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
         const int b = blockIdx.x * MPW + mg;
         float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
         if (b < A.B && l < A.nlay[b]) {
-            const ptrdiff_t o = (ptrdiff_t)b * A.sb + (ptrdiff_t)l * A.sl;
-            fd = (float)A.h[o];
-            fa = (float)A.vp[o];
-            fb = (float)A.vs[o];
-            fr = (float)A.rho[o];
+            const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
+            fd = (float)T.h[o];
+            fa = (float)T.vp[o];
+            fb = (float)T.vs[o];
+            fr = (float)T.rho[o];
         }
         mdl[(0 * Lmax + l) * MPW + mg] = fd;
         mdl[(1 * Lmax + l) * MPW + mg] = fa;
@@ -1017,7 +1081,8 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
 
     SearchRt S;
     S.XS = MPW;
-    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && !spare);
+    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && !spare, T.mode,
+           cpl + g, cpl + (size_t)K * MPW + g);
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
@@ -1230,26 +1295,111 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     }
 }
 
-size_t group_lds_bytes(int G, int Lmax, int Kmax)
+size_t group_lds_bytes(int G, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / G;
     return ((size_t)MPW * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
             (size_t)((Kmax + 1) & ~1)) * sizeof(double) +
-           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) + LIBM_TAB_BYTES;
+           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) + LIBM_TAB_BYTES +
+           (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
+}
+
+// ---- earth flattening, surfdisp96.f:486-553 (`sphere`, both calls) --------------------------------
+// One lane per model.  Arithmetic widths as in the Fortran (model arrays binary32, radii binary64).
+// log() and powf() here are the device library's: results agree with the reference to ~1e-7
+// relative, not bit for bit (the flat-earth default path is bit-exact).
+__global__ void sphere_kernel(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                              const double *vs, const double *rho, ptrdiff_t sl, ptrdiff_t sb, double *oh,
+                              double *ovp, double *ovs, double *orl, double *orr)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int mmax = nlay[b];
+    const double ar = 6370.0;
+    double dr = 0.0, r0 = ar;
+    for (int i = 0; i < mmax; ++i) {
+        const ptrdiff_t o = (ptrdiff_t)b * sb + (ptrdiff_t)i * sl;
+        const float d = (i == mmax - 1) ? 1.0f : (float)h[o]; // d(mmax) = 1.0 while transforming
+        const float a = (float)vp[o], bb = (float)vs[o], rt = (float)rho[o];
+        dr = dr + (double)d;
+        const double r1 = ar - dr;
+        const double z0 = ar * log(ar / r0);
+        const double z1 = ar * log(ar / r1);
+        const float dn = (i == mmax - 1) ? 0.0f : (float)(z1 - z0); // d(mmax) = 0 afterwards
+        const double tmp = (ar + ar) / (r0 + r1);                   // layer mid-point
+        const float btp = (float)tmp;
+        float p5 = btp * btp; // btp**(-5) the way compiler-rt's __powisf2 does it
+        p5 = p5 * p5;
+        p5 = btp * p5;
+        const size_t q = (size_t)i * B + b;
+        oh[q] = (double)dn;
+        ovp[q] = (double)(float)((double)a * tmp);
+        ovs[q] = (double)(float)((double)bb * tmp);
+        orl[q] = (double)(rt * (1.0f / p5));
+        orr[q] = (double)(rt * powf(btp, -2.275f));
+        r0 = r1;
+    }
+}
+
+// ---- np.interp, row-wise (numpy/core/src/multiarray/compiled_base.c: arr_interp) -------------------
+__global__ void interp_kernel(int B, int K0, const double *x0, const double *y0, int ld0, int K1,
+                              const double *x1, double *y1, int ld1)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * K1) return;
+    const int b = t / K1, k = t % K1;
+    const double x = x1[k];
+    const double *fp = y0 + (size_t)b * ld0;
+    double r;
+    if (x < x0[0]) r = fp[0];
+    else if (x > x0[K0 - 1]) r = fp[K0 - 1];
+    else {
+        int j = 0; // largest j with x0[j] <= x
+        for (int lo = 0, hi = K0; lo < hi;) {
+            const int mid = (lo + hi) >> 1;
+            if (x0[mid] <= x) { j = mid; lo = mid + 1; } else hi = mid;
+        }
+        if (j == K0 - 1 || x0[j] == x) r = fp[j];
+        else {
+            const double slope = (fp[j + 1] - fp[j]) / (x0[j + 1] - x0[j]);
+            r = slope * (x - x0[j]) + fp[j];
+            if (r != r) { // numpy's nan rescue (an infinity in fp)
+                r = slope * (x - x0[j + 1]) + fp[j + 1];
+                if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+            }
+        }
+    }
+    y1[(size_t)b * ld1 + k] = r;
 }
 
 } // namespace
 
-size_t bh_swd_lds_bytes(int Lmax, int K)
+void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
+                      const double *vs, const double *rho, ptrdiff_t sl, ptrdiff_t sb, double *oh,
+                      double *ovp, double *ovs, double *orho_love, double *orho_ray, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sphere_kernel, dim3((B + 127) / 128), dim3(128), 0, stream, B, Lmax, nlay, h, vp, vs, rho,
+                       sl, sb, oh, ovp, ovs, orho_love, orho_ray);
+}
+
+void bh_launch_interp(int B, int K0, const double *x0, const double *y0, int ld0, int K1,
+                      const double *x1, double *y1, int ld1, hipStream_t stream)
+{
+    const int n = B * K1;
+    hipLaunchKernelGGL(interp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, B, K0, x0, y0, ld0, K1, x1, y1, ld1);
+}
+
+size_t bh_swd_lds_bytes(int Lmax, int K, int mode)
 {
     return (size_t)4 * Lmax * BH_WAVE * sizeof(float) + (size_t)2 * NEV_MAX * BH_WAVE * sizeof(double) +
-           (size_t)((K + 1) & ~1) * sizeof(double) + LIBM_TAB_BYTES;
+           (size_t)((K + 1) & ~1) * sizeof(double) + LIBM_TAB_BYTES +
+           (mode > 1 ? (size_t)2 * K * BH_WAVE * sizeof(double) : 0);
 }
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 {
     const int grid = (a.B + BH_WAVE - 1) / BH_WAVE;
-    const size_t lds = bh_swd_lds_bytes(a.Lmax, a.K);
+    const size_t lds = bh_swd_lds_bytes(a.Lmax, a.K, a.mode);
     if (iwave == 1)
         hipLaunchKernelGGL(swd_kernel<1>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
     else
@@ -1268,15 +1418,18 @@ int bh_swd_pick_group(int B, int ntargets, int Lmax)
     return G;
 }
 
-size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax) { return group_lds_bytes(G, Lmax, Kmax); }
+size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax, int maxmode) { return group_lds_bytes(G, Lmax, Kmax, maxmode); }
 
 void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream)
 {
-    int kmax = 0;
-    for (int t = 0; t < a.ntargets; ++t) kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
+    int kmax = 0, maxmode = 1;
+    for (int t = 0; t < a.ntargets; ++t) {
+        kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
+        maxmode = a.t[t].mode > maxmode ? a.t[t].mode : maxmode;
+    }
     const int mpw = BH_WAVE / G;
     const dim3 grid((a.B + mpw - 1) / mpw, a.ntargets);
-    const size_t lds = group_lds_bytes(G, a.Lmax, kmax);
+    const size_t lds = group_lds_bytes(G, a.Lmax, kmax, maxmode);
     static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
     hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE), lds, stream, a, G | redundant);
 }

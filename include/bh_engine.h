@@ -84,8 +84,11 @@ int bh_engine_synchronize(bh_engine *e);
 
 /* ---- surface-wave dispersion: replaces surfdisp96 (surfdisp96.f:55-360) -----------------
  * For each of B models: velocities at K <= 60 periods [s] for wave type `iwave`, velocity
- * type `igr`, fundamental mode (`mode` = 1; higher modes: BH_EUNSUPPORTED for now), flat
- * earth (`flsph` = 0; 1: BH_EUNSUPPORTED for now).
+ * type `igr`, modes 1..`mode` computed in turn with the values of the last one returned
+ * (surfdisp96.f:219-357; a higher mode that finds no root leaves zeros and does not set err,
+ * :313), flat (`flsph` = 0) or earth-flattened (`flsph` = 1, surfdisp96.f:486-553) model.
+ * Flat-earth results are bit-identical to the reference; the flattening transform uses the
+ * device's log/powf and agrees to ~1e-7 relative.
  *   vel[b*K + k]  float64, values are binary32-rounded like the reference's output
  *   err[b]        0 ok / 1 no root found (then vel[b][k..] = 0 from the failing period on)
  */
@@ -134,7 +137,9 @@ typedef struct bh_target_desc {
     int32_t waveno, nsamp;
     double p_s_per_deg, gauss, fsamp, tshift, nsv;
     /* observed data, HOST pointers, copied by bh_targets_set: */
-    const double *x;    /* [n] periods [s] (SWD) -- for RF the time axis is implied by fsamp/tshift */
+    const double *x;    /* [n] periods [s] (SWD; n > 60: forward model on linspace(min, max, 60) and
+                           np.interp back, like surf96_modsw.py:35-43,:119-122) -- for RF the time axis
+                           is implied by fsamp/tshift */
     const double *yobs; /* [n] */
     const double *yerr; /* [n] or NULL (only BH_LAW_NOCORR_SCALED reads it) */
     const double *rinv; /* [n*n] or NULL (only BH_LAW_GAUSS reads it) */

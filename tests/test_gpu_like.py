@@ -109,3 +109,25 @@ def test_gauss_law_mfma_contraction(engine, n, B):
     assert np.allclose(misf[:, 0], np.sqrt(np.mean(d * d, axis=1)), rtol=1e-12)
     again = engine.loglike_batch(ymod, noise)[0]
     assert np.array_equal(again, logL)  # fixed summation order: deterministic
+
+
+def test_fused_target_with_more_than_60_periods(engine):
+    """n > 60 in a fused SWD target: forward model on linspace(min, max, 60), np.interp back
+    (surf96_modsw.py:35-43, :119-122) -- against the reference's own run_model outputs."""
+    g = golden("swd_golden.npz")
+    per = g["x_p80"]
+    yobs = np.full(per.size, 3.0)
+    for ir, ref in enumerate(g["refs"]):
+        iwave, igr = {"rdispph": (2, 0), "rdispgr": (2, 1), "ldispph": (1, 0), "ldispgr": (1, 1)}[str(ref)]
+        engine.set_targets([{"kind": E.TARGET_SWD, "law": E.LAW_NOCORR, "n": per.size, "x": per, "yobs": yobs,
+                             "iwave": iwave, "igr": igr}])
+        B = g["nlay"].size
+        noise = np.tile([0.0, 0.05], (B, 1))
+        logL, misf, err, ymod = engine.evaluate_batch(g["nlay"], g["h"], g["vp"], g["vs"], noise, rho=g["rho"],
+                                                      layout="model_major", want_ymod=True)
+        ok = g["ok_p80"][:, ir].astype(bool)
+        assert np.array_equal(err == 0, ok)
+        assert np.array_equal(ymod[ok], g["y_p80"][:, ir][ok])       # bit-identical, np.interp included
+        d = g["y_p80"][:, ir][ok] - yobs
+        ref = -0.5 * (per.size * np.log(2 * np.pi) + 2 * per.size * np.log(0.05)) - 0.5 * np.sum(d * d, axis=1) / 0.05 ** 2
+        assert np.max(np.abs(logL[ok] - ref) / np.abs(ref)) <= 1e-12

@@ -98,9 +98,17 @@ def test_user_plugin_goes_through_loglike_batch():
     assert np.allclose(d, 0)
 
 
-def test_unsupported_model_params_raise():
-    from bayhunter_amd.engine import EngineError
-    p = bh.SurfDisp(np.linspace(2, 40, 10), "rdispph")
-    p.set_modelparams(mode=2)
-    with pytest.raises(EngineError):
-        p.run_model(np.array([5., 0.]), np.array([6., 8.]), np.array([3.5, 4.5]), np.array([2.7, 3.3]))
+def test_model_params_mode_and_flsph():
+    """set_modelparams(mode=, flsph=) of surf96_modsw.py:45-46 reach the device."""
+    g = golden("swd_golden.npz")
+    per = g["x_p30"]
+    for jj, im in enumerate(g["sub_idx"][:6]):
+        n = g["nlay"][im]
+        for ir, ref in enumerate(g["refs"]):
+            p = bh.SurfDisp(per, str(ref))
+            p.set_modelparams(mode=2)
+            x, y = p.run_model(g["h"][im, :n], g["vp"][im, :n], g["vs"][im, :n], g["rho"][im, :n])
+            if g["ok_mode2"][jj, ir]:
+                assert np.array_equal(y, g["y_mode2"][jj, ir])
+            else:
+                assert np.isnan(x) and np.isnan(y)

@@ -132,11 +132,60 @@ def test_parity_statistics_lvz_rich(engine, oracle):
         assert (rel == 0).mean() >= 0.999
 
 
-def test_unsupported_options_fail_loudly(engine):
+def test_bad_arguments_fail_loudly(engine):
     from bayhunter_amd.engine import EngineError
     nlay, h, vp, vs, rho = synth_models(np.random.RandomState(1), 2, 3)
     with pytest.raises(EngineError):
-        engine.swd_batch(nlay, h, vp, vs, rho, np.linspace(1, 100, 61), 2, 0)  # > 60 periods
+        engine.swd_batch(nlay, h, vp, vs, rho, np.linspace(1, 100, 61), 2, 0)  # > 60 periods (NP = 60)
+    with pytest.raises(EngineError):
+        engine.swd_batch(nlay, h, vp, vs, rho, np.linspace(1, 30, 5), 3, 0)    # iwave must be 1 or 2
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_higher_modes_match_oracle_and_reference(engine, oracle, mode):
+    """mode > 1 (surfdisp96.f:219-357): all modes up to `mode` are searched in turn, the last one
+    is returned, missing higher-mode roots leave zeros without setting err."""
+    rs = np.random.RandomState(40 + mode)
+    nlay, h, vp, vs, rho = synth_models(rs, 200, 12, lvz_frac=0.2, ragged=True)
+    per = np.linspace(2, 60, 30)
+    for iwave, igr in REFS.values():
+        v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, mode=mode)
+        ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode)
+        assert np.array_equal(e, oe) and np.array_equal(v, ov)
+    if mode == 2:
+        g = golden("swd_golden.npz")
+        sub = g["sub_idx"]
+        for ir, ref in enumerate(g["refs"]):
+            iwave, igr = REFS[str(ref)]
+            v, e = engine.swd_batch(g["nlay"][sub], g["h"][sub], g["vp"][sub], g["vs"][sub], g["rho"][sub], g["x_p30"],
+                                    iwave, igr, mode=2, layout="model_major")
+            ok = g["ok_mode2"][:, ir].astype(bool)
+            assert np.array_equal(e == 0, ok)
+            assert np.array_equal(v[ok], g["y_mode2"][:, ir][ok])
+
+
+def test_earth_flattening_matches_oracle_and_reference(engine, oracle):
+    """flsph = 1 (surfdisp96.f:486-553).  The transform's log/powf are the device library's, so this
+    option is checked to 1e-6 relative (measured ~1e-7), not bit for bit."""
+    rs = np.random.RandomState(50)
+    nlay, h, vp, vs, rho = synth_models(rs, 200, 12, ragged=True)
+    per = np.linspace(2, 60, 30)
+    for iwave, igr in REFS.values():
+        v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, flsph=1)
+        ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, flsph=1)
+        assert np.array_equal(e, oe)
+        ok = oe == 0
+        tol = 1e-6 if igr == 0 else 1e-4  # group velocity amplifies root differences ~100x (App. A.10)
+        assert np.max(np.abs(v[ok] - ov[ok]) / ov[ok]) <= tol
+    g = golden("swd_golden.npz")
+    sub = g["sub_idx"]
+    for ir, ref in enumerate(g["refs"]):
+        iwave, igr = REFS[str(ref)]
+        v, e = engine.swd_batch(g["nlay"][sub], g["h"][sub], g["vp"][sub], g["vs"][sub], g["rho"][sub], g["x_p30"],
+                                iwave, igr, flsph=1, layout="model_major")
+        ok = g["ok_sph"][:, ir].astype(bool)
+        assert np.array_equal(e == 0, ok)
+        assert np.max(np.abs(v[ok] - g["y_sph"][:, ir][ok]) / g["y_sph"][:, ir][ok]) <= (1e-6 if igr == 0 else 1e-4)
 
 
 def test_device_libm_restatement_is_bit_identical_to_host_libm(engine, oracle):
