@@ -36,6 +36,9 @@ struct TargetHost {
 struct bh_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;             // receiver-function kernels run here, next to the dispersion kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, spec, ymod, noise, logL,
@@ -84,6 +87,7 @@ int ensure(bh_engine *e, DevBuf &b, size_t bytes)
     if (bytes <= b.cap) return BH_OK;
     if (b.p) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->aux) HIPCHK(e, hipStreamSynchronize(e->aux));
         HIPCHK(e, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -379,10 +383,14 @@ int bh_engine_create(int device, bh_engine **out)
     bh_engine *e = new (std::nothrow) bh_engine;
     if (!e) return BH_ENOMEM;
     e->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete e;
         return BH_EHIP;
     }
+    if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
     *out = e;
@@ -413,6 +421,9 @@ void bh_engine_destroy(bh_engine *e)
     for (auto &s : e->evsets)
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -716,6 +727,17 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
             }
         }
     }
+    // The receiver-function kernels are independent of the dispersion kernel and write other columns
+    // of ymod: they run on a second stream so that their (throughput-bound) wavefronts fill the issue
+    // slots the (latency-bound) dispersion wavefronts leave idle.  fork -> [swd | rf] -> join -> like.
+    bool have_rf = false;
+    for (int t = 0; t < nt; ++t) have_rf = have_rf || e->targets[(size_t)t].d.kind == BH_TARGET_RF;
+    const bool fork = have_rf && njobs > 0 && e->overlap_rf;
+    hipStream_t rst = fork ? e->aux : st;
+    if (fork) {
+        HIPCHK(e, hipEventRecord(e->ev_fork, st));
+        HIPCHK(e, hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+    }
     if ((rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs))) return rc;
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];
@@ -724,9 +746,13 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
             bh_launch_interp(B, T.kfwd, (const double *)T.x60.p, (const double *)T.vel60.p, T.kfwd, d.n,
                              (const double *)T.x.p, ymod_d + T.off, ldy, st);
         if (d.kind != BH_TARGET_RF) continue;
-        rc = launch_rf(e, st, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
+        rc = launch_rf(e, rst, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
                        d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
         if (rc) return rc;
+    }
+    if (fork) {
+        HIPCHK(e, hipEventRecord(e->ev_join, e->aux));
+        HIPCHK(e, hipStreamWaitEvent(st, e->ev_join, 0));
     }
     for (int t = 0; t < nt; ++t)
         if ((rc = prepare_like_target(e, st, B, ldy, ymod_d, e->targets[(size_t)t], la.t[t]))) return rc;
