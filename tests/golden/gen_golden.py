@@ -42,7 +42,37 @@ def import_reference():
     zmq.PUB, zmq.SUB, zmq.SNDMORE = 1, 2, 2
     sys.modules["zmq"] = zmq
     cfg = types.ModuleType("configobj")
-    cfg.ConfigObj = dict
+
+    class ConfigObj(dict):  # just enough of configobj for utils.load_params on defaults.ini
+        def __init__(self, path):
+            dict.__init__(self)
+            self.sections = []
+            cur = None
+            for line in open(path):
+                line = line.split("#")[0].strip()
+                if not line:
+                    continue
+                if line.startswith("["):
+                    cur = line.strip("[]")
+                    self[cur] = {}
+                    self.sections.append(cur)
+                else:
+                    k, v = [t.strip() for t in line.split("=", 1)]
+                    # configobj splits on top-level commas only
+                    parts, depth, tok = [], 0, ""
+                    for ch in v:
+                        if ch in "([":
+                            depth += 1
+                        if ch in ")]":
+                            depth -= 1
+                        if ch == "," and depth == 0:
+                            parts.append(tok.strip()); tok = ""
+                        else:
+                            tok += ch
+                    parts.append(tok.strip())
+                    self[cur][k] = parts if len(parts) > 1 else parts[0]
+
+    cfg.ConfigObj = ConfigObj
     sys.modules["configobj"] = cfg
     import matplotlib
     matplotlib.use("Agg")
@@ -259,6 +289,60 @@ def main():
                         n=np.array(n_l, dtype=np.int32), vpvs=np.array(vpvs_l),
                         use_mantle=np.array(mantle_l, dtype=np.int32), mantle=np.array([4.3, 1.8]),
                         vp=pad(vp_l, Lmax), vs=pad(vs_l, Lmax), h=pad(h_l, Lmax))
+    # ---- 5. a recorded SingleChain run (the caller of the hot path), two noise-law set-ups ---------------
+    from multiprocessing import sharedctypes
+    SingleChain = sys.modules["BayHunter.SingleChain"].SingleChain
+    xsw = period_sets["p21"]
+    xrf = time_axes["n201"]
+    st3 = lambda n: np.loadtxt(os.path.join(REF, "tutorial", "observed", "st3_%s.dat" % n)).T
+    nrs = np.random.RandomState(99)
+    ysw = st3("rdispph")[1] + nrs.normal(0, 0.012, xsw.size)
+    yrf = st3("prf")[1] + nrs.normal(0, 0.005, xrf.size)
+    out = {"xsw": xsw, "ysw": ysw, "xrf": xrf, "yrf": yrf}
+    setups = {"exp": dict(priors=dict(vpvs=(1.4, 2.1), layers=(1, 10), vs=(2, 5), z=(0, 60), rfnoise_corr=(0.35, 0.75),
+                                      rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1)),
+                          init=dict(nchains=1, iter_burnin=1500, iter_main=700, acceptance=(40, 80), thickmin=0.1, lvz=0.1,
+                                    hvz=None, rcond=None, maxmodels=400), seeds=(11, 12)),
+              "gauss": dict(priors=dict(vpvs=1.73, layers=(1, 8), vs=(2, 5), z=(0, 60), mohoest=(30, 8), rfnoise_corr=0.9,
+                                        rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1)),
+                            init=dict(nchains=1, iter_burnin=1200, iter_main=500, acceptance=(40, 80), thickmin=0.1, lvz=None,
+                                      hvz=None, rcond=1e-5, maxmodels=50000), seeds=(21,))}
+    for name, su in setups.items():
+        for seed in su["seeds"]:
+            t1 = Targets.RayleighDispersionPhase(xsw, ysw)
+            t2 = Targets.PReceiverFunction(xrf, yrf)
+            t2.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
+            jt = Targets.JointTarget(targets=[t1, t2])
+            tmp = tempfile.mkdtemp(prefix="bhchain_")
+            os.makedirs(os.path.join(tmp, "data"))
+            init = dict(su["init"]); init["savepath"] = tmp; init["station"] = "gold"
+            iters = init["iter_burnin"] + init["iter_main"]
+            nmodels = int(iters * np.max(init["acceptance"]) / 100.)
+            maxlayers = int(su["priors"]["layers"][1]) + 1
+            mk = lambda n: sharedctypes.RawArray("f", n)
+            shared = [mk(nmodels * maxlayers * 2), mk(nmodels * 3), mk(nmodels), mk(nmodels * 4), mk(nmodels)]
+            for a in shared:
+                np.frombuffer(a, dtype=np.float32).fill(np.nan)
+            chain = SingleChain(targets=jt, chainidx=0, initparams=init, modelpriors=su["priors"], sharedmodels=shared[0],
+                                sharedmisfits=shared[1], sharedlikes=shared[2], sharednoise=shared[3], sharedvpvs=shared[4],
+                                random_seed=seed)
+            chain.run_chain()
+            key = "%s_s%d_" % (name, seed)
+            out[key + "models"] = np.array(chain.chainmodels); out[key + "likes"] = np.array(chain.chainlikes)
+            out[key + "misfits"] = np.array(chain.chainmisfits); out[key + "noise"] = np.array(chain.chainnoise)
+            out[key + "vpvs"] = np.array(chain.chainvpvs); out[key + "iters"] = np.array(chain.chainiter)
+            out[key + "propdist"] = np.array(chain.propdist); out[key + "accepted"] = np.array(chain.accepted)
+            out[key + "proposed"] = np.array(chain.proposed)
+            for ph in ("p1", "p2"):   # the files the reference wrote (SingleChain.py:665-690)
+                for nm in ("models", "likes", "misfits", "noise", "vpvs"):
+                    f = os.path.join(tmp, "data", "c000_%s%s.npy" % (ph, nm))
+                    if os.path.exists(f):
+                        out[key + "file_" + ph + nm] = np.load(f)
+            print("chain", name, seed, "accepted rows", chain.chainlikes.size, "final logL", chain.chainlikes[-1],
+                  "propdist", chain.propdist)
+            shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, "chain_golden.npz"), **out)
+
     for f in sorted(os.listdir(HERE)):
         p = os.path.join(HERE, f)
         if os.path.isfile(p):
