@@ -12,12 +12,11 @@ REFS = {"rdispph": (2, 0), "rdispgr": (2, 1), "ldispph": (1, 0), "ldispgr": (1, 
 RTOL = 1e-5
 # Model 73 of the golden set (vs = 3.9/1.6/4.4/3.0 km/s: a 1.6 km/s channel over a slow
 # half-space) is search-chaotic: surf96 jumps between modes from period to period and its
-# Neville refinement is ill-conditioned there, so a 1-ulp difference between the device's
-# sin/cos/exp and glibc's changes the number of refinement steps (812 vs 813 evaluations).
-# The phase velocity still agrees to 5e-7, but the group velocity -- a finite difference of two
-# roots, ~100x amplification -- moves by 1.1e-4 at one period.  The
-# reference is not reproducible against itself at this level across libm builds either.
-CHAOTIC_RTOL = 2e-4
+# Neville refinement is ill-conditioned there.  With the device library's sin/cos/exp (1 ulp from
+# glibc) the number of refinement steps changed (812 vs 813 evaluations) and the group velocity
+# moved by 1.1e-4 at one period.  Since the dispersion kernels use the glibc-exact restatement
+# (csrc/bh_libm.h) this model, like every other, is reproduced bit for bit; it stays in the
+# tests as the canary for that property.
 
 
 def compare(vel, err, ovel, oerr):
@@ -42,7 +41,7 @@ def test_random_ragged_models_match_oracle(engine, oracle, ref):
     vel, err = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
     ovel, oerr, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
     rel = compare(vel, err, ovel, oerr)
-    assert (rel == 0).mean() > 0.99  # bit-identical after the binary32 output rounding
+    assert np.all(rel == 0)  # bit-identical
 
 
 @pytest.mark.parametrize("pset", ["p21", "p30"])
@@ -56,11 +55,8 @@ def test_reference_golden_vectors(engine, pset):
         ok = g["ok_" + pset][:, ir].astype(bool)
         assert np.array_equal(err == 0, ok)
         ref_y = g["y_" + pset][:, ir]
-        rel = np.abs(vel - ref_y) / np.abs(ref_y)
-        regular = ok.copy(); regular[73] = False
-        assert np.max(rel[regular]) <= RTOL
-        if ok[73]:
-            assert np.max(rel[73]) <= CHAOTIC_RTOL and (rel[73] > RTOL).sum() <= 1
+        assert np.max(np.abs(vel[ok] - ref_y[ok]) / np.abs(ref_y[ok])) <= RTOL   # north_star bar
+        assert np.array_equal(vel[ok], ref_y[ok])                                # what is achieved
 
 
 @pytest.mark.parametrize("ref", sorted(REFS))
@@ -109,16 +105,12 @@ def test_failing_models_are_reported_in_band(engine, oracle):
     for iwave, igr in REFS.values():
         v, e = engine.swd_batch(np.array([4]), h, vp, vs, rho, per, iwave, igr)
         ov, oe, _ = oracle.swd_batch(np.array([4]), h.T, vp.T, vs.T, rho.T, per, iwave, igr)
-        assert np.array_equal(e, oe) and np.array_equal(v == 0, ov == 0)
-        nz = ov != 0
-        rel = np.abs(v[nz] - ov[nz]) / ov[nz]
-        assert rel.max() <= CHAOTIC_RTOL and (rel > RTOL).sum() <= 1  # this is golden model 73
+        assert np.array_equal(e, oe) and np.array_equal(v, ov)  # golden model 73: bit for bit
     assert e[0] == 1  # Love finds no root at all beyond the 7th period
 
 
 def test_parity_statistics_lvz_rich(engine, oracle):
-    """20k models, a quarter with a low-velocity layer: how often does the 1-ulp libm
-    difference surface at all?  (Larger runs are quoted in DESIGN.md.)"""
+    """20k models, a quarter with a low-velocity layer, all four wave/velocity types."""
     rs = np.random.RandomState(2024)
     nlay, h, vp, vs, rho = synth_models(rs, 20000, 12, lvz_frac=0.25, ragged=True)
     per = np.linspace(2, 60, 30)
@@ -128,8 +120,7 @@ def test_parity_statistics_lvz_rich(engine, oracle):
         assert np.array_equal(e, oe)
         ok = oe == 0
         rel = np.abs(v[ok] - ov[ok]) / ov[ok]
-        assert (rel.max(axis=1) > RTOL).mean() <= 1e-3
-        assert (rel == 0).mean() >= 0.999
+        assert np.array_equal(v[ok], ov[ok])  # bit-identical, every model, every period
 
 
 def test_bad_arguments_fail_loudly(engine):
