@@ -228,7 +228,7 @@ def main():
                                 "achieved_tflops": flop / (fam_ms["swd"] / max(1, ncalls) * 1e-3) / 1e12,
                                 "peak_tflops": FP64_VALU_PEAK_TF,
                                 "note": "flop-equivalents (Rayleigh 320, Love 65 per layer step, ~equal eval counts)"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, args.workload)
             except Exception as ex:  # the baseline must never take the GPU number down with it
