@@ -1,0 +1,330 @@
+// bayhunter_amd/csrc/chain_kernel.hip -- device-resident rj-McMC chain step (one lane = one chain).
+//
+// Replaces, for thousands of chains advanced in lock-step, the host part of the reference's
+// per-chain sampler around the forward call (src/SingleChain.py:511-589 `iterate`):
+//   chain_propose_kernel   draw the modification and the proposal (:246-328, :394-413), sort the
+//                          nuclei (:315-328), check priors and validity (:330-420), convert the
+//                          Voronoi nuclei to layers (src/Models.py:26-52) and write the layered model
+//                          straight into the layer-major [Lmax][C] arrays bh_evaluate_batch reads;
+//   chain_accept_kernel    acceptance probability incl. the birth/death terms (:452-487), accept or
+//                          keep, move counters, proposal-width adaptation every 1000 iterations
+//                          (:425-450, :584-587).
+// The forward models + likelihood between the two are bh_evaluate_batch on device pointers.
+// Random numbers: Philox4x32-10, counter = (chain, iteration, purpose), key = seed -- every draw is
+// a pure function of its coordinates, so results do not depend on scheduling.  (The reference uses
+// one Mersenne-Twister stream per chain; trajectories therefore agree statistically, not draw by
+// draw.  The draw-by-draw replay of the reference is bayhunter_amd/chains.py.)  For testing, the
+// draws can be injected from a buffer instead.
+#include "../../include/bh_engine.h"
+#include "bh_device.h"
+
+namespace {
+
+struct Philox {
+    uint32_t k0, k1;
+    __device__ void round(uint32_t c[4])
+    {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    __device__ void gen(uint64_t seed, uint32_t a, uint32_t b, uint32_t cc, uint32_t out[4])
+    {
+        k0 = (uint32_t)seed;
+        k1 = (uint32_t)(seed >> 32);
+        uint32_t c[4] = {a, b, cc, 0u};
+        for (int i = 0; i < 10; ++i) round(c);
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) // [0, 1), 53 bits
+{
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// the draws one iteration of one chain may need
+struct Draws {
+    double u_move, u_index, u_z, u_accept, u_noise, normal;
+};
+
+__device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, int c, int C, int iiter)
+{
+    Draws d;
+    if (S.inject != nullptr) { // test mode: [6][C]
+        d.u_move = S.inject[0 * (size_t)C + c]; d.u_index = S.inject[1 * (size_t)C + c];
+        d.u_z = S.inject[2 * (size_t)C + c]; d.u_accept = S.inject[3 * (size_t)C + c];
+        d.u_noise = S.inject[4 * (size_t)C + c]; d.normal = S.inject[5 * (size_t)C + c];
+        return d;
+    }
+    Philox ph;
+    uint32_t r[4], q[4], t[4];
+    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 0u, r);
+    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 1u, q);
+    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 2u, t);
+    d.u_move = u01(r[0], r[1]); d.u_index = u01(r[2], r[3]);
+    d.u_z = u01(q[0], q[1]); d.u_accept = u01(q[2], q[3]);
+    d.u_noise = u01(t[0], t[1]);
+    const double a = 1.0 - u01(t[2], t[3]); // (0, 1]
+    const double bq = u01(r[0] ^ 0x9E3779B9u, q[1]);
+    d.normal = sqrt(-2.0 * log(a)) * cospi(2.0 * bq); // Box-Muller
+    return d;
+}
+
+enum { MV_VS = 0, MV_Z = 1, MV_BIRTH = 2, MV_DEATH = 3, MV_NOISE = 4, MV_VPVS = 5 };
+__device__ __forceinline__ int par_index(int mv) { return mv <= 1 ? mv : (mv <= 3 ? 2 : mv - 1); } // PAR_MAP
+
+__global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int C, int iiter)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int ML = cfg.maxlayers, nt = cfg.nt;
+    const Draws d = get_draws(cfg, S, c, C, iiter);
+    // ---- which modification (SingleChain.py:512-517, :596-599) ---------------------------------
+    int nnoise = 0;
+    for (int i = 0; i < 2 * nt; ++i) nnoise += (cfg.noise_lo[i] != cfg.noise_hi[i]);
+    const bool vpvs_free = cfg.vpvsmin != cfg.vpvsmax;
+    const bool early = (double)iiter < (-(double)cfg.iter_burnin + (double)cfg.iterations * 0.01);
+    int moves[6], nm = 0;
+    moves[nm++] = MV_VS;
+    moves[nm++] = MV_Z;
+    if (!early) {
+        moves[nm++] = MV_BIRTH;
+        moves[nm++] = MV_DEATH;
+    }
+    if (nnoise > 0) moves[nm++] = MV_NOISE;
+    if (vpvs_free) moves[nm++] = MV_VPVS;
+    int mi = (int)(d.u_move * nm);
+    if (mi >= nm) mi = nm - 1;
+    const int mv = moves[mi];
+
+    // ---- proposal -----------------------------------------------------------------------------------
+    double vs[BH_CHAIN_MAXLAYERS + 1], z[BH_CHAIN_MAXLAYERS + 1];
+    int n = S.n[c];
+    for (int i = 0; i < n; ++i) {
+        vs[i] = S.vs[(size_t)i * C + c];
+        z[i] = S.z[(size_t)i * C + c];
+    }
+    double vpvs = S.vpvs[c];
+    double noise[2 * BH_MAX_TARGETS];
+    for (int i = 0; i < 2 * nt; ++i) noise[i] = S.noise[(size_t)i * C + c];
+    double dvs2 = 0.0;
+    bool valid = true;
+    if (mv == MV_VS) {
+        int ind = (int)(d.u_index * n);
+        if (ind >= n) ind = n - 1;
+        vs[ind] = vs[ind] + d.normal * S.propdist[0 * (size_t)C + c];
+    } else if (mv == MV_Z) {
+        int ind = (int)(d.u_index * n);
+        if (ind >= n) ind = n - 1;
+        z[ind] = z[ind] + d.normal * S.propdist[1 * (size_t)C + c];
+    } else if (mv == MV_BIRTH) {
+        const double zb = cfg.zmin + d.u_z * (cfg.zmax - cfg.zmin);
+        int near = 0;
+        double best = fabs(z[0] - zb);
+        for (int i = 1; i < n; ++i)
+            if (fabs(z[i] - zb) < best) {
+                best = fabs(z[i] - zb);
+                near = i;
+            }
+        const double vb = vs[near] + d.normal * S.propdist[2 * (size_t)C + c];
+        dvs2 = (vb - vs[near]) * (vb - vs[near]);
+        if (n >= ML) valid = false; // would exceed the layer prior anyway
+        else {
+            vs[n] = vb;
+            z[n] = zb;
+            n += 1;
+        }
+    } else if (mv == MV_DEATH) {
+        int ind = (int)(d.u_index * n);
+        if (ind >= n) ind = n - 1;
+        const double zb = z[ind], vb = vs[ind];
+        for (int i = ind; i + 1 < n; ++i) {
+            vs[i] = vs[i + 1];
+            z[i] = z[i + 1];
+        }
+        n -= 1;
+        if (n < 1) valid = false;
+        else {
+            int near = 0;
+            double best = fabs(z[0] - zb);
+            for (int i = 1; i < n; ++i)
+                if (fabs(z[i] - zb) < best) {
+                    best = fabs(z[i] - zb);
+                    near = i;
+                }
+            dvs2 = (vs[near] - vb) * (vs[near] - vb);
+        }
+    } else if (mv == MV_NOISE) {
+        int pick = (int)(d.u_noise * nnoise);
+        if (pick >= nnoise) pick = nnoise - 1;
+        int idx = 0;
+        for (int i = 0, seen = 0; i < 2 * nt; ++i)
+            if (cfg.noise_lo[i] != cfg.noise_hi[i]) {
+                if (seen == pick) idx = i;
+                ++seen;
+            }
+        noise[idx] = noise[idx] + d.normal * S.propdist[3 * (size_t)C + c];
+        for (int i = 0; i < 2 * nt; ++i)
+            if (cfg.noise_lo[i] != cfg.noise_hi[i] && (noise[i] < cfg.noise_lo[i] || noise[i] > cfg.noise_hi[i])) valid = false;
+    } else {
+        vpvs = vpvs + d.normal * S.propdist[4 * (size_t)C + c];
+        if (vpvs < cfg.vpvsmin || vpvs > cfg.vpvsmax) valid = false;
+    }
+    // nuclei sorted by depth (:315-328); insertion sort is stable like the reference's argsort use
+    for (int i = 1; i < n; ++i) {
+        const double zi = z[i], vi = vs[i];
+        int j = i - 1;
+        while (j >= 0 && z[j] > zi) {
+            z[j + 1] = z[j];
+            vs[j + 1] = vs[j];
+            --j;
+        }
+        z[j + 1] = zi;
+        vs[j + 1] = vi;
+    }
+    // ---- nuclei -> layers (Models.py:39-52), validity with the CURRENT vp/vs (:330-392) ------------
+    double h[BH_CHAIN_MAXLAYERS + 1];
+    double prev = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double zd = (z[i] + z[i + 1]) / 2.;
+        h[i] = zd - prev;
+        prev = zd;
+    }
+    if (n >= 1) h[n - 1] = 0.0;
+    if (valid && (mv <= MV_DEATH)) {
+        const int layermodel = n - 1;
+        if (!(layermodel >= cfg.layermin && layermodel <= cfg.layermax)) valid = false;
+        double zc = 0.0;
+        for (int i = 0; i < n && valid; ++i) {
+            if (i < n - 1 && h[i] < cfg.thickmin) valid = false;
+            if (vs[i] < cfg.vsmin || vs[i] > cfg.vsmax) valid = false;
+            zc += h[i];
+            if (zc < cfg.zmin || zc > cfg.zmax) valid = false;
+            if (i + 1 < n) {
+                if (cfg.lvz >= 0.0 && !(vs[i + 1] - vs[i] * (1 - cfg.lvz) > 0)) valid = false;
+                if (cfg.hvz >= 0.0 && !(vs[i] * (1 + cfg.hvz) - vs[i + 1] > 0)) valid = false;
+            }
+        }
+    }
+    // ---- write the proposal and the layered model (invalid: re-evaluate the current model) ---------
+    S.move[c] = mv;
+    S.valid[c] = valid ? 1 : 0;
+    S.dvs2[c] = dvs2;
+    if (!valid) { // keep the evaluate batch well-formed: it sees the current model, result ignored
+        n = S.n[c];
+        for (int i = 0; i < n; ++i) {
+            vs[i] = S.vs[(size_t)i * C + c];
+            z[i] = S.z[(size_t)i * C + c];
+        }
+        vpvs = S.vpvs[c];
+        for (int i = 0; i < 2 * nt; ++i) noise[i] = S.noise[(size_t)i * C + c];
+        prev = 0.0;
+        for (int i = 0; i + 1 < n; ++i) {
+            const double zd = (z[i] + z[i + 1]) / 2.;
+            h[i] = zd - prev;
+            prev = zd;
+        }
+        h[n - 1] = 0.0;
+    }
+    S.pn[c] = n;
+    S.pvpvs[c] = vpvs;
+    for (int i = 0; i < n; ++i) {
+        S.pvs[(size_t)i * C + c] = vs[i];
+        S.pz[(size_t)i * C + c] = z[i];
+    }
+    for (int i = 0; i < 2 * nt; ++i) S.pnoise[(size_t)c * 2 * nt + i] = noise[i]; // [C][2nt]: evaluate's layout
+    // vp: crustal vp/vs down to the first layer with vs >= mantle[0], mantle[1] below (Models.py:26-37)
+    bool deep = false;
+    for (int i = 0; i < n; ++i) {
+        if (cfg.mantle_vs > 0.0 && vs[i] >= cfg.mantle_vs) deep = true;
+        S.lay_h[(size_t)i * C + c] = h[i];
+        S.lay_vs[(size_t)i * C + c] = vs[i];
+        S.lay_vp[(size_t)i * C + c] = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
+    }
+    S.lay_n[c] = n;
+}
+
+__global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C, int iiter, const double *logL,
+                                    const double *misfits)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int nt = cfg.nt;
+    if (S.valid[c]) {
+        const Draws d = get_draws(cfg, S, c, C, iiter);
+        const int mv = S.move[c];
+        const int pi = par_index(mv);
+        S.proposed[pi * (size_t)C + c] += 1.0;
+        const double like = logL[c], cur = S.like[c];
+        double alpha;
+        if (mv == MV_BIRTH || mv == MV_DEATH) { // Bodin et al. (2012), SingleChain.py:468-485
+            const double theta = S.propdist[2 * (size_t)C + c];
+            const double dv = cfg.vsmax - cfg.vsmin;
+            const double Bt = S.dvs2[c] / (2. * (theta * theta));
+            if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + (like - cur);
+            else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + (like - cur);
+        } else {
+            alpha = like - cur;
+        }
+        if (log(d.u_accept) < alpha) {
+            const int n = S.pn[c];
+            S.n[c] = n;
+            for (int i = 0; i < n; ++i) {
+                S.vs[(size_t)i * C + c] = S.pvs[(size_t)i * C + c];
+                S.z[(size_t)i * C + c] = S.pz[(size_t)i * C + c];
+            }
+            S.vpvs[c] = S.pvpvs[c];
+            for (int i = 0; i < 2 * nt; ++i) S.noise[(size_t)i * C + c] = S.pnoise[(size_t)c * 2 * nt + i];
+            S.like[c] = like;
+            for (int i = 0; i <= nt; ++i) S.misfits[(size_t)i * C + c] = misfits[(size_t)c * (nt + 1) + i];
+            S.accepted[pi * (size_t)C + c] += 1.0;
+            S.naccepted[c] += 1;
+        }
+        // proposal-width adaptation (SingleChain.py:425-450): only reached with a valid proposal (:584)
+        if (iiter % 1000 == 0) {
+            bool all = true;
+            for (int i = 0; i < 5; ++i) all = all && (S.proposed[i * (size_t)C + c] != 0.0);
+            if (all)
+                for (int i = 0; i < 5; ++i) {
+                    const double rate = S.accepted[i * (size_t)C + c] / S.proposed[i * (size_t)C + c] * 100;
+                    double pd = S.propdist[i * (size_t)C + c];
+                    if (rate < cfg.acc_lo) {
+                        pd = pd * 0.95;
+                        if (pd < 0.001) pd = 0.001;
+                    } else if (rate > cfg.acc_hi) {
+                        pd = pd * 1.05;
+                    }
+                    S.propdist[i * (size_t)C + c] = pd;
+                }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter)
+{
+    if (!cfg || !state || C < 0 || cfg->maxlayers > BH_CHAIN_MAXLAYERS || cfg->nt > BH_MAX_TARGETS) return BH_EINVAL;
+    if (C == 0) return BH_OK;
+    hipLaunchKernelGGL(chain_propose_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter);
+    return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
+}
+
+int bh_chain_accept(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
+                    const double *logL, const double *misfits)
+{
+    if (!cfg || !state || C < 0 || !logL || !misfits) return BH_EINVAL;
+    if (C == 0) return BH_OK;
+    hipLaunchKernelGGL(chain_accept_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter,
+                       logL, misfits);
+    return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
+}
+
+} // extern "C"

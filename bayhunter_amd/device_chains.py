@@ -1,0 +1,201 @@
+"""Device-resident chains: thousands of rj-McMC chains advanced in lock-step with no host work
+per chain.
+
+One iteration = three enqueues on the engine's stream (include/bh_engine.h):
+    bh_chain_propose  ->  bh_evaluate_batch (device pointers)  ->  bh_chain_accept
+so the per-chain Python of the reference's sampler (src/SingleChain.py:511-589 `iterate`, and the
+per-chain loops of `bayhunter_amd.chains.ChainBatch`) disappears from the loop; the host only
+counts iterations and takes thinned snapshots of the chain states.
+
+Random numbers are counter-based (Philox4x32-10) on the device, so a run is reproducible from
+`seed` but is NOT the reference's Mersenne-Twister trajectory: `ChainBatch` is the draw-for-draw
+replay of the reference, this class is the throughput mode.  The proposal / validity / acceptance
+arithmetic is the same and is tested against an independent numpy restatement with injected draws
+(tests/test_gpu_device_chains.py).
+
+The initial state (initial models, noise, covariance-law selection, first likelihood) is produced by
+`ChainBatch` exactly as the reference does (SingleChain.py:71-205) and uploaded once.
+
+Storage: the reference keeps every accepted model with its iteration stamp and, when saving,
+repeats each by its dwell time and thins to `maxmodels` rows (SingleChain.py:591-690) -- i.e. it
+keeps the chain's current model at every `thinning`-th iteration.  Here that sampling is done on
+the fly: every `thinning`-th iteration the current state of all chains is copied out, which is the
+same estimator without storing what would be thinned away.  (One difference: the reference's
+main-phase file starts with the first model ACCEPTED at iteration >= 0; here the main phase starts
+with the model that is current at iteration 0.)
+"""
+import ctypes as C
+import os
+import os.path as op
+
+import numpy as np
+
+from .chains import ChainBatch, DEFAULT_INITPARAMS, DEFAULT_PRIORS, _is_fixed
+from .engine import BH_CHAIN_MAXLAYERS, ChainConfig, ChainState, EngineError
+from .Targets import JointTarget
+
+
+class DeviceChains(object):
+    def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=0, inject=False):
+        import torch
+        self.torch = torch
+        self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
+        self.engine = self.targets.engine
+        self.priors = dict(DEFAULT_PRIORS)
+        self.priors.update(modelpriors or {})
+        self.initparams = dict(DEFAULT_INITPARAMS)
+        self.initparams.update(initparams or {})
+        ip, pr = self.initparams, self.priors
+        self.C = int(nchains)
+        self.nt = self.targets.ntargets
+        self.ML = int(pr["layers"][1]) + 1
+        if self.ML > BH_CHAIN_MAXLAYERS:
+            raise EngineError("priors['layers'][1] + 1 = %d exceeds BH_CHAIN_MAXLAYERS = %d" % (self.ML, BH_CHAIN_MAXLAYERS))
+        self.iter_phase1, self.iter_phase2 = int(ip["iter_burnin"]), int(ip["iter_main"])
+        self.iterations = self.iter_phase1 + self.iter_phase2
+        self.iiter = -self.iter_phase1
+        self.thinning = max(1, int(np.ceil(float(self.iter_phase2) / float(ip["maxmodels"]))))
+
+        # ---- initial state through the reference-order host code --------------------------------
+        seeds = np.random.RandomState((int(seed) ^ (int(seed) >> 32)) & 0xFFFFFFFF).randint(0, 2 ** 31 - 1, size=self.C)
+        host = ChainBatch(self.targets, seeds, ip, pr)
+        self.noisepriors = host.noisepriors
+        self.targets._register()  # constant target data + laws live on the device from here on
+
+        cfg = ChainConfig()
+        cfg.nt, cfg.maxlayers = self.nt, self.ML
+        cfg.layermin, cfg.layermax = int(pr["layers"][0]), int(pr["layers"][1])
+        cfg.iter_burnin, cfg.iterations = self.iter_phase1, self.iterations
+        (cfg.vsmin, cfg.vsmax), (cfg.zmin, cfg.zmax) = pr["vs"], pr["z"]
+        cfg.thickmin = ip["thickmin"]
+        cfg.lvz = -1.0 if ip["lvz"] is None else ip["lvz"]
+        cfg.hvz = -1.0 if ip["hvz"] is None else ip["hvz"]
+        if _is_fixed(pr["vpvs"]):
+            cfg.vpvsmin = cfg.vpvsmax = float(pr["vpvs"])
+        else:
+            cfg.vpvsmin, cfg.vpvsmax = pr["vpvs"]
+        if pr["mantle"] is None:
+            cfg.mantle_vs, cfg.mantle_vpvs = -1.0, 0.0
+        else:
+            cfg.mantle_vs, cfg.mantle_vpvs = pr["mantle"]
+        cfg.acc_lo, cfg.acc_hi = ip["acceptance"]
+        for i, p in enumerate(self.noisepriors):
+            if _is_fixed(p):
+                cfg.noise_lo[i] = cfg.noise_hi[i] = float(p)
+            else:
+                cfg.noise_lo[i], cfg.noise_hi[i] = p
+        cfg.seed = int(seed) & (2 ** 64 - 1)
+        self.cfg = cfg
+
+        dev = torch.device("cuda", device)
+        Cn, ML, nt = self.C, self.ML, self.nt
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        t = {}
+        vs0 = np.zeros((ML, Cn)); z0 = np.zeros((ML, Cn)); n0 = np.zeros(Cn, dtype=np.int32)
+        noise0 = np.zeros((2 * nt, Cn)); mis0 = np.zeros((nt + 1, Cn))
+        like0 = np.zeros(Cn); vpvs0 = np.zeros(Cn); pd0 = np.zeros((5, Cn))
+        for c, ch in enumerate(host.chains):
+            m = np.asarray(ch.currentmodel, dtype=float)
+            n = m.size // 2
+            n0[c] = n
+            vs0[:n, c], z0[:n, c] = m[:n], m[n:]
+            noise0[:, c] = ch.currentnoise
+            mis0[:, c] = ch.currentmisfits
+            like0[c], vpvs0[c] = ch.currentlikelihood, ch.currentvpvs
+            pd0[:, c] = ch.propdist
+        t["n"] = torch.from_numpy(n0).to(dev)
+        t["vs"], t["z"] = torch.from_numpy(vs0).to(dev), torch.from_numpy(z0).to(dev)
+        t["vpvs"], t["noise"] = torch.from_numpy(vpvs0).to(dev), torch.from_numpy(noise0).to(dev)
+        t["like"], t["misfits"] = torch.from_numpy(like0).to(dev), torch.from_numpy(mis0).to(dev)
+        t["propdist"] = torch.from_numpy(pd0).to(dev)
+        t["proposed"], t["accepted"] = torch.zeros((5, Cn), **f64), torch.zeros((5, Cn), **f64)
+        t["naccepted"] = torch.zeros(Cn, dtype=torch.int64, device=dev)
+        for k in ("pn", "move", "valid", "lay_n"):
+            t[k] = torch.zeros(Cn, **i32)
+        for k in ("pvs", "pz", "lay_h", "lay_vp", "lay_vs"):
+            t[k] = torch.zeros((ML, Cn), **f64)
+        t["pvpvs"], t["dvs2"] = torch.zeros(Cn, **f64), torch.zeros(Cn, **f64)
+        t["pnoise"] = torch.zeros((Cn, 2 * nt), **f64)
+        t["inject"] = torch.zeros((6, Cn), **f64) if inject else None
+        self.t = t
+        # outputs of the evaluate call of the current iteration
+        self.logL = torch.zeros(Cn, **f64)
+        self.mis = torch.zeros((Cn, nt + 1), **f64)
+        self.err = torch.zeros(Cn, **i32)
+        st = ChainState()
+        for k in ChainState._fields_:
+            v = t[k[0]]
+            setattr(st, k[0], None if v is None else v.data_ptr())
+        self.state = st
+        torch.cuda.synchronize(dev)
+        self.snap = {"p1": [], "p2": []}
+
+    # ---- one lock-step iteration of all chains: three enqueues, no synchronisation -----------------
+    def iterate(self):
+        e, t, Cn = self.engine, self.t, self.C
+        e.chain_propose(self.cfg, self.state, Cn, self.iiter)
+        e.evaluate_batch_dev(Cn, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
+                             t["lay_vs"].data_ptr(), None, Cn, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
+                             self.mis.data_ptr(), self.err.data_ptr())
+        e.chain_accept(self.cfg, self.state, Cn, self.iiter, self.logL.data_ptr(), self.mis.data_ptr())
+        self.iiter += 1
+
+    def _snapshot(self):
+        self.engine.synchronize()
+        t = self.t
+        row = dict(n=t["n"].cpu().numpy(), vs=t["vs"].cpu().numpy().astype(np.float32),
+                   z=t["z"].cpu().numpy().astype(np.float32), like=t["like"].cpu().numpy().astype(np.float32),
+                   misfits=t["misfits"].cpu().numpy().astype(np.float32), noise=t["noise"].cpu().numpy().astype(np.float32),
+                   vpvs=t["vpvs"].cpu().numpy().astype(np.float32))
+        self.snap["p1" if self.iiter < 0 else "p2"].append(row)
+
+    def run(self, progress=None):
+        while self.iiter < self.iter_phase2:
+            if self.iiter % self.thinning == 0:
+                self._snapshot()
+            self.iterate()
+            if progress is not None and self.iiter % 1000 == 0:
+                progress(self)
+        self.engine.synchronize()
+        return self
+
+    # ---- results -------------------------------------------------------------------------------------
+    def state_host(self):
+        self.engine.synchronize()
+        return {k: (None if v is None else v.cpu().numpy()) for k, v in self.t.items()}
+
+    def samples(self, phase="p2"):
+        """Thinned samples of every chain: dict of arrays with leading axes [nsnap, C]; `models` in the
+        reference's row layout [vs_1..vs_n NaN.., z_1..z_n NaN..] (2*maxlayers wide)."""
+        S = self.snap[phase]
+        ns, Cn, ML = len(S), self.C, self.ML
+        models = np.full((ns, Cn, 2 * ML), np.nan, dtype=np.float32)
+        for i, r in enumerate(S):
+            live = np.arange(ML)[:, None] < r["n"][None, :]          # [ML, C]
+            vs = np.where(live, r["vs"], np.nan).T                    # [C, ML]
+            z = np.where(live, r["z"], np.nan).T
+            # reference rows hold the n vs values first, then the n depths, then NaN padding
+            for c in range(Cn):
+                n = int(r["n"][c])
+                models[i, c, :n] = vs[c, :n]
+                models[i, c, n:2 * n] = z[c, :n]
+        out = dict(models=models)
+        for k in ("like", "vpvs"):
+            out[k + "s" if k == "like" else k] = np.array([r[k] for r in S], dtype=np.float32).reshape(ns, Cn)
+        out["misfits"] = np.array([r["misfits"].T for r in S], dtype=np.float32).reshape(ns, Cn, self.nt + 1)
+        out["noise"] = np.array([r["noise"].T for r in S], dtype=np.float32).reshape(ns, Cn, 2 * self.nt)
+        return out
+
+    def save(self, savepath=None):
+        """c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy per chain, the reference's result files."""
+        savepath = op.join(savepath or self.initparams["savepath"], "data")
+        os.makedirs(savepath, exist_ok=True)
+        for tag in ("p1", "p2"):
+            if not self.snap[tag]:
+                continue
+            s = self.samples(tag)
+            for c in range(self.C):
+                for k in ("models", "likes", "misfits", "noise", "vpvs"):
+                    np.save(op.join(savepath, "c%.3d_%s%s" % (c, tag, k)), s[k][:, c])
+        return savepath

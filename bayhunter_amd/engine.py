@@ -45,6 +45,32 @@ class TargetDesc(C.Structure):
                 ("x", _d), ("yobs", _d), ("yerr", _d), ("rinv", _d), ("logdet_r", C.c_double)]
 
 
+BH_MAX_TARGETS = 8
+BH_CHAIN_MAXLAYERS = 32
+
+
+class ChainConfig(C.Structure):
+    """bh_chain_config of include/bh_engine.h"""
+    _fields_ = [("nt", C.c_int32), ("maxlayers", C.c_int32), ("layermin", C.c_int32), ("layermax", C.c_int32),
+                ("iter_burnin", C.c_int32), ("iterations", C.c_int32),
+                ("vsmin", C.c_double), ("vsmax", C.c_double), ("zmin", C.c_double), ("zmax", C.c_double),
+                ("thickmin", C.c_double), ("lvz", C.c_double), ("hvz", C.c_double),
+                ("vpvsmin", C.c_double), ("vpvsmax", C.c_double), ("mantle_vs", C.c_double), ("mantle_vpvs", C.c_double),
+                ("acc_lo", C.c_double), ("acc_hi", C.c_double),
+                ("noise_lo", C.c_double * (2 * BH_MAX_TARGETS)), ("noise_hi", C.c_double * (2 * BH_MAX_TARGETS)),
+                ("seed", C.c_uint64)]
+
+
+CHAIN_STATE_FIELDS = ("n", "vs", "z", "vpvs", "noise", "like", "misfits", "propdist", "proposed", "accepted", "naccepted",
+                      "pn", "move", "valid", "pvs", "pz", "pvpvs", "pnoise", "dvs2", "lay_n", "lay_h", "lay_vp", "lay_vs",
+                      "inject")
+
+
+class ChainState(C.Structure):
+    """bh_chain_state of include/bh_engine.h (all members are device pointers)"""
+    _fields_ = [(k, C.c_void_p) for k in CHAIN_STATE_FIELDS]
+
+
 _lib = None
 
 
@@ -90,9 +116,11 @@ def load_library():
                                     C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, vp]
     L.bh_loglike_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
+    L.bh_chain_propose.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int]
+    L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group",
                  "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math"):
+                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 1:
         raise EngineError("ABI version mismatch")
@@ -103,7 +131,7 @@ def load_library():
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group",
                     "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math")
+                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept")
 
 
 def _f64(a):
@@ -336,6 +364,17 @@ class Engine(object):
                            ymod=None, stream=None):
         self._check(self._L.bh_evaluate_batch(self._h, DEVICE, stream, B, Lmax, nlay, h, vp, vs, rho,
                                               sl, sb, noise, logL, misfits, err, ymod))
+
+
+    def chain_propose(self, cfg, state, C_, iiter):
+        rc = self._L.bh_chain_propose(self.stream, C.byref(cfg), C.byref(state), int(C_), int(iiter))
+        if rc != BH_OK:
+            raise EngineError("bh_chain_propose failed (%d)" % rc)
+
+    def chain_accept(self, cfg, state, C_, iiter, logL, misfits):
+        rc = self._L.bh_chain_accept(self.stream, C.byref(cfg), C.byref(state), int(C_), int(iiter), logL, misfits)
+        if rc != BH_OK:
+            raise EngineError("bh_chain_accept failed (%d)" % rc)
 
 
 _default = {}

@@ -171,6 +171,65 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
                      const int32_t *fail, const double *noise, double *logL, double *misfits,
                      int32_t *err);
 
+/* ---- device-resident chain step: replaces the host part of SingleChain.iterate --------------
+ * C chains advance in lock-step, one iteration = bh_chain_propose -> bh_evaluate_batch (BH_DEVICE,
+ * on state->lay_*, stride_l = C, stride_b = 1, noise = state->pnoise) -> bh_chain_accept.
+ * bh_chain_propose: modification choice, proposal, nuclei sort, prior/validity checks and the
+ *   Voronoi->layer conversion (src/SingleChain.py:246-420, :511-556; src/Models.py:26-52).
+ * bh_chain_accept: acceptance incl. the birth/death terms, state update, counters and the
+ *   proposal-width adaptation every 1000 iterations (src/SingleChain.py:425-487, :558-589).
+ * All arrays are DEVICE pointers, float64 unless noted; "[k][C]" = k rows of C chains (chain index
+ * contiguous).  Random numbers are Philox4x32-10 keyed by `seed` with counter (chain, iteration,
+ * purpose): reproducible and independent of scheduling, but a different stream from the
+ * reference's per-chain Mersenne Twister -- chains agree with the reference statistically (the
+ * draw-for-draw replay is the host driver bayhunter_amd/chains.py).  If state->inject is not
+ * NULL the six draws of an iteration are read from it instead ([6][C]: u_move, u_index, u_z,
+ * u_accept, u_noise in [0,1) and one standard normal) -- used by the tests. */
+#define BH_CHAIN_MAXLAYERS 32 /* upper bound of cfg.maxlayers (nuclei per chain) */
+
+typedef struct bh_chain_config {
+    int32_t nt;                   /* targets (noise has 2*nt entries: corr, sigma per target) */
+    int32_t maxlayers;            /* row capacity of the nuclei arrays = priors 'layers' max + 1 */
+    int32_t layermin, layermax;   /* priors 'layers' (number of layers above the half space) */
+    int32_t iter_burnin, iterations;
+    double vsmin, vsmax, zmin, zmax; /* priors 'vs', 'z' */
+    double thickmin;              /* initparams 'thickmin' */
+    double lvz, hvz;              /* initparams 'lvz' / 'hvz'; < 0 = None */
+    double vpvsmin, vpvsmax;      /* priors 'vpvs'; equal = fixed */
+    double mantle_vs, mantle_vpvs; /* priors 'mantle' (vs threshold, vp/vs below); mantle_vs <= 0 = None */
+    double acc_lo, acc_hi;        /* initparams 'acceptance' [%] */
+    double noise_lo[2 * BH_MAX_TARGETS], noise_hi[2 * BH_MAX_TARGETS]; /* equal = fixed */
+    uint64_t seed;
+} bh_chain_config;
+
+typedef struct bh_chain_state {
+    /* current state */
+    int32_t *n;       /* [C] nuclei */
+    double *vs, *z;   /* [maxlayers][C] nuclei, sorted by depth */
+    double *vpvs;     /* [C] */
+    double *noise;    /* [2nt][C] */
+    double *like;     /* [C] log-likelihood of the current model */
+    double *misfits;  /* [nt+1][C] */
+    double *propdist; /* [5][C] vs, z, birth/death, noise, vpvs (SingleChain.py:117) */
+    double *proposed, *accepted; /* [5][C] counters */
+    int64_t *naccepted; /* [C] */
+    /* proposal (written by bh_chain_propose, read by bh_chain_accept) */
+    int32_t *pn, *move, *valid; /* [C] */
+    double *pvs, *pz;  /* [maxlayers][C] */
+    double *pvpvs;     /* [C] */
+    double *pnoise;    /* [C][2nt] -- bh_evaluate_batch's layout */
+    double *dvs2;      /* [C] */
+    /* layered model of the proposal (of the current model where the proposal is invalid) */
+    int32_t *lay_n;    /* [C] layers incl. half space */
+    double *lay_h, *lay_vp, *lay_vs; /* [maxlayers][C] */
+    const double *inject; /* NULL or [6][C] */
+} bh_chain_state;
+
+int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter);
+/* logL [C], misfits [C][nt+1]: outputs of bh_evaluate_batch for this iteration (device). */
+int bh_chain_accept(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
+                    const double *logL, const double *misfits);
+
 /* ---- diagnostics -------------------------------------------------------------------------
  * Evaluate one elementary function on the device for n float64 inputs (host pointers):
  * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x; op 6 / 7: in holds n pairs (a, b), out[i] = a/b

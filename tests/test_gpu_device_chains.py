@@ -1,0 +1,142 @@
+"""Device-resident chain step (bayhunter_amd/device_chains.py, csrc/chain_kernel.hip) against the
+host chain driver that replays the reference draw for draw (bayhunter_amd/chains.py, itself pinned to
+recorded reference runs in test_gpu_chains.py).
+
+The host driver's RandomState is replaced by an object handing out the SAME six draws per iteration
+the device kernel uses (tests/philox_ref.py), so both must walk the same trajectory:
+  * injected draws  -> the device reads them from a buffer: states must be identical;
+  * device Philox   -> the host gets the numpy Philox restatement of the same draws (the Box-Muller
+                       normal can differ in the last bit between numpy and the device): same decisions,
+                       states equal to 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+import bayhunter_amd as bh
+from bayhunter_amd.chains import ChainBatch
+from bayhunter_amd.device_chains import DeviceChains
+from philox_ref import InjectedRandomState, draws
+from test_gpu_chains import SETUPS, make_targets
+
+pytestmark = pytest.mark.gpu
+
+
+def host_twin(dc, targets, init, priors):
+    """A ChainBatch holding the device chains' current state, with injectable draws."""
+    hb = ChainBatch(targets, list(range(dc.C)), init, priors)
+    st = dc.state_host()
+    for c, ch in enumerate(hb.chains):
+        n = int(st["n"][c])
+        ch.currentmodel = np.concatenate((st["vs"][:n, c], st["z"][:n, c]))
+        ch.currentnoise = st["noise"][:, c].copy()
+        ch.currentvpvs = float(st["vpvs"][c])
+        ch.currentlikelihood = float(st["like"][c])
+        ch.currentmisfits = st["misfits"][:, c].copy()
+        ch.propdist = st["propdist"][:, c].copy()
+        ch.rstate = InjectedRandomState()
+    hb.iiter = dc.iiter
+    return hb
+
+
+def compare(dc, hb, exact):
+    st = dc.state_host()
+    eq = (lambda a, b: np.array_equal(a, b)) if exact else (lambda a, b: np.allclose(a, b, rtol=1e-9, atol=1e-12))
+    for c, ch in enumerate(hb.chains):
+        n = ch.currentmodel.size // 2
+        assert st["n"][c] == n, (dc.iiter, c)
+        assert eq(st["vs"][:n, c], ch.currentmodel[:n]) and eq(st["z"][:n, c], ch.currentmodel[n:]), (dc.iiter, c)
+        assert eq(st["noise"][:, c], ch.currentnoise) and eq(st["vpvs"][c], ch.currentvpvs), (dc.iiter, c)
+        assert eq(st["like"][c], ch.currentlikelihood), (dc.iiter, c, st["like"][c], ch.currentlikelihood)
+        assert eq(st["misfits"][:, c], ch.currentmisfits)
+        assert eq(st["propdist"][:, c], ch.propdist), (dc.iiter, c, st["propdist"][:, c], ch.propdist)
+        assert np.array_equal(st["proposed"][:, c], ch.proposed) and np.array_equal(st["accepted"][:, c], ch.accepted)
+
+
+@pytest.mark.parametrize("name", ["exp", "gauss"])
+def test_injected_draws_same_trajectory(name):
+    g = golden("chain_golden.npz")
+    su = SETUPS[name]
+    init = dict(su["init"], iter_burnin=1100, iter_main=150, lvz=0.1, hvz=0.4)
+    priors = dict(su["priors"], mantle=(4.3, 1.8))
+    C = 48
+    targets = make_targets(g)
+    dc = DeviceChains(targets, C, init, priors, seed=7, inject=True)
+    hb = host_twin(dc, targets, init, priors)
+    rs = np.random.RandomState(99)
+    it = 0
+    while dc.iiter < dc.iter_phase2:
+        d = np.vstack((rs.uniform(size=(5, C)), rs.normal(size=(1, C))))
+        dc.t["inject"].copy_(dc.torch.from_numpy(d))
+        dc.torch.cuda.synchronize()
+        for c, ch in enumerate(hb.chains):
+            ch.rstate.set(d[:, c])
+        dc.iterate()
+        hb.iterate()
+        it += 1
+        if it % 50 == 0 or dc.iiter in (-999, 1):      # incl. right after the width adaptations
+            compare(dc, hb, exact=True)
+    compare(dc, hb, exact=True)
+    st = dc.state_host()
+    assert (st["accepted"].sum(axis=0) > 50).all() and (st["n"] != st["n"][0]).any()   # chains really moved / differ
+    if name == "exp":   # (with a fixed vp/vs that family is never proposed and the reference never adapts, :584)
+        assert (st["propdist"] != np.asarray(hb.initparams["propdist"])[:, None]).any()    # widths were adapted
+
+
+def test_device_philox_same_trajectory_and_reproducible():
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=300, iter_main=120)
+    C, seed = 40, (0x1234 << 32) | 0x9abcdef1
+    targets = make_targets(g)
+    dc = DeviceChains(targets, C, init, su["priors"], seed=seed)
+    hb = host_twin(dc, targets, init, su["priors"])
+    while dc.iiter < dc.iter_phase2:
+        d = draws(seed, C, dc.iiter)
+        for c, ch in enumerate(hb.chains):
+            ch.rstate.set(d[:, c])
+        dc.iterate()
+        hb.iterate()
+        if dc.iiter % 60 == 0:
+            compare(dc, hb, exact=False)
+    compare(dc, hb, exact=False)
+    a = dc.state_host()
+    # same seed -> identical run; another seed -> another trajectory
+    dc2 = DeviceChains(make_targets(g), C, init, su["priors"], seed=seed).run()
+    b = dc2.state_host()
+    for k in ("n", "vs", "z", "like", "noise", "vpvs", "propdist", "accepted"):
+        assert np.array_equal(a[k], b[k]), k
+    dc3 = DeviceChains(make_targets(g), C, init, su["priors"], seed=seed + 1).run()
+    assert not np.array_equal(a["like"], dc3.state_host()["like"])
+
+
+def test_many_chains_converge_and_save(tmp_path):
+    """512 chains from random starts: all run the whole schedule on the device, the likelihood of
+    (nearly) every chain climbs to the level the recorded reference chains reach, and the result
+    files have the reference's names, dtypes and row layout."""
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=1500, iter_main=700, maxmodels=100, savepath=str(tmp_path))
+    C = 512
+    dc = DeviceChains(make_targets(g), C, init, su["priors"], seed=3).run()
+    st = dc.state_host()
+    ref_final = min(float(g["exp_s%d_likes" % s][-1]) for s in su["seeds"])
+    # (the chains start at logL of order -1e4 .. -1e5; the two recorded reference chains end at 610 and 760)
+    assert np.median(st["like"]) > ref_final - 150.0, (np.median(st["like"]), ref_final)
+    assert np.mean(st["like"] > 0.0) > 0.9
+    prop = st["proposed"].sum(axis=1) / st["proposed"].sum()
+    assert (prop > 0.1).all()                                   # every family of moves is being proposed
+    rate = st["accepted"].sum() / st["proposed"].sum()
+    assert 0.15 < rate < 0.9, rate
+    assert dc.thinning == 7 and len(dc.snap["p2"]) == 100
+    s = dc.samples("p2")
+    assert s["models"].shape == (100, C, 2 * dc.ML) and s["models"].dtype == np.float32
+    path = dc.save()
+    m = np.load(os.path.join(path, "c%.3d_p2models.npy" % (C - 1)))
+    lk = np.load(os.path.join(path, "c%.3d_p2likes.npy" % (C - 1)))
+    assert m.shape == (100, 2 * dc.ML) and lk.shape == (100,)
+    n, vs, z = bh.Model.split_modelparams(m[-1])
+    assert n == st["n"][C - 1] and np.all(np.diff(z) > 0)
+    assert np.allclose(vs, st["vs"][:n, C - 1].astype(np.float32))

@@ -84,3 +84,16 @@ def test_closed_forms_equal_dense_forms(oracle, n):
     yerr = rs.uniform(0.01, 0.05, n)
     c_inv, ld = v.get_covariance_nocorr_scalederr(s, n, yerr)
     assert abs(v.get_likelihood(yobs, ymod, c_inv, ld) - oracle.loglike_dense(1, ymod, yobs, 0, s, yerr=yerr)) <= 1e-9 * abs(ld)
+
+
+def test_philox_known_answers():
+    """The numpy Philox4x32-10 used to check the device chain step reproduces the Random123
+    known-answer vectors (kat_vectors: philox4x32 10)."""
+    from philox_ref import philox4x32_10
+    z = philox4x32_10(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]
+    assert [hex(int(v)) for v in z] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f = philox4x32_10(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [hex(int(v)) for v in f] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    p = philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], dtype=np.uint32),
+                      (0xa4093822, 0x299f31d0))[0]
+    assert [hex(int(v)) for v in p] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
