@@ -61,6 +61,7 @@ size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
 // group kernel: G lanes per model, all dispersion targets of a call in one launch
 struct SwdTarget {
     int iwave, igr, K, ldv, mode;
+    int look; // trial velocities per round for this target's wavefronts (>= 1), see SearchT::candidate
     const double *h, *vp, *vs, *rho; // model arrays this target reads (earth-flattened copies when flsph = 1)
     ptrdiff_t sl, sb;
     const double *periods;
@@ -74,8 +75,9 @@ struct SwdMultiArgs {
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
-size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax, int maxmode);
-void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
+void bh_swd_pick_lookahead(int B, int G, int ntargets, const int *iwave, int *look);
+size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
+void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream); // look-ahead per target in a.t[i].look
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

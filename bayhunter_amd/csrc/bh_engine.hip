@@ -51,6 +51,7 @@ struct bh_engine {
     bool timing = false, counting = false;
     bool no_mfma = false; // BH_NO_MFMA env: Gauss law through the in-kernel mat-vec (A/B testing)
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
+    int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
         hipEvent_t ev[8];
@@ -269,8 +270,20 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     int G = e->force_group > 0 ? e->force_group : bh_swd_pick_group(B, nlive, Lmax);
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
-    while (G > 1 && G < 64 && bh_swd_group_lds_bytes(G, Lmax, kmax, maxmode) > lds_cap) G += 1; // fewer models per wave
-    if (G > 1 && bh_swd_group_lds_bytes(G, Lmax, kmax, maxmode) > lds_cap) return fail(e, BH_EINVAL, "model too deep for LDS");
+    while (G > 1 && G < 64 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) G += 1; // fewer models per wave
+    if (G > 1 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) return fail(e, BH_EINVAL, "model too deep for LDS");
+    int look[BH_MAX_TARGETS];
+    if (G > 1) {
+        int iw[BH_MAX_TARGETS], n = 0;
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].K != 0) iw[n++] = jobs[j].iwave;
+        if (e->force_look > 0)
+            for (int t = 0; t < n; ++t) look[t] = e->force_look;
+        else
+            bh_swd_pick_lookahead(B, G, n, iw, look);
+        for (int t = 0; t < n; ++t)
+            while (look[t] > 1 && (G * look[t] > 64 || bh_swd_group_lds_bytes(G, look[t], Lmax, kmax, maxmode) > lds_cap)) look[t] -= 1;
+    }
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
     if (G <= 1) {
@@ -299,6 +312,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         if (J.K == 0) continue;
         SwdTarget &t = a.t[a.ntargets++];
         t.iwave = J.iwave; t.igr = J.igr; t.K = J.K; t.ldv = J.ldv; t.mode = J.mode;
+        t.look = look[a.ntargets - 1];
         t.h = m.h; t.vp = m.vp; t.vs = m.vs; t.rho = m.rho; t.sl = sl; t.sb = sb;
         if (J.flsph == 1) {
             t.h = sh; t.vp = svp; t.vs = svs; t.rho = (J.iwave == BH_WAVE_LOVE) ? srl : srr;
@@ -392,8 +406,18 @@ int bh_engine_create(int device, bh_engine **out)
     }
     if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
+    if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
     if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
     *out = e;
+    return BH_OK;
+}
+
+int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round)
+{
+    if (!e) return BH_EINVAL;
+    if (trials_per_round < 0 || trials_per_round > 12)
+        return fail(e, BH_EINVAL, "look-ahead must be 0 (auto) or 1..12 trial velocities per round");
+    e->force_look = trials_per_round;
     return BH_OK;
 }
 

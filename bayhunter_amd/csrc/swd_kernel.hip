@@ -44,12 +44,12 @@ struct LibmTabs {
 };
 constexpr int LIBM_TAB_BYTES = 256 * 8 + 440 * 8;
 
-__device__ __forceinline__ LibmTabs stage_libm_tables(unsigned char *lds, int lane)
+__device__ __forceinline__ LibmTabs stage_libm_tables(unsigned char *lds, int lane, int nthreads = BH_WAVE)
 {
     uint64_t *et = reinterpret_cast<uint64_t *>(lds);
     uint64_t *st = et + 256;
-    for (int i = lane; i < 256; i += BH_WAVE) et[i] = bhp_exp_tab[i];
-    for (int i = lane; i < 440; i += BH_WAVE) st[i] = bhp_sincos_tab_bits[i];
+    for (int i = lane; i < 256; i += nthreads) et[i] = bhp_exp_tab[i];
+    for (int i = lane; i < 440; i += nthreads) st[i] = bhp_sincos_tab_bits[i];
     return LibmTabs{et, reinterpret_cast<const double *>(st)};
 }
 __device__ __forceinline__ void bh_sincos(double x, double *sn, double *cs, const LibmTabs &T)
@@ -620,6 +620,32 @@ struct SearchT {
         ceval = c1;
     }
 
+    // Look-ahead: candidate 0 is the pending request; candidate r > 0 is the phase velocity the r-th
+    // request from now will most probably be for -- further bracket steps while stepping (:437-449),
+    // further halvings towards the side on which a straight line through the bracket ends puts the
+    // root while refining (:600-660).  Purely a guess about which values will be asked for: a value
+    // is only ever consumed by advance() if it was computed for exactly the (ceval, omega) requested.
+    __device__ __forceinline__ double candidate(int r) const
+    {
+        double q = ceval;
+        if (st == ST_FIRST || st == ST_STEP) {
+            const bool up = (st == ST_FIRST) || (idir > 0);
+            for (int j = 0; j < r; ++j) q = up ? q + dc : q - dc;
+        } else {
+            double lo = c1, hi = c2; // the function keeps the sign of del1 at `lo`
+            const double w = c2 - c1;
+            for (int j = 0; j < r; ++j) {
+                const double t = del1 * (c2 - q) + del2 * (q - c1); // (c2 - c1) * linear model at q
+                const bool neg_lin = (t < 0.0) != (w < 0.0);
+                const bool differs = neg_lin != (del1 < 0.0);
+                lo = differs ? lo : q;
+                hi = differs ? q : hi;
+                q = 0.5 * (lo + hi);
+            }
+        }
+        return q;
+    }
+
     __device__ void advance(double del)
     {
         ++evals;
@@ -1015,38 +1041,62 @@ __device__ __forceinline__ void park_ca25(double *dst, const Ca19 &c)
     d2[12] = make_double2(ca11, 0.0);                                      // (ca25=ca14, ca45=ca12, ca55=ca11)
 }
 
-__global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int Gflags)
+// Wavefronts per workgroup: they are independent (no barrier after start-up) and only share one LDS
+// copy of the libm tables, which is what lets 8 wavefronts fit a CU's 160 KB of LDS.
+constexpr int GROUP_WPB = 2;
+constexpr int LIBM_TAB_PAD = (LIBM_TAB_BYTES + 15) & ~15;
+
+// LDS ordering inside ONE wavefront: its LDS instructions execute in order, so a write by one lane is
+// visible to a later read by another lane of the same wavefront; only the compiler must not reorder.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     const int G = Gflags & 0xff;
-    const int MPW = BH_WAVE / G; // models per wavefront (lanes >= MPW*G idle along as clones of slot 0)
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const bool spare = lane >= MPW * G;
-    const int g = spare ? 0 : lane / G;  // model slot inside the wave
-    const int li = spare ? 0 : lane % G; // this lane's index inside the model's group
-    const int ib = blockIdx.x * MPW + g;
+    const SwdTarget T = A.t[blockIdx.y];
+    const int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target)
+    const int LPM = G * J;         // lanes per model: J groups of G lanes, group r evaluates candidate r
+    const int MPW = BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    const int lane = threadIdx.x & (BH_WAVE - 1);
+    const int wave = threadIdx.x / BH_WAVE;
+    const int wid = blockIdx.x * GROUP_WPB + wave; // wavefront index inside this target's row of the grid
+    // the workgroup's shared copy of the libm tables, then one private region per wavefront
+    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * GROUP_WPB);
+    __syncthreads();
+    if (wid * MPW >= A.B) return; // the grid is sized for the target with the fewest models per wave
+    unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
+    const bool spare = lane >= MPW * LPM;
+    const int g = spare ? 0 : lane / LPM;        // model slot inside the wave
+    const int rr = spare ? 0 : (lane % LPM) / G; // which candidate this lane's group evaluates
+    const int li = spare ? 0 : lane % G;         // this lane's index inside its group
+    const int slot = g * J + rr;                 // group index inside the wave
+    const int ib = wid * MPW + g;
     const bool valid = ib < A.B;
     const int Lmax = A.Lmax;
-    const SwdTarget T = A.t[blockIdx.y];
     const int K = T.K;
-    const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per workgroup
+    const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
 
-    // LDS carve-up (all offsets multiples of 16 B)
-    double *ca = reinterpret_cast<double *>(smem);                 // [MPW][Lmax][CA_STRIDE]
-    double *xs = ca + (size_t)MPW * Lmax * CA_STRIDE;              // [11][MPW]
+    // LDS carve-up of the wavefront's region (all offsets multiples of 16 B)
+    double *ca = reinterpret_cast<double *>(smem);                 // [MPW*J][Lmax][CA_STRIDE]
+    double *xs = ca + (size_t)MPW * J * Lmax * CA_STRIDE;          // [11][MPW]
     double *ys = xs + NEV_MAX * MPW;
     double *per = ys + NEV_MAX * MPW;                              // [K]
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
     unsigned char *after = reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15);
-    const LibmTabs LT = stage_libm_tables(after, lane);
-    double *cpl = reinterpret_cast<double *>(after + LIBM_TAB_BYTES); // [2][Kmax][MPW], only if a target has mode > 1
+    double *cpl = reinterpret_cast<double *>(after); // [2][Kmax][MPW], only if a target has mode > 1
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
     // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
     // layer-major input), binary32 rounding like the f2py boundary
     for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
         const int l = idx / MPW, mg = idx % MPW;
-        const int b = blockIdx.x * MPW + mg;
+        const int b = wid * MPW + mg;
         float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
         if (b < A.B && l < A.nlay[b]) {
             const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
@@ -1064,7 +1114,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     int mtop = mmax;
     for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
     mtop = __builtin_amdgcn_readfirstlane(mtop);
-    __syncthreads();
+    wave_sync();
     ModelLdsRt md;
     md.S = MPW;
     md.d = mdl + 0 * Lmax * MPW + g;
@@ -1072,17 +1122,17 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     md.b = mdl + 2 * Lmax * MPW + g;
     md.rho = mdl + 3 * Lmax * MPW + g;
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
-    double *cam = ca + (size_t)g * Lmax * CA_STRIDE; // this model's parked layers
+    double *cam = ca + (size_t)slot * Lmax * CA_STRIDE; // this group's parked layers
     const bool par5 = (G >= 5) && !(Gflags & 0x100);
-    const int gbase = g * G; // first lane of this model's group
+    const int gbase = slot * G; // first lane of this group
     // one layer count for the whole wavefront and no water layer: the recursion needs no masking
     const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
     const int col = li % 5;                          // the 5-vector component this lane owns
 
     SearchRt S;
     S.XS = MPW;
-    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && !spare, T.mode,
-           cpl + g, cpl + (size_t)K * MPW + g);
+    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g);
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
@@ -1093,7 +1143,8 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (prof) t0 = clock64();
         const double omg = S.omega;
-        const double wvno = omg / S.ceval;
+        const double cev = (J == 1) ? S.ceval : S.candidate(rr);
+        const double wvno = omg / cev;
         double del;
         if (ifunc == 2) {
             double omega = omg;
@@ -1164,7 +1215,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                 e[3] = rho1 * rb;
                 e[4] = wvno2 - ra * rb;
             }
-            __syncthreads();
+            wave_sync();
             if (prof) t1c = clock64();
             // ---- phase B: the sequential recursion, bottom-up over the parked layers -----------
             {
@@ -1197,7 +1248,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                 const double w0 = -rho1 * v.w;
                 del = v.cosp * e[0] + w0 * e[1];
             }
-            __syncthreads();
+            wave_sync();
         } else {
             const double omega = omg;
             if (omega != c_omega) {
@@ -1253,7 +1304,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                 e1 = rho1 * rb;
                 e2 = h_gammk;
             }
-            __syncthreads();
+            wave_sync();
             if (prof) t1c = clock64();
             {
                 const double s1 = e1, s2 = e2;
@@ -1268,10 +1319,25 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
                 }
             }
             del = e1;
-            __syncthreads();
+            wave_sync();
         }
         if (prof) t2c = clock64();
-        if (S.active) S.advance(del);
+        // Every lane of the model can read all J (velocity, value) pairs; the search consumes them for
+        // as long as its next request is the very velocity (at the same omega) the next group evaluated.
+        {
+            bool live = S.active;
+            for (int j = 0; j < J; ++j) {
+                double dj = del;
+                if (J > 1) {
+                    const int src = (g * J + j) * G;
+                    const double cj = __shfl(cev, src);
+                    dj = __shfl(del, src);
+                    live = live && S.active && S.ceval == cj && S.omega == omg;
+                }
+                if (__ballot(live) == 0ull) break;
+                if (live) S.advance(dj);
+            }
+        }
         if (prof) {
             const long long t3 = clock64();
             tA += t1c - t0;
@@ -1279,9 +1345,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
             tS += t3 - t2c;
         }
     }
-    if (valid && li == 0 && !spare) T.err[ib] = S.errflag;
+    if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
     if (prof) {
-        unsigned long long tot = (li == 0 && !spare) ? S.evals : 0u;
+        unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
         if (lane == 0) {
             atomicAdd(A.neval, tot);
@@ -1295,12 +1361,12 @@ __global__ __launch_bounds__(BH_WAVE) void swd_group_kernel(SwdMultiArgs A, int 
     }
 }
 
-size_t group_lds_bytes(int G, int Lmax, int Kmax, int maxmode)
+size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
-    const int MPW = BH_WAVE / G;
-    return ((size_t)MPW * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
+    const int MPW = BH_WAVE / (G * J);
+    return ((size_t)MPW * J * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
             (size_t)((Kmax + 1) & ~1)) * sizeof(double) +
-           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) + LIBM_TAB_BYTES +
+           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) +
            (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
 }
 
@@ -1418,7 +1484,58 @@ int bh_swd_pick_group(int B, int ntargets, int Lmax)
     return G;
 }
 
-size_t bh_swd_group_lds_bytes(int G, int Lmax, int Kmax, int maxmode) { return group_lds_bytes(G, Lmax, Kmax, maxmode); }
+void bh_swd_pick_lookahead(int B, int G, int ntargets, const int *iwave, int *look)
+{
+    // Trial velocities per round, per target (see SearchT::candidate).  More of them shorten every
+    // model's chain of dependent secular evaluations (what a small batch is bound by) but cost lanes,
+    // i.e. wavefronts; that pays for as long as all wavefronts of the launch are resident at once:
+    // 2 per SIMD at this kernel's register budget = 2048 on the chip.  Greedy: keep shortening the
+    // target with the longest wavefronts while the launch still fits.  Relative wavefront durations
+    // measured on MI355X (10-layer models, 30 periods; profiles/): Rayleigh 1 / .64 / .52 / .45 / .36
+    // for 1 / 2 / 3 / 4 / 7 trials, Love 0.79 x (1 / .70 / .49 / .42 / .33).
+    static const int levels[5] = {1, 2, 3, 4, 7};
+    static const double dur[2][5] = {{0.79, 0.55, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
+    const int slots = 2048;
+    int lvl[8];
+    for (int t = 0; t < ntargets; ++t) lvl[t] = 0;
+    auto feasible = [&](int t, int l) { // largest J <= levels[l] that fits a wavefront
+        int J = levels[l];
+        while (J > 1 && G * J > BH_WAVE) --J;
+        return J;
+    };
+    auto waves = [&](int t, int l) {
+        const int J = feasible(t, l);
+        const int mpw = BH_WAVE / (G * J);
+        return (B + mpw - 1) / mpw;
+    };
+    for (;;) {
+        int worst = -1;
+        double dworst = 0.0;
+        for (int t = 0; t < ntargets; ++t) {
+            const double d = dur[iwave[t] == 2 ? 1 : 0][lvl[t]];
+            if (d > dworst) {
+                dworst = d;
+                worst = t;
+            }
+        }
+        if (worst < 0 || lvl[worst] >= 4) break;
+        const int nl = lvl[worst] + 1;
+        if (feasible(worst, nl) == feasible(worst, lvl[worst])) break; // no more lanes to give
+        int total = 0;
+        for (int t = 0; t < ntargets; ++t) total += waves(t, t == worst ? nl : lvl[t]);
+        // one model per wavefront with many trials keeps the LDS pipes busier: leave headroom there
+        const int cap = (levels[nl] > 4) ? slots / 2 : slots;
+        if (total > cap) break;
+        lvl[worst] = nl;
+    }
+    for (int t = 0; t < ntargets; ++t) look[t] = feasible(t, lvl[t]);
+}
+
+// LDS of one workgroup = shared libm tables + GROUP_WPB wavefront regions
+size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
+{
+    return LIBM_TAB_PAD + GROUP_WPB * ((group_lds_bytes(G, J, Lmax, Kmax, maxmode) + 15) & ~(size_t)15);
+}
 
 void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream)
 {
@@ -1427,9 +1544,18 @@ void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream)
         kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
         maxmode = a.t[t].mode > maxmode ? a.t[t].mode : maxmode;
     }
-    const int mpw = BH_WAVE / G;
-    const dim3 grid((a.B + mpw - 1) / mpw, a.ntargets);
-    const size_t lds = group_lds_bytes(G, a.Lmax, kmax, maxmode);
+    int nwaves = 1;
+    size_t wave_lds = 0;
+    for (int t = 0; t < a.ntargets; ++t) {
+        const int J = a.t[t].look > 1 ? a.t[t].look : 1;
+        const int mpw = BH_WAVE / (G * J);
+        const int nx = (a.B + mpw - 1) / mpw;
+        nwaves = nx > nwaves ? nx : nwaves;
+        const size_t l = (group_lds_bytes(G, J, a.Lmax, kmax, maxmode) + 15) & ~(size_t)15;
+        wave_lds = l > wave_lds ? l : wave_lds;
+    }
+    const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets);
+    const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
     static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
-    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE), lds, stream, a, G | redundant);
+    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, G | redundant, (int)wave_lds);
 }

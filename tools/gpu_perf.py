@@ -14,12 +14,17 @@ spec = [dict(kind=E.TARGET_SWD, law=0, n=30, x=SWD_PERIODS, yobs=yobs, iwave=2, 
 eng.set_targets(spec)
 Bs = [int(a) for a in sys.argv[1].split(',')] if len(sys.argv) > 1 else [4096]
 Gs = [int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1, 4, 8, 16]
+Js = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1]
+LVZ = float(os.environ.get("LVZ", "0"))
 ref = {}
 for B in Bs:
-    nlay, h, vp, vs, rho = synth_models(rs, B, 10)
+    nlay, h, vp, vs, rho = synth_models(rs, B, 10, lvz_frac=LVZ) if LVZ else synth_models(rs, B, 10)
     noise = np.tile([0, 0.05, 0, 0.05], (B, 1))
-    for G in Gs:
+    for G, J in [(G, J) for G in Gs for J in Js]:
+        if G * J > 64 or (G == 1 and J > 1):
+            continue
         eng.set_swd_group(G)
+        eng.set_swd_lookahead(J)
         out = None
         eng.evaluate_batch(nlay, h, vp, vs, noise)
         eng.timing_reset()
@@ -32,4 +37,4 @@ for B in Bs:
             same = np.array_equal(ref[key][0], out[0]) and np.array_equal(ref[key][3], out[3])
         else:
             ref[key] = out
-        print('B', B, 'G', G, 'swd ms', round(fam['swd'] / n, 3), 'evals/s', int(B / (fam['swd'] / n * 1e-3)), 'identical to first G:', same, flush=True)
+        print('B', B, 'G', G, 'J', J, 'swd ms', round(fam['swd'] / n, 3), 'evals/s', int(B / (fam['swd'] / n * 1e-3)), 'identical to first G:', same, flush=True)
