@@ -112,6 +112,20 @@ def cpu_baseline(spec, batch, noise, workload):
                       % (n, workload, best, sorted(probe_rates), ncpu, 1.0 / per_model)}
 
 
+def pmc_traffic(workload, B):
+    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be read
+    from inside the timed run: they come from the separate rocprofv3 --pmc passes of the same command
+    (tools/profile_round.sh), whose summary is committed as profiles/pmc_traffic.json; null when that
+    file is missing or was taken for another workload / batch."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if d["workload"] == workload and int(d["batch"]) == int(B):
+            return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": d["source"]}
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +224,7 @@ def main():
                        "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
                        "parallelism": "models sharded one batch per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, B),
                          "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
                          "kernel_ms_per_launch": swd_ms_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,

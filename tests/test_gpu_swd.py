@@ -241,3 +241,34 @@ def test_lane_mappings_return_identical_bits(engine, G):
             assert np.array_equal(v1, v2) and np.array_equal(e1, e2)
     finally:
         engine.set_swd_group(0)
+
+
+@pytest.mark.parametrize("G,J", [(5, 2), (9, 3), (9, 7), (13, 4), (16, 2), (21, 3)])
+def test_lookahead_does_not_change_results(engine, G, J):
+    """Look-ahead (extra lane groups evaluating the trial velocities the root search will probably
+    ask for next, bh_engine_set_swd_lookahead) only changes WHEN a secular value is computed, never
+    which values the search consumes: velocities (all wave/velocity types, higher modes, failing
+    models, ragged layer counts, water layers) and the number of consumed evaluations are unchanged."""
+    rs = np.random.RandomState(77)
+    nlay, h, vp, vs, rho = synth_models(rs, 200, 12, lvz_frac=0.3, ragged=True)
+    vs[0, :8] = 0.0                      # a few models with a water layer on top
+    vp[0, :8] = 1.5
+    vs[:, 8:12] *= 0.2                   # and some that fail the search
+    per = np.linspace(1.5, 70, 35)
+    try:
+        for iwave, igr in REFS.values():
+            for mode in (1, 3):
+                engine.set_swd_group(G)
+                engine.set_swd_lookahead(1)
+                engine.set_instrumentation(False, True)
+                v1, e1 = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, mode=mode)
+                n1 = engine.last_neval()
+                engine.set_swd_lookahead(J)
+                v2, e2 = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, mode=mode)
+                n2 = engine.last_neval()
+                assert np.array_equal(v1, v2) and np.array_equal(e1, e2), (iwave, igr, mode)
+                assert n1 == n2 and n1 > 0
+    finally:
+        engine.set_swd_group(0)
+        engine.set_swd_lookahead(0)
+        engine.set_instrumentation(False, False)
