@@ -8,5 +8,14 @@ from .rfmini_modrf import RFminiModRF  # noqa: F401
 from .Targets import (ObservedData, ModeledData, Valuation, SingleTarget, JointTarget,  # noqa: F401
                       RayleighDispersionPhase, RayleighDispersionGroup, LoveDispersionPhase,
                       LoveDispersionGroup, PReceiverFunction, SReceiverFunction, select_noise_laws)
+from .chains import ChainBatch, MCMC_Optimizer  # noqa: F401
+
+
+def __getattr__(name):  # DeviceChains needs torch: imported on first use only
+    if name == "DeviceChains":
+        from .device_chains import DeviceChains
+        return DeviceChains
+    raise AttributeError(name)
+
 
 __version__ = "0.1.0"
