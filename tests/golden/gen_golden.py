@@ -306,13 +306,25 @@ def main():
               "gauss": dict(priors=dict(vpvs=1.73, layers=(1, 8), vs=(2, 5), z=(0, 60), mohoest=(30, 8), rfnoise_corr=0.9,
                                         rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1)),
                             init=dict(nchains=1, iter_burnin=1200, iter_main=500, acceptance=(40, 80), thickmin=0.1, lvz=None,
-                                      hvz=None, rcond=1e-5, maxmodels=50000), seeds=(21,))}
+                                      hvz=None, rcond=1e-5, maxmodels=50000), seeds=(21,)),
+              # BASELINE configs[0]: the tutorial's set-up reduced to its Rayleigh phase target (observed errors
+              # given -> scaled-error law), priors / proposal widths of tutorial/config.ini, 1 chain
+              "tut": dict(priors=dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None,
+                                      swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.05)),
+                          init=dict(nchains=1, iter_burnin=1400, iter_main=600, propdist=(0.015, 0.015, 0.015, 0.005, 0.005),
+                                    acceptance=(40, 80), thickmin=0.1, lvz=None, hvz=None, rcond=1e-5, maxmodels=50000),
+                          seeds=(31,), swd_only=True)}
+    ysw_err = SynthObs.compute_expnoise(st3("rdispph")[1], corr=0.0, sigma=0.012)
+    out["ysw_err"] = ysw_err
     for name, su in setups.items():
         for seed in su["seeds"]:
-            t1 = Targets.RayleighDispersionPhase(xsw, ysw)
-            t2 = Targets.PReceiverFunction(xrf, yrf)
-            t2.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
-            jt = Targets.JointTarget(targets=[t1, t2])
+            if su.get("swd_only"):
+                jt = Targets.JointTarget(targets=[Targets.RayleighDispersionPhase(xsw, ysw, yerr=ysw_err)])
+            else:
+                t1 = Targets.RayleighDispersionPhase(xsw, ysw)
+                t2 = Targets.PReceiverFunction(xrf, yrf)
+                t2.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
+                jt = Targets.JointTarget(targets=[t1, t2])
             tmp = tempfile.mkdtemp(prefix="bhchain_")
             os.makedirs(os.path.join(tmp, "data"))
             init = dict(su["init"]); init["savepath"] = tmp; init["station"] = "gold"
@@ -320,7 +332,8 @@ def main():
             nmodels = int(iters * np.max(init["acceptance"]) / 100.)
             maxlayers = int(su["priors"]["layers"][1]) + 1
             mk = lambda n: sharedctypes.RawArray("f", n)
-            shared = [mk(nmodels * maxlayers * 2), mk(nmodels * 3), mk(nmodels), mk(nmodels * 4), mk(nmodels)]
+            ntg = len(jt.targets)
+            shared = [mk(nmodels * maxlayers * 2), mk(nmodels * (ntg + 1)), mk(nmodels), mk(nmodels * 2 * ntg), mk(nmodels)]
             for a in shared:
                 np.frombuffer(a, dtype=np.float32).fill(np.nan)
             chain = SingleChain(targets=jt, chainidx=0, initparams=init, modelpriors=su["priors"], sharedmodels=shared[0],

@@ -23,10 +23,19 @@ SETUPS = {"exp": dict(priors=dict(vpvs=(1.4, 2.1), layers=(1, 10), vs=(2, 5), z=
           "gauss": dict(priors=dict(vpvs=1.73, layers=(1, 8), vs=(2, 5), z=(0, 60), mohoest=(30, 8), rfnoise_corr=0.9,
                                     rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1)),
                         init=dict(nchains=1, iter_burnin=1200, iter_main=500, acceptance=(40, 80), thickmin=0.1, lvz=None,
-                                  hvz=None, rcond=1e-5, maxmodels=50000), seeds=(21,))}
+                                  hvz=None, rcond=1e-5, maxmodels=50000), seeds=(21,)),
+          # BASELINE configs[0]: the tutorial reduced to its Rayleigh phase target (observed errors given ->
+          # scaled-error law), priors / proposal widths of the reference's tutorial/config.ini, 1 chain
+          "tut": dict(priors=dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), mohoest=None,
+                                  swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.05)),
+                      init=dict(nchains=1, iter_burnin=1400, iter_main=600, propdist=(0.015, 0.015, 0.015, 0.005, 0.005),
+                                acceptance=(40, 80), thickmin=0.1, lvz=None, hvz=None, rcond=1e-5, maxmodels=50000),
+                      seeds=(31,), swd_only=True)}
 
 
-def make_targets(g):
+def make_targets(g, swd_only=False):
+    if swd_only:
+        return bh.JointTarget([bh.RayleighDispersionPhase(g["xsw"], g["ysw"], yerr=g["ysw_err"])])
     t1 = bh.RayleighDispersionPhase(g["xsw"], g["ysw"])
     t2 = bh.PReceiverFunction(g["xrf"], g["yrf"])
     t2.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
@@ -52,7 +61,7 @@ def test_replay_of_recorded_reference_chains(name, tmp_path):
     g = golden("chain_golden.npz")
     su = SETUPS[name]
     # all seeds of the set-up as ONE lock-step batch: chains must not influence each other
-    batch = ChainBatch(make_targets(g), list(su["seeds"]), su["init"], su["priors"]).run()
+    batch = ChainBatch(make_targets(g, su.get("swd_only", False)), list(su["seeds"]), su["init"], su["priors"]).run()
     for ci, seed in enumerate(su["seeds"]):
         check_chain(batch, ci, g, "%s_s%d_" % (name, seed))
     # the result files, reference format (SingleChain.py:646-690)
