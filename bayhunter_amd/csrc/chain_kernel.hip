@@ -261,15 +261,17 @@ __global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C
         const int pi = par_index(mv);
         S.proposed[pi * (size_t)C + c] += 1.0;
         const double like = logL[c], cur = S.like[c];
+        const double beta = S.beta ? S.beta[c] : 1.0;
+        const double dl = (S.beta ? beta * (like - cur) : like - cur);
         double alpha;
         if (mv == MV_BIRTH || mv == MV_DEATH) { // Bodin et al. (2012), SingleChain.py:468-485
             const double theta = S.propdist[2 * (size_t)C + c];
             const double dv = cfg.vsmax - cfg.vsmin;
             const double Bt = S.dvs2[c] / (2. * (theta * theta));
-            if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + (like - cur);
-            else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + (like - cur);
+            if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + dl;
+            else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + dl;
         } else {
-            alpha = like - cur;
+            alpha = dl;
         }
         if (log(d.u_accept) < alpha) {
             const int n = S.pn[c];

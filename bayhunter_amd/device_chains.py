@@ -36,7 +36,14 @@ from .Targets import JointTarget
 
 
 class DeviceChains(object):
-    def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=0, inject=False):
+    def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=0, inject=False,
+                 betas=None, ladder=None, swap_every=0, dist=None):
+        """betas / ladder / swap_every: parallel tempering (no counterpart in the reference).  `betas[c]` is
+        the inverse temperature chain c starts with, `ladder[c]` the id of the temperature ladder it
+        belongs to (ids are global across ranks); every `swap_every` iterations neighbouring temperatures
+        of each ladder are exchanged (`parallel.tempering_exchange`; chains keep their states and swap
+        betas, so nothing but (logL, beta, ladder) of each chain crosses GPUs).  Posterior samples are the
+        snapshots of chains that hold beta = 1 at that time (`samples(..., cold_only=True)`)."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
@@ -55,6 +62,7 @@ class DeviceChains(object):
         self.iterations = self.iter_phase1 + self.iter_phase2
         self.iiter = -self.iter_phase1
         self.thinning = max(1, int(np.ceil(float(self.iter_phase2) / float(ip["maxmodels"]))))
+        self.swap_every, self.dist, self.nswaps, self.sweep, self.seed = int(swap_every), dist, 0, 0, int(seed)
 
         # ---- initial state through the reference-order host code --------------------------------
         seeds = np.random.RandomState((int(seed) ^ (int(seed) >> 32)) & 0xFFFFFFFF).randint(0, 2 ** 31 - 1, size=self.C)
@@ -111,6 +119,8 @@ class DeviceChains(object):
         t["propdist"] = torch.from_numpy(pd0).to(dev)
         t["proposed"], t["accepted"] = torch.zeros((5, Cn), **f64), torch.zeros((5, Cn), **f64)
         t["naccepted"] = torch.zeros(Cn, dtype=torch.int64, device=dev)
+        t["beta"] = None if betas is None else torch.as_tensor(np.asarray(betas, dtype=np.float64)).to(dev)
+        self.ladder = None if betas is None else np.asarray(ladder if ladder is not None else np.zeros(Cn), dtype=np.int64)
         for k in ("pn", "move", "valid", "lay_n"):
             t[k] = torch.zeros(Cn, **i32)
         for k in ("pvs", "pz", "lay_h", "lay_vp", "lay_vs"):
@@ -140,6 +150,18 @@ class DeviceChains(object):
                              self.mis.data_ptr(), self.err.data_ptr())
         e.chain_accept(self.cfg, self.state, Cn, self.iiter, self.logL.data_ptr(), self.mis.data_ptr())
         self.iiter += 1
+        if self.swap_every > 0 and t["beta"] is not None and self.iiter % self.swap_every == 0:
+            self.exchange()
+
+    def exchange(self):
+        """One replica-exchange sweep (the only step of a sharded job with a collective)."""
+        from .parallel import tempering_exchange
+        self.engine.synchronize()
+        newb, nacc = tempering_exchange(self.t["like"], self.t["beta"], self.ladder, self.sweep, self.seed, self.dist)
+        self.t["beta"].copy_(newb)
+        self.torch.cuda.synchronize()
+        self.sweep += 1
+        self.nswaps += nacc
 
     def _snapshot(self):
         self.engine.synchronize()
@@ -147,7 +169,8 @@ class DeviceChains(object):
         row = dict(n=t["n"].cpu().numpy(), vs=t["vs"].cpu().numpy().astype(np.float32),
                    z=t["z"].cpu().numpy().astype(np.float32), like=t["like"].cpu().numpy().astype(np.float32),
                    misfits=t["misfits"].cpu().numpy().astype(np.float32), noise=t["noise"].cpu().numpy().astype(np.float32),
-                   vpvs=t["vpvs"].cpu().numpy().astype(np.float32))
+                   vpvs=t["vpvs"].cpu().numpy().astype(np.float32),
+                   beta=None if t["beta"] is None else t["beta"].cpu().numpy())
         self.snap["p1" if self.iiter < 0 else "p2"].append(row)
 
     def run(self, progress=None):
@@ -185,6 +208,8 @@ class DeviceChains(object):
             out[k + "s" if k == "like" else k] = np.array([r[k] for r in S], dtype=np.float32).reshape(ns, Cn)
         out["misfits"] = np.array([r["misfits"].T for r in S], dtype=np.float32).reshape(ns, Cn, self.nt + 1)
         out["noise"] = np.array([r["noise"].T for r in S], dtype=np.float32).reshape(ns, Cn, 2 * self.nt)
+        if ns and S[0]["beta"] is not None:
+            out["beta"] = np.array([r["beta"] for r in S]).reshape(ns, Cn)   # cold samples: out["beta"] == 1
         return out
 
     def save(self, savepath=None):

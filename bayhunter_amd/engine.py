@@ -62,7 +62,7 @@ class ChainConfig(C.Structure):
 
 
 CHAIN_STATE_FIELDS = ("n", "vs", "z", "vpvs", "noise", "like", "misfits", "propdist", "proposed", "accepted", "naccepted",
-                      "pn", "move", "valid", "pvs", "pz", "pvpvs", "pnoise", "dvs2", "lay_n", "lay_h", "lay_vp", "lay_vs",
+                      "beta", "pn", "move", "valid", "pvs", "pz", "pvpvs", "pnoise", "dvs2", "lay_n", "lay_h", "lay_vp", "lay_vs",
                       "inject")
 
 

@@ -76,3 +76,47 @@ def tempering_swap(local_logL, local_beta, sweep, seed, dist=None):
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     perm = swap_decisions(allv[:, 0], allv[:, 1], sweep, seed)
     return perm, shard_slice(allv.shape[0], rank, world) if world > 1 else slice(0, allv.shape[0])
+
+
+def ladder_swap_betas(logL, beta, ladder, sweep, seed):
+    """Replica exchange by swapping TEMPERATURES, so that no chain state ever moves between chains
+    (or GPUs): `logL[i]`, `beta[i]`, `ladder[i]` for ALL chains of the job (any order, e.g. rank-major
+    after an all-gather).  Inside every ladder the chains are ordered by temperature (beta descending,
+    ties by chain index) and neighbours (r, r+1) with r of parity `sweep % 2` exchange their betas
+    with probability min(1, exp((beta_r - beta_{r+1}) * (logL_{r+1} - logL_r))) -- the rule of
+    `swap_decisions`.  Deterministic in (seed, sweep): every rank computes the identical answer.
+    Returns (new beta array, number of accepted swaps)."""
+    logL = np.asarray(logL, dtype=float)
+    beta = np.asarray(beta, dtype=float)
+    ladder = np.asarray(ladder)
+    out = beta.copy()
+    nacc = 0
+    for lid in np.unique(ladder):
+        idx = np.flatnonzero(ladder == lid)
+        order = idx[np.lexsort((idx, -beta[idx]))]          # rung 0 = coldest
+        perm = swap_decisions(logL[order], beta[order], sweep, (int(seed) * 7919 + int(lid)) % (2 ** 31))
+        # rung r continues with the state of rung perm[r]  <=>  the chain at rung perm[r] takes beta of rung r
+        out[order[perm]] = beta[order]
+        nacc += int(np.count_nonzero(perm != np.arange(perm.size)) // 2)
+    return out, nacc
+
+
+def tempering_exchange(local_logL, local_beta, local_ladder, sweep, seed, dist=None):
+    """The swap step of a sharded job: all-gather (logL, beta, ladder) of every rank's chains (RCCL over
+    xGMI when the tensors are on GPUs; a few floats per chain), decide with `ladder_swap_betas`, return
+    this rank's new betas (same dtype/device as `local_beta`) and the global number of accepted swaps."""
+    import torch
+    lb = torch.as_tensor(local_beta)
+    local = torch.stack((torch.as_tensor(local_logL, dtype=torch.float64, device=lb.device),
+                         lb.to(torch.float64), torch.as_tensor(local_ladder, device=lb.device).to(torch.float64)), dim=1)
+    allv = all_gather_rows(local, dist).cpu().numpy()
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    newb, nacc = ladder_swap_betas(allv[:, 0], allv[:, 1], allv[:, 2].astype(np.int64), sweep, seed)
+    if world > 1:   # rank-major concatenation: this rank's block
+        counts = all_gather_rows(torch.tensor([[local.shape[0]]], device=lb.device, dtype=torch.int64), dist).cpu().numpy().ravel()
+        start = int(counts[:rank].sum())
+        mine = slice(start, start + local.shape[0])
+    else:
+        mine = slice(0, local.shape[0])
+    return torch.as_tensor(newb[mine], dtype=lb.dtype, device=lb.device), nacc

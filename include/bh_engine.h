@@ -219,6 +219,8 @@ typedef struct bh_chain_state {
     double *propdist; /* [5][C] vs, z, birth/death, noise, vpvs (SingleChain.py:117) */
     double *proposed, *accepted; /* [5][C] counters */
     int64_t *naccepted; /* [C] */
+    const double *beta; /* NULL or [C]: inverse temperature of each chain (parallel tempering: the
+                           likelihood ratio enters the acceptance as beta*(logL' - logL); 1 = the reference) */
     /* proposal (written by bh_chain_propose, read by bh_chain_accept) */
     int32_t *pn, *move, *valid; /* [C] */
     double *pvs, *pz;  /* [maxlayers][C] */

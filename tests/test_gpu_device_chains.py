@@ -140,3 +140,36 @@ def test_many_chains_converge_and_save(tmp_path):
     n, vs, z = bh.Model.split_modelparams(m[-1])
     assert n == st["n"][C - 1] and np.all(np.diff(z) > 0)
     assert np.allclose(vs, st["vs"][:n, C - 1].astype(np.float32))
+
+
+def test_parallel_tempering_on_device_chains():
+    """Parallel tempering (no reference counterpart: invariants only).  32 ladders x 6 temperatures:
+    beta = 1 everywhere and no swaps reproduces the untempered run bit for bit; with a ladder every ladder
+    keeps its set of temperatures, swaps happen, hot chains accept more, and the chains that hold beta = 1
+    sit at a higher likelihood than the hottest ones."""
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=900, iter_main=300, maxmodels=30)
+    nl, nr = 32, 6
+    C = nl * nr
+    plain = DeviceChains(make_targets(g), C, init, su["priors"], seed=11).run().state_host()
+    ones = DeviceChains(make_targets(g), C, init, su["priors"], seed=11, betas=np.ones(C), ladder=np.repeat(np.arange(nl), nr),
+                        swap_every=0).run().state_host()
+    for k in ("n", "vs", "z", "like", "noise", "vpvs", "propdist", "accepted"):
+        assert np.array_equal(plain[k], ones[k]), k
+    ladder = np.repeat(np.arange(nl), nr)
+    betas = np.tile(1.0 / np.geomspace(1.0, 30.0, nr), nl)
+    dc = DeviceChains(make_targets(g), C, init, su["priors"], seed=11, betas=betas, ladder=ladder, swap_every=20).run()
+    st = dc.state_host()
+    assert dc.sweep == 1200 // 20 and dc.nswaps > 50
+    for lid in range(nl):
+        assert np.allclose(np.sort(st["beta"][ladder == lid]), np.sort(betas[ladder == lid]), rtol=0, atol=0)
+    cold, hot = st["beta"] == 1.0, st["beta"] == betas.min()
+    assert cold.sum() == nl and hot.sum() == nl
+    assert np.median(st["like"][cold]) > np.median(st["like"][hot]) + 20.0
+    s = dc.samples("p2")
+    assert s["beta"].shape == (len(dc.snap["p2"]), C) and (np.sum(s["beta"] == 1.0, axis=1) == nl).all()
+    # acceptance is easier at high temperature: compare chains that spent the run hot vs cold on average
+    mean_beta = np.mean([r["beta"] for r in dc.snap["p1"] + dc.snap["p2"]], axis=0)
+    rate = st["accepted"].sum(axis=0) / np.maximum(st["proposed"].sum(axis=0), 1)
+    assert np.mean(rate[mean_beta < 0.2]) > np.mean(rate[mean_beta > 0.6])

@@ -50,6 +50,41 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _pt_job():
+    rs = np.random.RandomState(4)
+    L = rs.normal(-40.0, 6.0, 12)
+    Bt = np.repeat([1.0, 0.6], 6)            # rank 0 holds the cold rung of every ladder, rank 1 the warm one
+    lad = np.tile(np.arange(6), 2)
+    return L, Bt, lad
+
+
+def test_ladder_swap_betas_properties():
+    rs = np.random.RandomState(0)
+    nl, nr = 5, 8
+    ladder = np.repeat(np.arange(nl), nr)
+    beta0 = np.tile(1.0 / np.geomspace(1, 50, nr), nl)
+    order = rs.permutation(nl * nr)                       # any chain order
+    ladder, beta = ladder[order], beta0[order]
+    acc = 0
+    for sweep in range(40):
+        logL = rs.normal(-100, 15, nl * nr)
+        newb, nacc = parallel.ladder_swap_betas(logL, beta, ladder, sweep, seed=3)
+        again, _ = parallel.ladder_swap_betas(logL, beta, ladder, sweep, seed=3)
+        assert np.array_equal(newb, again)               # deterministic in (seed, sweep)
+        for lid in range(nl):                             # every ladder keeps its set of temperatures
+            assert np.array_equal(np.sort(newb[ladder == lid]), np.sort(beta[ladder == lid]))
+        changed = np.flatnonzero(newb != beta)
+        assert changed.size == 2 * nacc
+        acc += nacc
+        beta = newb
+    assert acc > 20
+    # a swap that raises the cold chain's likelihood is always accepted; the reverse with probability exp(-delta)
+    nb, n1 = parallel.ladder_swap_betas([-100.0, -10.0], [1.0, 0.5], [0, 0], 0, 1)
+    assert n1 == 1 and nb.tolist() == [0.5, 1.0]
+    f = np.mean([parallel.ladder_swap_betas([-28.0, -30.0], [1.0, 0.5], [0, 0], 0, s)[1] for s in range(4000)])
+    assert abs(f - np.exp(-1.0)) < 0.03
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,7 +103,11 @@ def _worker(rank, world, port, out):
         allL = np.array([-50.0, -40.0, -45.0, -20.0, -60.0]); allB = 1.0 / np.geomspace(1, 8, 5)
         off = 0 if rank == 0 else 3
         perm, mine = parallel.tempering_swap(allL[off:off + nl], allB[off:off + nl], sweep=1, seed=5, dist=dist)
-        out.put((rank, float(t.item()), rows.squeeze(1).tolist(), perm.tolist(), (mine.start, mine.stop)))
+        # temperature exchange of a job sharded "one temperature per rank": 2 ranks x 6 chains, 6 ladders of 2 rungs
+        L, Bt, lad = _pt_job()
+        my = slice(0, 6) if rank == 0 else slice(6, 12)
+        newb, nacc = parallel.tempering_exchange(torch.tensor(L[my]), torch.tensor(Bt[my]), lad[my], sweep=0, seed=9, dist=dist)
+        out.put((rank, float(t.item()), rows.squeeze(1).tolist(), perm.tolist(), (mine.start, mine.stop), newb.tolist(), nacc))
     finally:
         dist.destroy_process_group()
 
@@ -85,7 +124,11 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, t0, rows0, perm0, mine0), (r1, t1, rows1, perm1, mine1) = res
+    (r0, t0, rows0, perm0, mine0, nb0, na0), (r1, t1, rows1, perm1, mine1, nb1, na1) = res
+    L, Bt, lad = _pt_job()
+    expect_b, expect_n = parallel.ladder_swap_betas(L, Bt, lad, 0, 9)
+    assert na0 == na1 == expect_n and expect_n > 0
+    assert nb0 == expect_b[:6].tolist() and nb1 == expect_b[6:].tolist()
     assert t0 == t1 == 2.0
     assert rows0 == rows1 == [2.0 * i for i in range(11)]
     assert perm0 == perm1 and sorted(perm0) == [0, 1, 2, 3, 4]
