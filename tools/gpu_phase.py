@@ -8,7 +8,7 @@ rs = np.random.RandomState(5)
 yobs = 3.4 + 0.01 * SWD_PERIODS
 eng.set_targets([dict(kind=E.TARGET_SWD, law=0, n=30, x=SWD_PERIODS, yobs=yobs, iwave=2, igr=0),
                  dict(kind=E.TARGET_SWD, law=0, n=30, x=SWD_PERIODS, yobs=yobs, iwave=1, igr=0)])
-B = 4096
+B = int(os.environ.get("B", "4096"))
 nlay, h, vp, vs, rho = synth_models(rs, B, 10, lvz_frac=0.1)
 noise = np.tile([0, 0.05, 0, 0.05], (B, 1))
 Js = [int(a) for a in (sys.argv[2] if len(sys.argv) > 2 else '1').split(',')]
