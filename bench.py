@@ -13,6 +13,8 @@ Workloads (BASELINE.json configs):
      uncorrelated noise law.
   c3: c2 + P receiver function (Gauss a = 2.5, 1024 kept samples @ 20 Hz -> nsamp 2048,
      p = 6.4 s/deg), exponential-correlated noise law on the RF.
+  c2g / c3g: the "second runs" of SURVEY.md 8(d) -- c2 with GROUP velocities; c3 with the Gauss law
+     (fixed r = 0.92, rcond = 1e-6: the dense quadratic form on the FP64 matrix cores).
 N > 1: one process per GPU (torchrun), independent batches per rank, no data-path collective
 (the path shards by model) -> "scaling": "weak"; barrier + max-over-ranks timing.
 
@@ -48,16 +50,25 @@ def build_workload(name, B, L, seed):
     rs = np.random.RandomState(seed)
     batches = [synth_models(rs, B, L, lvz_frac=0.1) for _ in range(NPOOL)]
     per = SWD_PERIODS
-    spec = [dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=2, igr=0, name="rdispph"),
-            dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=1, igr=0, name="ldispph")]
-    if name == "c3":
+    igr = 1 if name == "c2g" else 0     # c2g: the "second run" of SURVEY.md 8(d) with group velocities
+    spec = [dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=2, igr=igr, name="rdispgr" if igr else "rdispph"),
+            dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=1, igr=igr, name="ldispgr" if igr else "ldispph")]
+    if name in ("c3", "c3g"):
         spec.append(dict(kind=E.TARGET_RF, law=E.LAW_EXP, n=RF_TIME.size, waveno=0, nsamp=2048, p=6.4,
                          gauss=2.5, fsamp=20.0, tshift=5.0, name="prf"))
+    if name == "c3g":                   # second run of 8(d): Gauss law with fixed r = 0.92, rcond = 1e-6
+        n = RF_TIME.size
+        idx = np.arange(n)
+        R = 0.92 ** ((idx[:, None] - idx[None, :]) ** 2.0)          # Targets.py:150-160
+        spec[-1].update(law=E.LAW_GAUSS, rinv=np.linalg.pinv(R, rcond=1e-6), logdet_r=float(np.linalg.slogdet(R)[1]))
     nt = len(spec)
     noise = np.zeros((B, 2 * nt))
     for t, s in enumerate(spec):
         if s["law"] == E.LAW_EXP:
             noise[:, 2 * t] = rs.uniform(0.35, 0.75, B)
+            noise[:, 2 * t + 1] = rs.uniform(1e-3, 0.05, B)
+        elif s["law"] == E.LAW_GAUSS:
+            noise[:, 2 * t] = 0.92
             noise[:, 2 * t + 1] = rs.uniform(1e-3, 0.05, B)
         else:
             noise[:, 2 * t + 1] = rs.uniform(0.005, 0.05, B)
@@ -131,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c2g", "c3g"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -220,7 +231,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
-                                    "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF"}[args.workload],
+                                    "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF",
+                                    "c2g": "joint Rayleigh+Love GROUP dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
+                                    "c3g": "c3 with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF"}[args.workload],
                        "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
                        "parallelism": "models sharded one batch per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

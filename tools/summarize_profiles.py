@@ -23,7 +23,7 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for wl in ("c2", "c3"):
+for wl in ("c2", "c3", "c2g", "c3g"):
     f = find("trace_%s/**/*kernel_stats.csv" % wl)
     if f:
         shutil.copy(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)))
@@ -78,7 +78,7 @@ open(os.path.join(out, "%s_pmc_hbm.txt" % tag), "w").write("\n".join(lines) + "\
 print("\n".join(lines))
 
 sq = counters("pmc_SQ/**/*counter_collection.csv")
-lines = ["rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -- python bench.py "
+lines = ["rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -- python bench.py "
          "--no-cpu-baseline --steps 4 --warmup 1 (c2); per dispatch, summed over XCDs", ""]
 for kern, cs in sq.items():
     if "swd_group_kernel" in kern:
@@ -87,5 +87,8 @@ for kern, cs in sq.items():
             lines.append("%-22s %16.0f" % (k, m[k]))
         if m.get("SQ_WAVE_CYCLES") and m.get("SQ_ACTIVE_INST_VALU"):
             lines.append("VALU-active share of resident-wave cycles = %.3f" % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]))
+        if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
+            lines.append("active-lane fraction of VALU cycles (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = %.3f"
+                         % (m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])))
 open(os.path.join(out, "%s_pmc_sq.txt" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
