@@ -272,3 +272,17 @@ def test_lookahead_does_not_change_results(engine, G, J):
         engine.set_swd_group(0)
         engine.set_swd_lookahead(0)
         engine.set_instrumentation(False, False)
+
+
+@pytest.mark.parametrize("L,B", [(100, 5), (21, 300), (50, 40)])
+def test_deep_models_up_to_the_fortran_limit(engine, oracle, L, B):
+    """Models with up to NL = 100 layers (surfdisp96.f:59) -- the lanes-per-model choice has to adapt to
+    what fits the LDS -- and the 20-layer transdimensional case of BASELINE configs[4]; all types."""
+    rs = np.random.RandomState(L)
+    nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.2, ragged=(L == 21))
+    h[:-1] *= 10.0 / L                       # keep the stack ~60 km thick
+    per = np.linspace(2, 60, 24)
+    for iwave, igr in REFS.values():
+        v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+        ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
+        assert np.array_equal(e, oe) and np.array_equal(v, ov), (L, iwave, igr)
