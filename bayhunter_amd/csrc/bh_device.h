@@ -75,7 +75,7 @@ struct SwdMultiArgs {
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
-void bh_swd_pick_lookahead(int B, int G, int ntargets, const int *iwave, int *look);
+double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
 void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream); // look-ahead per target in a.t[i].look
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies

@@ -267,23 +267,22 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                          base + 3 * ne, base + 4 * ne, st);
         sh = base; svp = base + ne; svs = base + 2 * ne; srl = base + 3 * ne; srr = base + 4 * ne;
     }
-    int G = e->force_group > 0 ? e->force_group : bh_swd_pick_group(B, nlive, Lmax);
+    int iw[BH_MAX_TARGETS], look[BH_MAX_TARGETS], G = 1;
+    {
+        int n = 0;
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].K != 0) iw[n++] = jobs[j].iwave;
+        bh_swd_plan(B, Lmax, n, iw, e->force_group, &G, look);
+        if (e->force_look > 0 && G > 1)
+            for (int t = 0; t < n; ++t) look[t] = e->force_look;
+    }
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
     while (G > 1 && G < 64 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) G += 1; // fewer models per wave
     if (G > 1 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) return fail(e, BH_EINVAL, "model too deep for LDS");
-    int look[BH_MAX_TARGETS];
-    if (G > 1) {
-        int iw[BH_MAX_TARGETS], n = 0;
-        for (int j = 0; j < njobs; ++j)
-            if (jobs[j].K != 0) iw[n++] = jobs[j].iwave;
-        if (e->force_look > 0)
-            for (int t = 0; t < n; ++t) look[t] = e->force_look;
-        else
-            bh_swd_pick_lookahead(B, G, n, iw, look);
-        for (int t = 0; t < n; ++t)
+    if (G > 1)
+        for (int t = 0; t < nlive; ++t)
             while (look[t] > 1 && (G * look[t] > 64 || bh_swd_group_lds_bytes(G, look[t], Lmax, kmax, maxmode) > lds_cap)) look[t] -= 1;
-    }
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
     if (G <= 1) {

@@ -1472,63 +1472,96 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
         hipLaunchKernelGGL(swd_kernel<2>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
 }
 
+// ---- launch plan ------------------------------------------------------------------------------------
+// Which mapping (one lane per model, or G lanes per model) and how many trial velocities per round and
+// target.  Cost model, calibrated on MI355X with 10-layer models and 30 periods (profiles/):
+// at this kernel's register budget 2 wavefronts are resident per SIMD = 2048 on the chip; a launch runs in
+// ceil(wavefronts / 2048) rounds, each as long as its longest wavefront.  Relative wavefront durations:
+//   group kernel, Rayleigh: 1 / .64 / .52 / .45 / .36 for 1 / 2 / 3 / 4 / 7 trials per round,
+//   group kernel, Love:     0.79 x (1 / .70 / .49 / .42 / .33),
+//   one lane per model:     4.3 (64 models per wavefront, every layer term serial).
+// More trials shorten every model's chain of dependent secular evaluations (what a small batch is bound
+// by) but cost lanes, i.e. wavefronts.  The plan minimises rounds x longest wavefront.
+namespace {
+constexpr int PLAN_LEVELS = 5;
+const int plan_trials[PLAN_LEVELS] = {1, 2, 3, 4, 7};
+const double plan_dur[2][PLAN_LEVELS] = {{0.79, 0.55, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
+constexpr int PLAN_SLOTS = 2048;
+constexpr double PLAN_LANE_PER_MODEL = 4.3;
+
+int plan_fit(int G, int level) // largest trial count <= the level's that fits a wavefront
+{
+    int J = plan_trials[level];
+    while (J > 1 && G * J > BH_WAVE) --J;
+    return J;
+}
+} // namespace
+
 int bh_swd_pick_group(int B, int ntargets, int Lmax)
 {
-    // One lane per model when the batch alone gives every SIMD >= 2 wavefronts; otherwise one
-    // lane per finite layer (at least 5: the width of the Rayleigh vector recursion), capped
-    // at 16, so that phase A needs a single round.
-    if ((long)B * ntargets / BH_WAVE >= 2048) return 1;
+    // one lane per finite layer (at least 5: the width of the Rayleigh vector recursion), capped at
+    // 16, so that phase A needs a single round
     int G = Lmax - 1;
     if (G < 5) G = 5;
     if (G > 16) G = 16;
+    (void)B; (void)ntargets;
     return G;
 }
 
-void bh_swd_pick_lookahead(int B, int G, int ntargets, const int *iwave, int *look)
+// Returns the plan's cost; *G = 1 selects the lane-per-model kernel (look[] is then all 1).
+// Gforce > 0: the caller fixed the lanes per model, only the trials are planned.
+double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look)
 {
-    // Trial velocities per round, per target (see SearchT::candidate).  More of them shorten every
-    // model's chain of dependent secular evaluations (what a small batch is bound by) but cost lanes,
-    // i.e. wavefronts; that pays for as long as all wavefronts of the launch are resident at once:
-    // 2 per SIMD at this kernel's register budget = 2048 on the chip.  Greedy: keep shortening the
-    // target with the longest wavefronts while the launch still fits.  Relative wavefront durations
-    // measured on MI355X (10-layer models, 30 periods; profiles/): Rayleigh 1 / .64 / .52 / .45 / .36
-    // for 1 / 2 / 3 / 4 / 7 trials, Love 0.79 x (1 / .70 / .49 / .42 / .33).
-    static const int levels[5] = {1, 2, 3, 4, 7};
-    static const double dur[2][5] = {{0.79, 0.55, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
-    const int slots = 2048;
-    int lvl[8];
-    for (int t = 0; t < ntargets; ++t) lvl[t] = 0;
-    auto feasible = [&](int t, int l) { // largest J <= levels[l] that fits a wavefront
-        int J = levels[l];
-        while (J > 1 && G * J > BH_WAVE) --J;
-        return J;
-    };
-    auto waves = [&](int t, int l) {
-        const int J = feasible(t, l);
-        const int mpw = BH_WAVE / (G * J);
-        return (B + mpw - 1) / mpw;
-    };
-    for (;;) {
-        int worst = -1;
-        double dworst = 0.0;
+    const int Gg = Gforce > 1 ? Gforce : bh_swd_pick_group(B, ntargets, Lmax);
+    int lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, best_lvl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double best = 1e300;
+    auto cost = [&](const int *l) {
+        long waves = 0;
+        double dmax = 0.0, dsum = 0.0;
         for (int t = 0; t < ntargets; ++t) {
-            const double d = dur[iwave[t] == 2 ? 1 : 0][lvl[t]];
-            if (d > dworst) {
-                dworst = d;
-                worst = t;
+            const int J = plan_fit(Gg, l[t]);
+            const int mpw = BH_WAVE / (Gg * J);
+            waves += (B + mpw - 1) / mpw;
+            const double d = plan_dur[iwave[t] == 2 ? 1 : 0][l[t]];
+            dmax = d > dmax ? d : dmax;
+            dsum += d;
+        }
+        const long rounds = (waves + PLAN_SLOTS - 1) / PLAN_SLOTS;
+        // (two wavefronts on a SIMD slow each other down a little; ties go to the shorter wavefronts)
+        return (double)rounds * dmax * (waves > PLAN_SLOTS / 2 ? 1.15 : 1.0) + 1e-3 * dsum;
+    };
+    if (ntargets <= 4) { // exhaustive
+        for (;;) {
+            const double c = cost(lvl);
+            if (c < best) {
+                best = c;
+                for (int t = 0; t < ntargets; ++t) best_lvl[t] = lvl[t];
+            }
+            int t = 0;
+            while (t < ntargets && ++lvl[t] == PLAN_LEVELS) lvl[t++] = 0;
+            if (t == ntargets) break;
+        }
+    } else { // same level for all targets
+        for (int l = 0; l < PLAN_LEVELS; ++l) {
+            for (int t = 0; t < ntargets; ++t) lvl[t] = l;
+            const double c = cost(lvl);
+            if (c < best) {
+                best = c;
+                for (int t = 0; t < ntargets; ++t) best_lvl[t] = l;
             }
         }
-        if (worst < 0 || lvl[worst] >= 4) break;
-        const int nl = lvl[worst] + 1;
-        if (feasible(worst, nl) == feasible(worst, lvl[worst])) break; // no more lanes to give
-        int total = 0;
-        for (int t = 0; t < ntargets; ++t) total += waves(t, t == worst ? nl : lvl[t]);
-        // one model per wavefront with many trials keeps the LDS pipes busier: leave headroom there
-        const int cap = (levels[nl] > 4) ? slots / 2 : slots;
-        if (total > cap) break;
-        lvl[worst] = nl;
     }
-    for (int t = 0; t < ntargets; ++t) look[t] = feasible(t, lvl[t]);
+    // the lane-per-model kernel: one launch per target, 64 models per wavefront
+    const long w1 = (long)ntargets * ((B + BH_WAVE - 1) / BH_WAVE);
+    const double c1 = (double)((w1 + PLAN_SLOTS - 1) / PLAN_SLOTS) * PLAN_LANE_PER_MODEL;
+    if (Gforce == 1 || (Gforce <= 0 && c1 < best)) {
+        *G = 1;
+        for (int t = 0; t < ntargets; ++t) look[t] = 1;
+        return c1;
+    }
+    *G = Gg;
+    for (int t = 0; t < ntargets; ++t) look[t] = plan_fit(Gg, best_lvl[t]);
+    return best;
 }
 
 // LDS of one workgroup = shared libm tables + GROUP_WPB wavefront regions

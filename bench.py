@@ -157,10 +157,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torchrun (one rank per GPU)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
+    # Dry-run aid for boxes with ONE GPU: BH_BENCH_DRYRUN=1 puts every rank on GPU 0 and uses gloo, so
+    # that the N > 1 control flow (rendezvous, barriers, max-over-ranks) can be exercised; never set by
+    # the driver, and the JSON line then says so in "data".
+    dryrun = os.environ.get("BH_BENCH_DRYRUN", "0") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     from bayhunter_amd import engine as E
@@ -229,7 +238,7 @@ def main():
             "metric": "forward-model+logL evals/sec (batched 10-layer models)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not dryrun else "synthetic (DRY RUN: all ranks on one GPU, gloo)",
             "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
                                     "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF",
                                     "c2g": "joint Rayleigh+Love GROUP dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
