@@ -62,6 +62,7 @@ size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
 struct SwdTarget {
     int iwave, igr, K, ldv, mode;
     int look; // trial velocities per round for this target's wavefronts (>= 1), see SearchT::candidate
+    int inlook; // Love only: further trials inside a lane group (1..4), see swd_group_kernel
     const double *h, *vp, *vs, *rho; // model arrays this target reads (earth-flattened copies when flsph = 1)
     ptrdiff_t sl, sb;
     const double *periods;

@@ -935,6 +935,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
 // elided for a single-wave workgroup).
 // =================================================================================================
 constexpr int CA_STRIDE = 26;
+constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used): up to 4 trials share a row
 
 // Phase B of the group kernel, Rayleigh.  `cam` = this model's parked layers (column-major
 // 5x5 each), e = half-space vector on entry / surface vector on exit.
@@ -1059,7 +1060,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
 {
     const int G = Gflags & 0xff;
     const SwdTarget T = A.t[blockIdx.y];
-    const int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target)
+    const int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
+    // Love only: further trials INSIDE a lane group.  Its recursion is scalar (every lane of the group
+    // would repeat it), so lane l runs trial l mod JL instead; only the layer terms cost JL passes.
+    const int JL = (T.iwave == 1 && T.inlook > 1) ? T.inlook : 1;
     const int LPM = G * J;         // lanes per model: J groups of G lanes, group r evaluates candidate r
     const int MPW = BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
     extern __shared__ __align__(16) unsigned char smem_all[];
@@ -1143,7 +1147,8 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (prof) t0 = clock64();
         const double omg = S.omega;
-        const double cev = (J == 1) ? S.ceval : S.candidate(rr);
+        const int cb = rr * JL + (li % JL); // the trial this lane carries through the recursion
+        const double cev = (J * JL == 1) ? S.ceval : S.candidate(cb);
         const double wvno = omg / cev;
         double del;
         if (ifunc == 2) {
@@ -1258,40 +1263,43 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
                 h_xkb = omega / beta1;
                 h_gammk = 1.0 / (beta1 * beta1); // e2 of the half-space (surfdisp96.f:731)
             }
-            // ---- phase A (Love): cosq, y, z, xmu per layer ----------------------------------------
-            for (int m = li; m <= mmax - 2; m += G) {
-                if (m >= llw - 1) {
-                    const double beta1 = md.Bv(m);
-                    const double rho1 = md.R(m);
-                    const double dm = md.D(m);
-                    const double xmu = rho1 * beta1 * beta1;
-                    const double xkb = (m == li) ? c_xkb : omega / beta1;
-                    const double wvnop = wvno + xkb;
-                    const double wvnom = fabs(wvno - xkb);
-                    const double rb = sqrt(wvnop * wvnom);
-                    const double q = dm * rb;
-                    double cosq, y, z;
-                    if (wvno < xkb) {
-                        double sinq;
-                        bh_sincos(q, &sinq, &cosq, LT);
-                        y = sinq / rb;
-                        z = -rb * sinq;
-                    } else if (wvno == xkb) {
-                        cosq = 1.0;
-                        y = dm;
-                        z = 0.0;
-                    } else {
-                        double fac = 0.0;
-                        if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
-                        cosq = (1.0 + fac) * 0.5;
-                        const double sinq = (1.0 - fac) * 0.5;
-                        y = sinq / rb;
-                        z = rb * sinq;
+            // ---- phase A (Love): cosq, y, z, xmu per layer, for each of the group's JL trials ----------
+            for (int jj = 0; jj < JL; ++jj) {
+                const double wv = (JL == 1) ? wvno : omg / S.candidate(rr * JL + jj);
+                for (int m = li; m <= mmax - 2; m += G) {
+                    if (m >= llw - 1) {
+                        const double beta1 = md.Bv(m);
+                        const double rho1 = md.R(m);
+                        const double dm = md.D(m);
+                        const double xmu = rho1 * beta1 * beta1;
+                        const double xkb = (m == li) ? c_xkb : omega / beta1;
+                        const double wvnop = wv + xkb;
+                        const double wvnom = fabs(wv - xkb);
+                        const double rb = sqrt(wvnop * wvnom);
+                        const double q = dm * rb;
+                        double cosq, y, z;
+                        if (wv < xkb) {
+                            double sinq;
+                            bh_sincos(q, &sinq, &cosq, LT);
+                            y = sinq / rb;
+                            z = -rb * sinq;
+                        } else if (wv == xkb) {
+                            cosq = 1.0;
+                            y = dm;
+                            z = 0.0;
+                        } else {
+                            double fac = 0.0;
+                            if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
+                            cosq = (1.0 + fac) * 0.5;
+                            const double sinq = (1.0 - fac) * 0.5;
+                            y = sinq / rb;
+                            z = rb * sinq;
+                        }
+                        double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE + LOVE_TERMS * jj);
+                        dst[0] = make_double2(cosq, y);
+                        dst[1] = make_double2(z, xmu);
+                        dst[2] = make_double2(bh_rcp_refined(xmu), 0.0);
                     }
-                    double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE);
-                    dst[0] = make_double2(cosq, y);
-                    dst[1] = make_double2(z, xmu);
-                    dst[2] = make_double2(bh_rcp_refined(xmu), 0.0);
                 }
             }
             double e1, e2;
@@ -1310,12 +1318,13 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
                 const double s1 = e1, s2 = e2;
                 DivRange dr;
                 dr.reset();
-                if (ragged) love_chain_group<true, false>(e1, e2, cam, mtop, mmax, llw, dr);
-                else love_chain_group<false, false>(e1, e2, cam, mtop, mmax, llw, dr);
+                const double *camt = cam + LOVE_TERMS * (li % JL); // this lane's trial
+                if (ragged) love_chain_group<true, false>(e1, e2, camt, mtop, mmax, llw, dr);
+                else love_chain_group<false, false>(e1, e2, camt, mtop, mmax, llw, dr);
                 if (!dr.ok() && S.active) {
                     e1 = s1;
                     e2 = s2;
-                    love_chain_group<true, true>(e1, e2, cam, mtop, mmax, llw, dr);
+                    love_chain_group<true, true>(e1, e2, camt, mtop, mmax, llw, dr);
                 }
             }
             del = e1;
@@ -1326,10 +1335,11 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
         // as long as its next request is the very velocity (at the same omega) the next group evaluated.
         {
             bool live = S.active;
-            for (int j = 0; j < J; ++j) {
+            const int Jtot = J * JL;
+            for (int j = 0; j < Jtot; ++j) {
                 double dj = del;
-                if (J > 1) {
-                    const int src = (g * J + j) * G;
+                if (Jtot > 1) {
+                    const int src = (g * J + j / JL) * G + (j % JL); // a lane that carried trial j
                     const double cj = __shfl(cev, src);
                     dj = __shfl(del, src);
                     live = live && S.active && S.ceval == cj && S.omega == omg;
@@ -1478,14 +1488,14 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 // at this kernel's register budget 2 wavefronts are resident per SIMD = 2048 on the chip; a launch runs in
 // ceil(wavefronts / 2048) rounds, each as long as its longest wavefront.  Relative wavefront durations:
 //   group kernel, Rayleigh: 1 / .64 / .52 / .45 / .36 for 1 / 2 / 3 / 4 / 7 trials per round,
-//   group kernel, Love:     0.79 x (1 / .70 / .49 / .42 / .33),
+//   group kernel, Love:     .735 / .54 / .39 / .33 / .26 (with two in-group trials at the first two levels),
 //   one lane per model:     4.3 (64 models per wavefront, every layer term serial).
 // More trials shorten every model's chain of dependent secular evaluations (what a small batch is bound
 // by) but cost lanes, i.e. wavefronts.  The plan minimises rounds x longest wavefront.
 namespace {
 constexpr int PLAN_LEVELS = 5;
 const int plan_trials[PLAN_LEVELS] = {1, 2, 3, 4, 7};
-const double plan_dur[2][PLAN_LEVELS] = {{0.79, 0.55, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
+const double plan_dur[2][PLAN_LEVELS] = {{0.735, 0.54, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
 constexpr int PLAN_SLOTS = 2048;
 constexpr double PLAN_LANE_PER_MODEL = 4.3;
 
