@@ -220,4 +220,118 @@ BH_HD int bhp_sincos_bl(double x, double *sn_out, double *cs_out, const double *
     *cs_out = co;
     return k < 0x419921FB;
 }
+
+/* ---- log: dbl-64/e_log.c, the FMA ifunc variant (__log_fma) ------------------------------------
+ * bhp_log_data: ln2hi, ln2lo, A[5] (poly), B[11] (poly1, B[0] = -0.5), then tab[128] of (invc, logc).
+ * Returns 0 for arguments the table paths do not cover (x <= 0, subnormal, inf, nan). */
+BH_HD int bhp_log(double x, double *out, const uint64_t *D)
+{
+    const double ln2hi = bhp_asdouble(D[0]), ln2lo = bhp_asdouble(D[1]);
+    const uint64_t *A = D + 2, *B = D + 7, *T = D + 18;
+    const uint64_t ix = bhp_asuint(x);
+    const uint32_t top = (uint32_t)(ix >> 48);
+    if (ix - 0x3fee000000000000ull <= 0x308ffffffffffull) { /* 1 - 2^-4 <= x < 1 + 0x1.09p-4 */
+        if (ix == 0x3ff0000000000000ull) {
+            *out = 0.0;
+            return 1;
+        }
+        const double r = x - 1.0;
+        const double p1 = __builtin_fma(r, bhp_asdouble(B[2]), bhp_asdouble(B[1]));
+        const double p4 = __builtin_fma(r, bhp_asdouble(B[5]), bhp_asdouble(B[4]));
+        const double r2 = r * r;
+        const double p7 = __builtin_fma(r, bhp_asdouble(B[8]), bhp_asdouble(B[7]));
+        const double q1 = __builtin_fma(r2, bhp_asdouble(B[3]), p1);
+        const double q4 = __builtin_fma(r2, bhp_asdouble(B[6]), p4);
+        const double r3 = r * r2;
+        double q7 = __builtin_fma(r2, bhp_asdouble(B[9]), p7);
+        q7 = __builtin_fma(r3, bhp_asdouble(B[10]), q7);
+        double poly = __builtin_fma(q7, r3, q4);
+        poly = __builtin_fma(poly, r3, q1);
+        const double two27 = 0x1p27;
+        const double w = __builtin_fma(r, two27, r);
+        const double rhi = __builtin_fma(-two27, r, w);
+        const double b0 = bhp_asdouble(B[0]);
+        const double rhi2 = rhi * rhi;
+        const double rlo = r - rhi;
+        const double hi = __builtin_fma(rhi2, b0, r);
+        const double rmhi = r - hi;
+        const double rsum = r + rhi;
+        double lo = __builtin_fma(rhi2, b0, rmhi);
+        const double b0rlo = b0 * rlo;
+        lo = __builtin_fma(b0rlo, rsum, lo);
+        const double y = __builtin_fma(poly, r3, lo);
+        *out = y + hi;
+        return 1;
+    }
+    if (top - 0x0010u > 0x7fdfu) return 0; /* zero, subnormal, negative, inf, nan */
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)((tmp >> 45) & 127);
+    const int64_t k = (int64_t)tmp >> 52;
+    const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    const double invc = bhp_asdouble(T[2 * i]), logc = bhp_asdouble(T[2 * i + 1]);
+    const double z = bhp_asdouble(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double kd = (double)(int32_t)k;
+    const double w = __builtin_fma(kd, ln2hi, logc);
+    const double p = __builtin_fma(r, bhp_asdouble(A[2]), bhp_asdouble(A[1]));
+    const double hi = w + r;
+    const double r2 = r * r;
+    double lo = w - hi;
+    lo = lo + r;
+    lo = __builtin_fma(kd, ln2lo, lo);
+    const double r3 = r * r2;
+    double q = __builtin_fma(r, bhp_asdouble(A[4]), bhp_asdouble(A[3]));
+    lo = __builtin_fma(r2, bhp_asdouble(A[0]), lo);
+    q = __builtin_fma(q, r2, p);
+    const double y = __builtin_fma(r3, q, lo);
+    *out = y + hi;
+    return 1;
+}
+
+/* ---- powf: flt-32/e_powf.c, the FMA ifunc variant (__powf_fma), main path only ----------------------
+ * x positive and normal, y finite and non-zero, |y*log2(x)| < 126.  bhp_powf_log2_data: tab[16] of
+ * (invc, logc), A[5]; bhp_exp2f_data: tab[32], shift_scaled, C[3].  Returns 0 outside that domain. */
+BH_HD int bhp_powf(float x, float y, float *out, const uint64_t *L, const uint64_t *E)
+{
+    union { float f; uint32_t u; } cx, cy, cz;
+    cx.f = x;
+    cy.f = y;
+    const uint32_t ix = cx.u, iy = cy.u;
+    if (ix - 0x00800000u > 0x7effffffu) return 0;       /* x < 2^-126, negative, inf or nan */
+    if (2u * iy - 1u > 0xfefffffeu) return 0;            /* y zero, inf or nan */
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15);
+    const uint32_t topb = tmp & 0xff800000u;
+    cz.u = ix - topb;
+    const int32_t k = (int32_t)topb >> 23;
+    const double invc = bhp_asdouble(L[2 * i]), logc = bhp_asdouble(L[2 * i + 1]);
+    const uint64_t *A = L + 32;
+    const double z = (double)cz.f;
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double ya = __builtin_fma(r, bhp_asdouble(A[0]), bhp_asdouble(A[1]));
+    const double p = __builtin_fma(r, bhp_asdouble(A[2]), bhp_asdouble(A[3]));
+    const double r2 = r * r;
+    double q = __builtin_fma(r, bhp_asdouble(A[4]), y0);
+    const double r4 = r2 * r2;
+    q = __builtin_fma(r2, p, q);
+    const double logx = __builtin_fma(ya, r4, q);
+    const double ylogx = (double)y * logx;
+    if (((bhp_asuint(ylogx) >> 47) & 0xffff) > 0x80beu) return 0; /* |ylogx| >= 126: over/underflow handling */
+    const double shift = bhp_asdouble(E[32]);
+    const uint64_t *C = E + 33;
+    double kd = ylogx + shift;
+    const uint64_t ki = bhp_asuint(kd);
+    kd = kd - shift;
+    const double rr = ylogx - kd;
+    const uint64_t t = E[ki & 31] + (ki << 47);
+    const double zz = __builtin_fma(rr, bhp_asdouble(C[0]), bhp_asdouble(C[1]));
+    const double rr2 = rr * rr;
+    double yy = __builtin_fma(rr, bhp_asdouble(C[2]), 1.0);
+    yy = __builtin_fma(zz, rr2, yy);
+    yy = yy * bhp_asdouble(t);
+    *out = (float)yy;
+    return 1;
+}
+
 #endif

@@ -1380,10 +1380,22 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
            (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
 }
 
+// log / powf of the host's libm (what the reference's compiled Fortran calls), restated in bh_libm.h;
+// arguments outside the restated paths (never produced by a physical model) use the device library.
+__device__ __forceinline__ double sphere_log(double x)
+{
+    double y;
+    return bhp_log(x, &y, bhp_log_data) ? y : log(x);
+}
+__device__ __forceinline__ float sphere_powf(float x, float y)
+{
+    float r;
+    return bhp_powf(x, y, &r, bhp_powf_log2_data, bhp_exp2f_data) ? r : powf(x, y);
+}
+
 // ---- earth flattening, surfdisp96.f:486-553 (`sphere`, both calls) --------------------------------
-// One lane per model.  Arithmetic widths as in the Fortran (model arrays binary32, radii binary64).
-// log() and powf() here are the device library's: results agree with the reference to ~1e-7
-// relative, not bit for bit (the flat-earth default path is bit-exact).
+// One lane per model.  Arithmetic widths as in the Fortran (model arrays binary32, radii binary64);
+// log() and powf() are the glibc restatements, so the transformed model is bit-identical to the reference's.
 __global__ void sphere_kernel(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
                               const double *vs, const double *rho, ptrdiff_t sl, ptrdiff_t sb, double *oh,
                               double *ovp, double *ovs, double *orl, double *orr)
@@ -1399,8 +1411,8 @@ __global__ void sphere_kernel(int B, int Lmax, const int32_t *nlay, const double
         const float a = (float)vp[o], bb = (float)vs[o], rt = (float)rho[o];
         dr = dr + (double)d;
         const double r1 = ar - dr;
-        const double z0 = ar * log(ar / r0);
-        const double z1 = ar * log(ar / r1);
+        const double z0 = ar * sphere_log(ar / r0);
+        const double z1 = ar * sphere_log(ar / r1);
         const float dn = (i == mmax - 1) ? 0.0f : (float)(z1 - z0); // d(mmax) = 0 afterwards
         const double tmp = (ar + ar) / (r0 + r1);                   // layer mid-point
         const float btp = (float)tmp;
@@ -1412,7 +1424,7 @@ __global__ void sphere_kernel(int B, int Lmax, const int32_t *nlay, const double
         ovp[q] = (double)(float)((double)a * tmp);
         ovs[q] = (double)(float)((double)bb * tmp);
         orl[q] = (double)(rt * (1.0f / p5));
-        orr[q] = (double)(rt * powf(btp, -2.275f));
+        orr[q] = (double)(rt * sphere_powf(btp, -2.275f));
         r0 = r1;
     }
 }

@@ -93,8 +93,7 @@ int bh_engine_synchronize(bh_engine *e);
  * type `igr`, modes 1..`mode` computed in turn with the values of the last one returned
  * (surfdisp96.f:219-357; a higher mode that finds no root leaves zeros and does not set err,
  * :313), flat (`flsph` = 0) or earth-flattened (`flsph` = 1, surfdisp96.f:486-553) model.
- * Flat-earth results are bit-identical to the reference; the flattening transform uses the
- * device's log/powf and agrees to ~1e-7 relative.
+ * Results are bit-identical to the reference, with or without the flattening transform.
  *   vel[b*K + k]  float64, values are binary32-rounded like the reference's output
  *   err[b]        0 ok / 1 no root found (then vel[b][k..] = 0 from the failing period on)
  */

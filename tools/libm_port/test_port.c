@@ -37,5 +37,29 @@ int main(void)
             ++n;
         }
     printf("exp: %ld inputs, mismatches %ld\n", n, bad_e);
-    return (bad_s || bad_c || bad_e || bad_bl) ? 2 : 0;
+    long bad_l = 0, bad_p = 0, skipped = 0;
+    n = 0;
+    const double lr[][2] = {{0.9375, 1.0648}, {1.0, 1.07}, {0.5, 2.0}, {1e-300, 1e-290}, {0.0, 10.0}, {1.0, 1e6}, {1e6, 1e300}};
+    for (int r = 0; r < 7; ++r)
+        for (long i = 0; i < 20000000; ++i) {
+            double x = lr[r][0] + urand() * (lr[r][1] - lr[r][0]);
+            if (r == 6) x = exp(urand() * 690.0);
+            double l0 = log(x), l1;
+            if (!bhp_log(x, &l1, bhp_log_data)) { ++skipped; continue; }
+            if (memcmp(&l0, &l1, 8)) { if (bad_l < 5) printf("log mismatch x=%.17g %a %a\n", x, l0, l1); ++bad_l; }
+            ++n;
+        }
+    printf("log: %ld inputs (%ld outside the table paths), mismatches %ld\n", n, skipped, bad_l);
+    n = 0; skipped = 0;
+    for (int r = 0; r < 4; ++r)
+        for (long i = 0; i < 20000000; ++i) {
+            float x = (float)(r == 0 ? 0.9 + 0.2 * urand() : r == 1 ? 0.5 + 1.5 * urand() : r == 2 ? 1e-3 + 50.0 * urand() : exp(-80.0 + 160.0 * urand()));
+            float y = (r < 2 && (i & 1)) ? -2.275f : (float)(-12.0 + 24.0 * urand());
+            float p0 = powf(x, y), p1;
+            if (!bhp_powf(x, y, &p1, bhp_powf_log2_data, bhp_exp2f_data)) { ++skipped; continue; }
+            if (memcmp(&p0, &p1, 4)) { if (bad_p < 5) printf("powf mismatch x=%.9g y=%.9g %a %a\n", x, y, p0, p1); ++bad_p; }
+            ++n;
+        }
+    printf("powf: %ld inputs (%ld outside the main path), mismatches %ld\n", n, skipped, bad_p);
+    return (bad_s || bad_c || bad_e || bad_bl || bad_l || bad_p) ? 2 : 0;
 }
