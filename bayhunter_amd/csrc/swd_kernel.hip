@@ -515,8 +515,15 @@ struct SearchT {
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
+        // Input sanity.  The reference's loops are bounded only through the model's velocities: with a NaN
+        // or an absurd value in the model it walks the velocity axis (practically) for ever.  A GPU kernel
+        // must end: such a model is reported in-band as failed (err = 1, zeros) without being searched.
+        bool sane = true;
         for (int i = 0; i < mmax; ++i) {
             const float bi = md.Bf(i), ai = md.Af(i);
+            const float di = md.Df(i), ri = (float)md.R(i);
+            sane = sane && (ai > 0.0f) && (ai <= 100.0f) && (bi >= 0.0f) && (bi <= 100.0f) && (ri > 0.0f) && (ri < 1.0e6f) &&
+                   (i == mmax - 1 || (di >= 0.0f && di < 1.0e7f));
             if (bi > 0.01f && bi < betmn) {
                 betmn = bi;
                 jmn = i;
@@ -557,8 +564,13 @@ struct SearchT {
         iq = 1;
         ift = 999;
         k = 0; root = 0; st = ST_FIRST; ifirst = 1;
-        active = valid && K > 0;
+        active = valid && K > 0 && sane;
         errflag = 0;
+        if (valid && !sane) {
+            errflag = 1;
+            if (writer_)
+                for (int i = 0; i < K_; ++i) vel_[i] = 0.0;
+        }
         c1 = cc; c2 = 0.0; clow = cc; del1 = del2 = del1st = 0.0;
         c3 = del3 = ck = 0.0;
         idir = 1; nev = 1; mnev = 1; nctrl = 1;
@@ -1342,7 +1354,9 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
                     const int src = (g * J + j / JL) * G + (j % JL); // a lane that carried trial j
                     const double cj = __shfl(cev, src);
                     dj = __shfl(del, src);
-                    live = live && S.active && S.ceval == cj && S.omega == omg;
+                    // trial 0 IS the pending request (consumed unconditionally, also when a broken model
+                    // has driven the search to NaN); a later trial only if the search now asks for it
+                    if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
                 }
                 if (__ballot(live) == 0ull) break;
                 if (live) S.advance(dj);

@@ -96,6 +96,9 @@ int bh_engine_synchronize(bh_engine *e);
  * Results are bit-identical to the reference, with or without the flattening transform.
  *   vel[b*K + k]  float64, values are binary32-rounded like the reference's output
  *   err[b]        0 ok / 1 no root found (then vel[b][k..] = 0 from the failing period on)
+ * A model with a non-finite or non-physical parameter (vp, rho <= 0, vs < 0, velocities > 100 km/s,
+ * negative thickness) is reported as failed without being searched: the reference's search loops are
+ * bounded only through the model's velocities and do not terminate on such input.
  */
 int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, const int32_t *nlay,
                  const double *h, const double *vp, const double *vs, const double *rho,

@@ -284,3 +284,28 @@ def test_deep_models_up_to_the_fortran_limit(engine, oracle, L, B):
         v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
         ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
         assert np.array_equal(e, oe) and np.array_equal(v, ov), (L, iwave, igr)
+
+
+def test_broken_models_are_failed_in_band(engine, oracle):
+    """NaN / infinite / negative / absurd parameters (a caller's bug).  The reference bounds its loops only
+    through the model's velocities and walks the velocity axis for ever on such input; the kernels report
+    such a model as failed (err = 1, zeros) without searching, and the healthy models of the batch are
+    unaffected -- for every lane mapping and look-ahead setting the planner can choose."""
+    rs = np.random.RandomState(8)
+    nlay, h, vp, vs, rho = synth_models(rs, 24, 6)
+    vs[2, 0] = np.nan; vp[1, 1] = np.inf; h[0, 2] = np.nan; rho[3, 3] = -1.0; vs[:, 4] = -1.0; h[1, 5] = -5.0
+    vp[:, 6] = 1e-60; vs[:, 7] = 1e30
+    per = np.linspace(2, 40, 12)
+    good = np.arange(8, 24)
+    try:
+        for G, J in ((0, 0), (1, 1), (9, 1), (9, 2), (9, 7), (16, 4)):
+            engine.set_swd_group(G)
+            engine.set_swd_lookahead(J)
+            for iwave, igr in REFS.values():
+                v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+                assert (e[:8] == 1).all() and (v[:8] == 0).all()
+                ov, oe, _ = oracle.swd_batch(nlay[good], h.T[good], vp.T[good], vs.T[good], rho.T[good], per, iwave, igr)
+                assert np.array_equal(v[good], ov) and np.array_equal(e[good], oe)
+    finally:
+        engine.set_swd_group(0)
+        engine.set_swd_lookahead(0)
