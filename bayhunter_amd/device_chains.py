@@ -194,15 +194,14 @@ class DeviceChains(object):
         S = self.snap[phase]
         ns, Cn, ML = len(S), self.C, self.ML
         models = np.full((ns, Cn, 2 * ML), np.nan, dtype=np.float32)
+        j = np.arange(2 * ML)[:, None]                               # position inside a reference row
         for i, r in enumerate(S):
-            live = np.arange(ML)[:, None] < r["n"][None, :]          # [ML, C]
-            vs = np.where(live, r["vs"], np.nan).T                    # [C, ML]
-            z = np.where(live, r["z"], np.nan).T
+            n = r["n"][None, :].astype(np.int64)                      # [1, C]
             # reference rows hold the n vs values first, then the n depths, then NaN padding
-            for c in range(Cn):
-                n = int(r["n"][c])
-                models[i, c, :n] = vs[c, :n]
-                models[i, c, n:2 * n] = z[c, :n]
+            both = np.vstack((r["vs"], r["z"]))                       # [2*ML, C]: vs rows, then z rows
+            src = np.where(j < n, j, ML + (j - n))                    # row of `both` feeding position j
+            row = np.take_along_axis(both, np.clip(src, 0, 2 * ML - 1), axis=0)
+            models[i] = np.where(j < 2 * n, row, np.nan).T
         out = dict(models=models)
         for k in ("like", "vpvs"):
             out[k + "s" if k == "like" else k] = np.array([r[k] for r in S], dtype=np.float32).reshape(ns, Cn)
