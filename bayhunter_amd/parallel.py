@@ -33,6 +33,9 @@ def all_gather_rows(local, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
+    home = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:   # CPU tests / dry runs: gloo moves host memory
+        return all_gather_rows(local.cpu(), dist).to(home)
     n = torch.tensor([local.shape[0]], device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
