@@ -46,6 +46,7 @@ __device__ __forceinline__ bool bh_div_safe(double x)
 struct SwdKernelArgs {
     int B, Lmax, K, igr, mode;
     const int32_t *nlay;
+    const int32_t *perm; // optional: models in the order the wavefronts take them (deepest first), see bh_launch_order
     const double *h, *vp, *vs, *rho;
     ptrdiff_t sl, sb; // element strides: layer, model
     const double *periods;
@@ -56,6 +57,9 @@ struct SwdKernelArgs {
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
+// perm[0..B) = model indices sorted by layer count, deepest first: wavefronts then hold models of (nearly)
+// one depth -- no masked layers, and the long-running deep models start first.  Results do not depend on it.
+void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, hipStream_t stream);
 size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
 
 // group kernel: G lanes per model, all dispersion targets of a call in one launch
@@ -72,6 +76,7 @@ struct SwdTarget {
 struct SwdMultiArgs {
     int B, Lmax, ntargets;
     const int32_t *nlay;
+    const int32_t *perm; // optional, as in SwdKernelArgs
     unsigned long long *neval;
     SwdTarget t[8];
 };

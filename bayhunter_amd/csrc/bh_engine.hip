@@ -42,7 +42,7 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, spec, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter, sph;
+        misfits, err_t, probe_in, probe_out, counter, sph, perm;
     // targets
     int nt = 0;
     int ldy = 0;
@@ -50,8 +50,10 @@ struct bh_engine {
     // instrumentation
     bool timing = false, counting = false;
     bool no_mfma = false; // BH_NO_MFMA env: Gauss law through the in-kernel mat-vec (A/B testing)
+    bool no_order = false; // BH_NO_ORDER env: wavefronts take the models in batch order (A/B testing)
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
+    int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int love_inlook = 0; // BH_SWD_LOVE_INLOOK env (experiment switch): Love trials inside a lane group, 0 = automatic
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -131,6 +133,7 @@ int check_models(bh_engine *e, int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb)
 struct Staged {
     const int32_t *nlay;
     const double *h, *vp, *vs, *rho, *qp, *qs;
+    int typ_layers = 0; // typical layer count of the batch when the host can see it (0 = unknown)
 };
 
 // Copy the model arrays of a BH_HOST call into the engine's device buffers.
@@ -150,6 +153,11 @@ int stage_models(bh_engine *e, int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb, cons
     HIPCHK(e, hipMemcpyAsync(e->vp.p, vp, bytes, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->vs.p, vs, bytes, hipMemcpyHostToDevice, e->stream));
     if (rho) HIPCHK(e, hipMemcpyAsync(e->rho.p, rho, bytes, hipMemcpyHostToDevice, e->stream));
+    {   // mean layer count, rounded up: what the lanes-per-model choice should be sized for
+        long sum = 0;
+        for (int b = 0; b < B; ++b) sum += nlay[b];
+        s.typ_layers = B > 0 ? (int)((sum + B - 1) / B) : 0;
+    }
     s.nlay = (const int32_t *)e->nlay.p;
     s.h = (const double *)e->h.p;
     s.vp = (const double *)e->vp.p;
@@ -273,7 +281,11 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         int n = 0;
         for (int j = 0; j < njobs; ++j)
             if (jobs[j].K != 0) iw[n++] = jobs[j].iwave;
-        bh_swd_plan(B, Lmax, n, iw, e->force_group, &G, look);
+        // lanes per model follow the TYPICAL depth of the batch (deeper models take further passes over
+        // their layers): known for host batches, a caller's hint for device-resident ones, else Lmax
+        int Lplan = m.typ_layers > 0 ? m.typ_layers : (e->hint_layers > 0 ? e->hint_layers : Lmax);
+        if (Lplan > Lmax) Lplan = Lmax;
+        bh_swd_plan(B, Lplan, n, iw, e->force_group, &G, look);
         if (e->force_look > 0 && G > 1)
             for (int t = 0; t < n; ++t) look[t] = e->force_look;
     }
@@ -286,12 +298,19 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             while (look[t] > 1 && (G * look[t] > 64 || bh_swd_group_lds_bytes(G, look[t], Lmax, kmax, maxmode) > lds_cap)) look[t] -= 1;
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
+    // processing order: deepest models first, wavefronts of (nearly) one depth
+    const int32_t *perm = nullptr;
+    if (B > 1 && !e->no_order) {
+        if ((rc = ensure(e, e->perm, (size_t)B * sizeof(int32_t)))) return rc;
+        bh_launch_order(B, m.nlay, (int32_t *)e->perm.p, st);
+        perm = (const int32_t *)e->perm.p;
+    }
     if (G <= 1) {
         for (int j = 0; j < njobs; ++j) {
             const SwdJob &J = jobs[j];
             if (J.K == 0) continue;
             SwdKernelArgs a{};
-            a.B = B; a.Lmax = Lmax; a.K = J.K; a.igr = J.igr; a.mode = J.mode;
+            a.B = B; a.Lmax = Lmax; a.K = J.K; a.igr = J.igr; a.mode = J.mode; a.perm = perm;
             a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.sl = sl; a.sb = sb;
             if (J.flsph == 1) {
                 a.h = sh; a.vp = svp; a.vs = svs; a.rho = (J.iwave == BH_WAVE_LOVE) ? srl : srr;
@@ -306,7 +325,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         return BH_OK;
     }
     SwdMultiArgs a{};
-    a.B = B; a.Lmax = Lmax; a.ntargets = 0; a.nlay = m.nlay; a.neval = counter;
+    a.B = B; a.Lmax = Lmax; a.ntargets = 0; a.nlay = m.nlay; a.neval = counter; a.perm = perm;
     for (int j = 0; j < njobs; ++j) {
         const SwdJob &J = jobs[j];
         if (J.K == 0) continue;
@@ -415,7 +434,16 @@ int bh_engine_create(int device, bh_engine **out)
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
     }
     if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
+    if (std::getenv("BH_NO_ORDER")) e->no_order = true;
     *out = e;
+    return BH_OK;
+}
+
+int bh_engine_set_typical_layers(bh_engine *e, int nlay)
+{
+    if (!e) return BH_EINVAL;
+    if (nlay < 0 || nlay > BH_MAX_LAYERS) return fail(e, BH_EINVAL, "typical layer count must be 0 (unknown) or 1..100");
+    e->hint_layers = nlay;
     return BH_OK;
 }
 
@@ -444,7 +472,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->spec, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm})
         release(*b);
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);

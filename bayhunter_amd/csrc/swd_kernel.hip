@@ -26,6 +26,7 @@
 //     binary32 arithmetic of the start value and of the group-velocity formula follow the
 //     reference exactly; only the device sin/cos/exp differ from the host
 //     libm in the last ulp.
+#include "../../include/bh_engine.h"
 #include "bh_device.h"
 #include <cstdlib>
 
@@ -850,8 +851,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int ib = blockIdx.x * BH_WAVE + lane;
-    const bool valid = ib < A.B;
+    const int sidx = blockIdx.x * BH_WAVE + lane; // position in the processing order
+    const bool valid = sidx < A.B;
+    const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
     const int Lmax = A.Lmax;
     const int K = A.K;
 
@@ -1092,8 +1094,9 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     const int rr = spare ? 0 : (lane % LPM) / G; // which candidate this lane's group evaluates
     const int li = spare ? 0 : lane % G;         // this lane's index inside its group
     const int slot = g * J + rr;                 // group index inside the wave
-    const int ib = wid * MPW + g;
-    const bool valid = ib < A.B;
+    const int sidx = wid * MPW + g; // position in the processing order
+    const bool valid = sidx < A.B;
+    const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
     const int Lmax = A.Lmax;
     const int K = T.K;
     const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
@@ -1112,9 +1115,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     // layer-major input), binary32 rounding like the f2py boundary
     for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
         const int l = idx / MPW, mg = idx % MPW;
-        const int b = wid * MPW + mg;
+        const int sb = wid * MPW + mg;
+        const int b = sb < A.B ? (A.perm ? A.perm[sb] : sb) : 0;
         float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
-        if (b < A.B && l < A.nlay[b]) {
+        if (sb < A.B && l < A.nlay[b]) {
             const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
             fd = (float)T.h[o];
             fa = (float)T.vp[o];
@@ -1394,6 +1398,35 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
            (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
 }
 
+// ---- processing order: models by layer count, deepest first (counting sort, one workgroup) -------------
+__global__ __launch_bounds__(1024) void order_kernel(int B, const int32_t *nlay, int32_t *perm)
+{
+    __shared__ int bin[BH_MAX_LAYERS + 2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < BH_MAX_LAYERS + 2; i += 1024) bin[i] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {
+        int n = nlay[b];
+        n = n < 0 ? 0 : (n > BH_MAX_LAYERS + 1 ? BH_MAX_LAYERS + 1 : n);
+        atomicAdd(&bin[n], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { // start offset of every depth, deepest first
+        int acc = 0;
+        for (int n = BH_MAX_LAYERS + 1; n >= 0; --n) {
+            const int c = bin[n];
+            bin[n] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += 1024) {
+        int n = nlay[b];
+        n = n < 0 ? 0 : (n > BH_MAX_LAYERS + 1 ? BH_MAX_LAYERS + 1 : n);
+        perm[atomicAdd(&bin[n], 1)] = b; // order inside a depth is arbitrary: per-model results do not depend on it
+    }
+}
+
 // log / powf of the host's libm (what the reference's compiled Fortran calls), restated in bh_libm.h;
 // arguments outside the restated paths (never produced by a physical model) use the device library.
 __device__ __forceinline__ double sphere_log(double x)
@@ -1475,6 +1508,11 @@ __global__ void interp_kernel(int B, int K0, const double *x0, const double *y0,
 }
 
 } // namespace
+
+void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, hipStream_t stream)
+{
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, B, nlay, perm);
+}
 
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
                       const double *vs, const double *rho, ptrdiff_t sl, ptrdiff_t sb, double *oh,

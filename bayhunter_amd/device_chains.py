@@ -172,6 +172,8 @@ class DeviceChains(object):
                    vpvs=t["vpvs"].cpu().numpy().astype(np.float32),
                    beta=None if t["beta"] is None else t["beta"].cpu().numpy())
         self.snap["p1" if self.iiter < 0 else "p2"].append(row)
+        # transdimensional chains: size the dispersion kernel's lane groups for the models the chains hold now
+        self.engine.set_typical_layers(int(np.ceil(row["n"].mean())))
 
     def run(self, progress=None):
         while self.iiter < self.iter_phase2:
@@ -181,6 +183,7 @@ class DeviceChains(object):
             if progress is not None and self.iiter % 1000 == 0:
                 progress(self)
         self.engine.synchronize()
+        self.engine.set_typical_layers(0)
         return self
 
     # ---- results -------------------------------------------------------------------------------------

@@ -103,6 +103,7 @@ def load_library():
     L.bh_engine_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
     L.bh_engine_set_swd_group.argtypes = [vp, C.c_int]
     L.bh_engine_set_swd_lookahead.argtypes = [vp, C.c_int]
+    L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
     L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -119,7 +120,7 @@ def load_library():
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
     L.bh_chain_propose.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int]
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
                  "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept"):
         getattr(L, name).restype = C.c_int
@@ -130,7 +131,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
                     "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept")
 
@@ -202,6 +203,10 @@ class Engine(object):
     def set_swd_group(self, lanes_per_model):
         """0 = automatic; 1..32 lanes of a wavefront per model in the dispersion kernel."""
         self._check(self._L.bh_engine_set_swd_group(self._h, int(lanes_per_model)))
+
+    def set_typical_layers(self, nlay):
+        """Hint for device-resident batches: typical layer count (0 = unknown)."""
+        self._check(self._L.bh_engine_set_typical_layers(self._h, int(nlay)))
 
     def set_swd_lookahead(self, trials_per_round):
         """0 = automatic; 1..12 trial phase velocities per round of the dispersion root search."""

@@ -83,6 +83,11 @@ int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
  * lanes, the velocities the search will most probably ask for next and hands them over if and only
  * if it does.  Results do not depend on it. */
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
+/* Tuning hint for BH_DEVICE calls: the typical number of layers (incl. the half-space) of the models in
+ * the batches to come, when it is well below Lmax (transdimensional chains: capacity 21, typically 5-7).
+ * The lanes-per-model choice is sized for it; 0 = unknown (Lmax is used).  BH_HOST calls look at nlay
+ * themselves.  Results do not depend on it. */
+int bh_engine_set_typical_layers(bh_engine *e, int nlay);
 /* The engine's own stream as a hipStream_t cast to void*. */
 void *bh_engine_stream(bh_engine *e);
 /* Block until everything enqueued on the engine's stream has finished. */
