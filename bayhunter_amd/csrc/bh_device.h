@@ -59,7 +59,7 @@ struct SwdKernelArgs {
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
 // perm[0..B) = model indices sorted by layer count, deepest first: wavefronts then hold models of (nearly)
 // one depth -- no masked layers, and the long-running deep models start first.  Results do not depend on it.
-void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, hipStream_t stream);
+void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, int Lcut, int32_t *split, hipStream_t stream);
 size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
 
 // group kernel: G lanes per model, all dispersion targets of a call in one launch
@@ -77,13 +77,22 @@ struct SwdMultiArgs {
     int B, Lmax, ntargets;
     const int32_t *nlay;
     const int32_t *perm; // optional, as in SwdKernelArgs
+    // Two classes of models in processing order: [0, split[0]) have more than `Lcut` layers ("deep"),
+    // the rest at most Lcut.  Each class gets its own launch with LDS rows for its depth, so that a
+    // batch whose array capacity (Lmax) is far above its typical depth still packs many models per
+    // wavefront.  Both classes run in ONE launch (blockIdx.z = class) with the same LDS budget per
+    // wavefront: the deep class simply takes fewer models per wavefront (more lanes per model).
+    // split == nullptr: one class (index 1), rows = Lmax.  rows[] / lanes[] are set by the launcher.
+    const int32_t *split;
+    int Lcut;
+    int rows[2], lanes[2]; // per class (0 = deep, 1 = the rest): LDS rows per model, lanes per model (G)
     unsigned long long *neval;
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
 double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
-void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream); // look-ahead per target in a.t[i].look
+int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream); // look-ahead per target in a.t[i].look; 0 ok, -1 too deep for LDS
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

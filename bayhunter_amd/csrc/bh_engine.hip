@@ -291,19 +291,20 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
-    while (G > 1 && G < 64 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) G += 1; // fewer models per wave
-    if (G > 1 && bh_swd_group_lds_bytes(G, 1, Lmax, kmax, maxmode) > lds_cap) return fail(e, BH_EINVAL, "model too deep for LDS");
-    if (G > 1)
-        for (int t = 0; t < nlive; ++t)
-            while (look[t] > 1 && (G * look[t] > 64 || bh_swd_group_lds_bytes(G, look[t], Lmax, kmax, maxmode) > lds_cap)) look[t] -= 1;
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
     // processing order: deepest models first, wavefronts of (nearly) one depth
-    const int32_t *perm = nullptr;
+    const int32_t *perm = nullptr, *split = nullptr;
+    int Lcut = Lmax;
     if (B > 1 && !e->no_order) {
-        if ((rc = ensure(e, e->perm, (size_t)B * sizeof(int32_t)))) return rc;
-        bh_launch_order(B, m.nlay, (int32_t *)e->perm.p, st);
-        perm = (const int32_t *)e->perm.p;
+        if ((rc = ensure(e, e->perm, ((size_t)B + 4) * sizeof(int32_t)))) return rc;
+        int32_t *p = (int32_t *)e->perm.p;
+        // LDS rows for the bulk of the batch: its typical depth plus a margin; deeper models get their own launch
+        const int typ = m.typ_layers > 0 ? m.typ_layers : e->hint_layers;
+        if (typ > 0 && typ + 2 < Lmax) Lcut = typ + 2;
+        bh_launch_order(B, m.nlay, p + 4, Lcut, p, st);
+        perm = p + 4;
+        split = (Lcut < Lmax) ? p : nullptr;
     }
     if (G <= 1) {
         for (int j = 0; j < njobs; ++j) {
@@ -326,6 +327,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     SwdMultiArgs a{};
     a.B = B; a.Lmax = Lmax; a.ntargets = 0; a.nlay = m.nlay; a.neval = counter; a.perm = perm;
+    a.split = split; a.Lcut = Lcut;
     for (int j = 0; j < njobs; ++j) {
         const SwdJob &J = jobs[j];
         if (J.K == 0) continue;
@@ -343,8 +345,9 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
     }
     ev_begin(e, 0, st);
-    bh_launch_swd_group(a, G, st);
+    const int lrc = bh_launch_swd_group(a, G, st);
     ev_end(e, 0, st);
+    if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
 }

@@ -1072,9 +1072,11 @@ __device__ __forceinline__ void wave_sync()
 
 __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
-    const int G = Gflags & 0xff;
+    const int cls = (A.split != nullptr) ? (int)blockIdx.z : 1; // 0 = the deep models of a ragged batch, 1 = the rest
+    const int G = A.lanes[cls];
     const SwdTarget T = A.t[blockIdx.y];
-    const int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
+    int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
+    while (J > 1 && G * J > BH_WAVE) --J;
     // Love only: further trials INSIDE a lane group.  Its recursion is scalar (every lane of the group
     // would repeat it), so lane l runs trial l mod JL instead; only the layer terms cost JL passes.
     const int JL = (T.iwave == 1 && T.inlook > 1) ? T.inlook : 1;
@@ -1085,19 +1087,27 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     const int wave = threadIdx.x / BH_WAVE;
     const int wid = blockIdx.x * GROUP_WPB + wave; // wavefront index inside this target's row of the grid
     // the workgroup's shared copy of the libm tables, then one private region per wavefront
+    // this launch's range of the processing order (see SwdMultiArgs::split)
+    int lo = 0, hi = A.B;
+    if (A.split != nullptr) {
+        const int ndeep = A.split[0];
+        if (cls == 0) hi = ndeep;
+        else lo = ndeep;
+    }
+    if (lo + (int)blockIdx.x * GROUP_WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
     const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * GROUP_WPB);
     __syncthreads();
-    if (wid * MPW >= A.B) return; // the grid is sized for the target with the fewest models per wave
+    if (lo + wid * MPW >= hi) return;
     unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
     const bool spare = lane >= MPW * LPM;
     const int g = spare ? 0 : lane / LPM;        // model slot inside the wave
     const int rr = spare ? 0 : (lane % LPM) / G; // which candidate this lane's group evaluates
     const int li = spare ? 0 : lane % G;         // this lane's index inside its group
     const int slot = g * J + rr;                 // group index inside the wave
-    const int sidx = wid * MPW + g; // position in the processing order
-    const bool valid = sidx < A.B;
+    const int sidx = lo + wid * MPW + g; // position in the processing order
+    const bool valid = sidx < hi;
     const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
-    const int Lmax = A.Lmax;
+    const int Lmax = A.rows[cls]; // LDS rows per model of this class (>= every layer count it meets)
     const int K = T.K;
     const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
 
@@ -1115,10 +1125,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     // layer-major input), binary32 rounding like the f2py boundary
     for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
         const int l = idx / MPW, mg = idx % MPW;
-        const int sb = wid * MPW + mg;
-        const int b = sb < A.B ? (A.perm ? A.perm[sb] : sb) : 0;
+        const int sb = lo + wid * MPW + mg;
+        const int b = sb < hi ? (A.perm ? A.perm[sb] : sb) : 0;
         float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
-        if (sb < A.B && l < A.nlay[b]) {
+        if (sb < hi && l < A.nlay[b]) {
             const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
             fd = (float)T.h[o];
             fa = (float)T.vp[o];
@@ -1399,7 +1409,7 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 }
 
 // ---- processing order: models by layer count, deepest first (counting sort, one workgroup) -------------
-__global__ __launch_bounds__(1024) void order_kernel(int B, const int32_t *nlay, int32_t *perm)
+__global__ __launch_bounds__(1024) void order_kernel(int B, const int32_t *nlay, int32_t *perm, int Lcut, int32_t *split)
 {
     __shared__ int bin[BH_MAX_LAYERS + 2];
     const int tid = threadIdx.x;
@@ -1417,7 +1427,9 @@ __global__ __launch_bounds__(1024) void order_kernel(int B, const int32_t *nlay,
             const int c = bin[n];
             bin[n] = acc;
             acc += c;
+            if (n == Lcut + 1 && split != nullptr) split[0] = acc; // models with more than Lcut layers come first
         }
+        if (split != nullptr && Lcut + 1 > BH_MAX_LAYERS + 1) split[0] = 0;
     }
     __syncthreads();
     for (int b = tid; b < B; b += 1024) {
@@ -1509,9 +1521,9 @@ __global__ void interp_kernel(int B, int K0, const double *x0, const double *y0,
 
 } // namespace
 
-void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, hipStream_t stream)
+void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, int Lcut, int32_t *split, hipStream_t stream)
 {
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, B, nlay, perm);
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, B, nlay, perm, Lcut, split);
 }
 
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
@@ -1644,25 +1656,87 @@ size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
     return LIBM_TAB_PAD + GROUP_WPB * ((group_lds_bytes(G, J, Lmax, Kmax, maxmode) + 15) & ~(size_t)15);
 }
 
-void bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream)
+// A wavefront's LDS region small enough for 8 wavefronts (4 workgroups) per CU of 160 KB
+constexpr size_t WAVE_LDS_TARGET = (160 * 1024 / 4 - LIBM_TAB_PAD) / GROUP_WPB;
+constexpr size_t WG_LDS_CAP = 64 * 1024;
+
+int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
 {
     int kmax = 0, maxmode = 1;
-    for (int t = 0; t < a.ntargets; ++t) {
-        kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
-        maxmode = a.t[t].mode > maxmode ? a.t[t].mode : maxmode;
+    for (int t = 0; t < a0.ntargets; ++t) {
+        kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
+        maxmode = a0.t[t].mode > maxmode ? a0.t[t].mode : maxmode;
     }
-    int nwaves = 1;
-    size_t wave_lds = 0;
-    for (int t = 0; t < a.ntargets; ++t) {
-        const int J = a.t[t].look > 1 ? a.t[t].look : 1;
-        const int mpw = BH_WAVE / (G * J);
-        const int nx = (a.B + mpw - 1) / mpw;
-        nwaves = nx > nwaves ? nx : nwaves;
-        const size_t l = (group_lds_bytes(G, J, a.Lmax, kmax, maxmode) + 15) & ~(size_t)15;
-        wave_lds = l > wave_lds ? l : wave_lds;
-    }
-    const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets);
-    const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
     static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
-    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, G | redundant, (int)wave_lds);
+    SwdMultiArgs a = a0;
+    const bool two = a0.split != nullptr && a0.Lcut < a0.Lmax;
+    if (!two) a.split = nullptr;
+    size_t wave_lds = 0;
+    int nwaves = 1;
+    for (int cls = two ? 0 : 1; cls <= 1; ++cls) {
+        const int rows = (two && cls == 1) ? a0.Lcut : a0.Lmax;
+        // fewer models per wavefront (more lanes per model) until the parked layers fit: first the
+        // residency target, at the latest the 64 KB a workgroup may ask for
+        int G = G0;
+        auto trials = [&](int g, int t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && g * J > BH_WAVE) --J;
+            return J;
+        };
+        auto wave_bytes = [&](int g) {
+            size_t w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const size_t l = (group_lds_bytes(g, trials(g, t), rows, kmax, maxmode) + 15) & ~(size_t)15;
+                w = l > w ? l : w;
+            }
+            return w;
+        };
+        auto waves = [&](int g) {
+            long w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                w += (a.B + mpw - 1) / mpw;
+            }
+            return w;
+        };
+        auto most_models = [&](int g) {
+            int m = 1;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                m = mpw > m ? mpw : m;
+            }
+            return m;
+        };
+        // a batch that leaves half the chip idle anyway: one lane per layer of the deepest model of the
+        // class (a single pass over the layers) instead of lanes for the typical depth
+        // (only where that costs neither look-ahead nor residency)
+        for (int Gwide = rows - 1 > 16 ? 16 : rows - 1; Gwide > G; --Gwide) {
+            bool same = waves(Gwide) <= PLAN_SLOTS / 8;
+            for (int t = 0; t < a.ntargets; ++t) same = same && trials(Gwide, t) == trials(G, t);
+            if (same) {
+                G = Gwide;
+                break;
+            }
+        }
+        while (most_models(G) > 1 && wave_bytes(G) > WAVE_LDS_TARGET) G += 1;
+        while (G < BH_WAVE && LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) G += 1;
+        if (LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) return -1;
+        a.rows[cls] = rows;
+        a.lanes[cls] = G;
+        const size_t wb = wave_bytes(G);
+        wave_lds = wb > wave_lds ? wb : wave_lds;
+        for (int t = 0; t < a.ntargets; ++t) {
+            const int mpw = BH_WAVE / (G * trials(G, t));
+            const int nx = (a.B + mpw - 1) / mpw; // worst case: the whole batch is in this class
+            nwaves = nx > nwaves ? nx : nwaves;
+        }
+    }
+    if (!two) {
+        a.rows[0] = a.rows[1];
+        a.lanes[0] = a.lanes[1];
+    }
+    const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
+    const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
+    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+    return 0;
 }
