@@ -72,3 +72,36 @@ def test_device_api_equals_host_api(engine, batch):
     torch.cuda.synchronize()
     v, e = engine.swd_batch(nlay, h, vp, vs, rho, SWD_PERIODS, 2, 0)
     assert np.array_equal(d_vel.cpu().numpy(), v) and np.array_equal(d_err.cpu().numpy(), e)
+
+
+@pytest.mark.parametrize("hint", [0, 2, 4, 7, 12, 40])
+def test_ragged_device_batch_any_depth_hint(engine, oracle, hint):
+    """A transdimensional batch (2..21 layers, mostly shallow) through the device API with the caller's
+    typical-depth hint right, wrong or absent: the hint only sizes lane groups and LDS rows (processing
+    order by depth, two depth classes in one launch) -- velocities and flags are those of the oracle."""
+    import torch
+    rs = np.random.RandomState(17)
+    Bn, L = 1500, 21
+    nlay, h, vp, vs, rho = synth_models(rs, Bn, L, lvz_frac=0.2, ragged=True)
+    shallow = rs.rand(Bn) < 0.8                           # 80 % of the models keep at most 7 layers
+    for b in np.flatnonzero(shallow):
+        n = min(int(nlay[b]), int(rs.randint(2, 8)))
+        nlay[b] = n
+        h[n - 1:, b] = 0.0
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    per = np.linspace(2, 50, 20)
+    d = [t(a) for a in (nlay, h, vp, vs, rho, per)]
+    d_vel = torch.zeros((Bn, per.size), dtype=torch.float64, device=dev)
+    d_err = torch.zeros(Bn, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        engine.set_typical_layers(hint)
+        for iwave, igr in ((2, 0), (1, 1)):
+            engine.swd_batch_dev(Bn, L, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                 Bn, 1, per.size, d[5].data_ptr(), iwave, igr, d_vel.data_ptr(), d_err.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
+            assert np.array_equal(d_err.cpu().numpy(), oe) and np.array_equal(d_vel.cpu().numpy(), ov), (hint, iwave, igr)
+    finally:
+        engine.set_typical_layers(0)
