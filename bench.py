@@ -13,6 +13,11 @@ Workloads (BASELINE.json configs):
      uncorrelated noise law.
   c3: c2 + P receiver function (Gauss a = 2.5, 1024 kept samples @ 20 Hz -> nsamp 2048,
      p = 6.4 s/deg), exponential-correlated noise law on the RF.
+  c4 / c5 (BASELINE configs[3] / [4], the CALLER of the hot path): device-resident transdimensional
+     chains (up to 20 layers) on the joint SWD + P-RF targets of c3; a "step" is one lock-step iteration
+     of all chains = one forward+logL evaluation per chain.  c4: 8 chains per GPU.  c5: 64 chains per GPU
+     at one temperature of an 8-rung ladder per rank, temperature exchange every 100 iterations (the
+     all-gather of 3 floats per chain is the only collective).  Not the headline metric.
   c2g / c3g: the "second runs" of SURVEY.md 8(d) -- c2 with GROUP velocities; c3 with the Gauss law
      (fixed r = 0.92, rcond = 1e-6: the dense quadratic form on the FP64 matrix cores).
 N > 1: one process per GPU (torchrun), independent batches per rank, no data-path collective
@@ -123,6 +128,68 @@ def cpu_baseline(spec, batch, noise, workload):
                       % (n, workload, best, sorted(probe_rates), ncpu, 1.0 / per_model)}
 
 
+def run_chains(args, eng, rank, world, dist, dev):
+    """c4 / c5: device-resident chains (bayhunter_amd.device_chains) on the c3 targets."""
+    import bayhunter_amd as bh
+    from bayhunter_amd.device_chains import DeviceChains
+    from bayhunter_amd.synth import true_model, SWD_PERIODS, RF_TIME, SEED
+    C = args.chains or (8 if args.workload == "c4" else 64)
+    nlay, h, vp, vs, rho = true_model(args.layers)
+    nrs = np.random.RandomState(SEED + 2)
+    ys = {}
+    for name, iwave in (("r", 2), ("l", 1)):
+        y, err = eng.swd_batch(nlay, h, vp, vs, rho, SWD_PERIODS, iwave, 0)
+        ys[name] = y[0] + nrs.normal(0, 0.012, SWD_PERIODS.size)
+    yrf = eng.rf_batch(nlay, h, vp, vs, rho, 6.4, 2.5, 2048, 20.0, 5.0, 0, RF_TIME.size)[0] + nrs.normal(0, 0.005, RF_TIME.size)
+    t3 = bh.PReceiverFunction(RF_TIME, yrf)
+    t3.moddata.plugin.set_modelparams(gauss=2.5, p=6.4)
+    jt = bh.JointTarget([bh.RayleighDispersionPhase(SWD_PERIODS, ys["r"]), bh.LoveDispersionPhase(SWD_PERIODS, ys["l"]), t3], engine=eng)
+    priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), rfnoise_corr=(0.35, 0.75), rfnoise_sigma=(1e-5, 0.05),
+                  swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1))
+    init = dict(iter_burnin=args.warmup, iter_main=args.steps, acceptance=(40, 45), thickmin=0.1, lvz=None, hvz=None, rcond=None,
+                maxmodels=max(1, args.steps // 100))
+    kw = {}
+    if args.workload == "c5":   # one temperature per rank (geometric ladder 1..30 over 8 rungs), ladders = chains
+        ladder = 1.0 / np.geomspace(1.0, 30.0, 8)
+        kw = dict(betas=np.full(C, ladder[rank % 8]), ladder=np.arange(C), swap_every=100, dist=dist if world > 1 else None)
+    dc = DeviceChains(jt, C, init, priors, seed=20260927 + rank, device=dev.index, **kw)
+    import torch
+    def fence():
+        eng.synchronize(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    while dc.iiter < 0:            # burn-in = warm-up, untimed
+        dc.iterate()
+    fence()
+    eng.set_instrumentation(timing=True, counting=False)
+    eng.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    while dc.iiter < dc.iter_phase2:
+        dc.iterate()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ncalls, tot_ms, fam_ms = eng.timing_collect()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        st = dc.state_host()
+        out = {"metric": "forward-model+logL evals/sec (one per chain and iteration of device-resident transdimensional chains)",
+               "value": world * C * args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": {"c4": "BASELINE configs[3]: independent chains sharded per GPU, joint Rayleigh+Love+P-RF, up to 20 layers",
+                                       "c5": "BASELINE configs[4]: parallel tempering, one temperature of an 8-rung ladder per rank, exchange "
+                                             "every 100 iterations, joint Rayleigh+Love+P-RF, up to 20 layers"}[args.workload],
+                          "chains_per_gpu": C, "mean_layers_at_end": float(st["n"].mean()), "accepted_swaps": int(dc.nswaps),
+                          "parallelism": "chains sharded per GPU; c5: one small all-gather per exchange"},
+               "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
+               "median_logL": float(np.median(st["like"]))}
+        print(json.dumps(out))
+
+
 def pmc_traffic(workload, B):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be read
     from inside the timed run: they come from the separate rocprofv3 --pmc passes of the same command
@@ -142,7 +209,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c2g", "c3g"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c2g", "c3g", "c4", "c5"])
+    ap.add_argument("--chains", type=int, default=0, help="c4/c5: chains per GPU (default 8 / 64)")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,6 +242,12 @@ def main():
 
     from bayhunter_amd import engine as E
     eng = E.Engine(local_rank)
+    if args.workload in ("c4", "c5"):
+        run_chains(args, eng, rank, world, dist, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     B, L = args.batch, args.layers
     spec, batches, noise, truth, nrs = build_workload(args.workload, B, L, seed=20260927 + 1000 * rank)
     observed_data(eng, spec, truth, nrs)
