@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the dispersion kernels against the CPU oracle: random batch sizes, depths,
+raggedness, periods, wave/velocity types, modes, earth flattening, lane mappings, look-ahead and depth
+hints (dev tool; the fixed cases live in tests/)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from bayhunter_amd import engine as E
+from bayhunter_amd.synth import synth_models
+from oracle import oracle as O
+
+eng = E.Engine(0)
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+dev = torch.device("cuda:0")
+bad = 0
+t0 = time.time()
+for it in range(ncfg):
+    B = int(rs.choice([1, 2, 7, 33, 64, 65, 200, 700, 1500]))
+    L = int(rs.choice([2, 3, 5, 8, 10, 13, 17, 21, 30]))
+    ragged = bool(rs.rand() < 0.6) and L > 2
+    nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=float(rs.choice([0.0, 0.2, 0.5])), ragged=ragged)
+    if L > 10:
+        h[:-1] *= 10.0 / L
+    K = int(rs.choice([1, 5, 21, 30, 60]))
+    per = np.sort(rs.uniform(1.0, 80.0, K)) if rs.rand() < 0.5 else np.linspace(2, 60, K)
+    iwave, igr = int(rs.choice([1, 2])), int(rs.choice([0, 1]))
+    mode = int(rs.choice([1, 1, 1, 2, 3]))
+    flsph = int(rs.rand() < 0.25)
+    G = int(rs.choice([0, 0, 0, 1, 3, 5, 9, 12, 16, 21]))
+    J = int(rs.choice([0, 0, 1, 2, 3, 4, 7]))
+    hint = int(rs.choice([0, 0, 3, 6, 12]))
+    eng.set_swd_group(G); eng.set_swd_lookahead(J); eng.set_typical_layers(hint)
+    ov, oe, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
+    if rs.rand() < 0.5:
+        v, e = eng.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, mode=mode, flsph=flsph)
+    else:
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d = [t(a) for a in (nlay, h, vp, vs, rho, per)]
+        dv = torch.zeros((B, K), dtype=torch.float64, device=dev); de = torch.zeros(B, dtype=torch.int32, device=dev)
+        eng.swd_batch_dev(B, L, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), B, 1, K,
+                          d[5].data_ptr(), iwave, igr, dv.data_ptr(), de.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                          mode=mode, flsph=flsph)
+        torch.cuda.synchronize()
+        v, e = dv.cpu().numpy(), de.cpu().numpy()
+    ok = np.array_equal(e, oe) and np.array_equal(v, ov)
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(B=B, L=L, ragged=ragged, K=K, iwave=iwave, igr=igr, mode=mode, flsph=flsph, G=G, J=J, hint=hint),
+              "err diff", int((e != oe).sum()), "vel diff", int((v != ov).sum()), flush=True)
+print("%d configurations, %d mismatches, %.0f s" % (ncfg, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
