@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Randomised check of the fused forward + likelihood call against the CPU oracle: random target sets
+(dispersion types, P/SV receiver functions), noise laws (uncorrelated, scaled errors, exponential), noise
+values, ragged batches (dev tool; the fixed cases live in tests/)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bayhunter_amd import engine as E
+from bayhunter_amd.synth import synth_models
+from oracle import oracle as O
+
+eng = E.Engine(0)
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad, worst = 0, 0.0
+for it in range(ncfg):
+    B = int(rs.choice([1, 9, 64, 130, 400]))
+    L = int(rs.choice([3, 6, 10, 15, 21]))
+    nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.2, ragged=bool(rs.rand() < 0.5))
+    if L > 10:
+        h[:-1] *= 10.0 / L
+    nt = int(rs.randint(1, 5))
+    spec = []
+    for t in range(nt):
+        if rs.rand() < 0.65:
+            K = int(rs.choice([7, 21, 30, 60]))
+            per = np.linspace(2, 50, K)
+            law = int(rs.choice([E.LAW_NOCORR, E.LAW_NOCORR_SCALED, E.LAW_EXP]))
+            s = dict(kind=E.TARGET_SWD, law=law, n=K, x=per, iwave=int(rs.choice([1, 2])), igr=int(rs.choice([0, 1])),
+                     yobs=3.0 + 0.02 * per + rs.normal(0, 0.02, K))
+        else:
+            nsamp = int(rs.choice([256, 512, 1024])); n = int(nsamp // 2 - rs.randint(0, 20))
+            law = int(rs.choice([E.LAW_NOCORR, E.LAW_NOCORR_SCALED, E.LAW_EXP]))
+            s = dict(kind=E.TARGET_RF, law=law, n=n, waveno=int(rs.choice([0, 1])), nsamp=nsamp, p=float(rs.uniform(4, 8)),
+                     gauss=float(rs.choice([1.0, 2.5])), fsamp=float(rs.choice([10.0, 20.0])), tshift=5.0, yobs=rs.normal(0, 0.05, n))
+        if s["law"] == E.LAW_NOCORR_SCALED:
+            s["yerr"] = rs.uniform(0.5, 2.0, s["n"])
+        spec.append(s)
+    noise = np.zeros((B, 2 * nt))
+    for t, s in enumerate(spec):
+        noise[:, 2 * t] = rs.uniform(0.2, 0.9, B) if s["law"] == E.LAW_EXP else 0.0
+        noise[:, 2 * t + 1] = rs.uniform(0.005, 0.1, B)
+    eng.set_targets(spec)
+    logL, misf, err = eng.evaluate_batch(nlay, h, vp, vs, noise)
+    oL, om = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
+    relL = np.max(np.abs(logL - oL) / np.maximum(1.0, np.abs(oL)))
+    relm = np.max(np.abs(misf - om) / np.maximum(1e-30, np.abs(om)))
+    worst = max(worst, relL, relm)
+    if not (relL <= 1e-8 and relm <= 1e-8):
+        bad += 1
+        print("MISMATCH", it, dict(B=B, L=L, nt=nt), [(s["kind"], s["law"], s["n"]) for s in spec], relL, relm, flush=True)
+print("%d configurations, %d beyond 1e-8, worst relative difference %.2e" % (ncfg, bad, worst))
+sys.exit(1 if bad else 0)
