@@ -1,31 +1,33 @@
 // bayhunter_amd/csrc/swd_kernel.hip -- Rayleigh/Love phase & group dispersion on gfx950.
 //
 // Replaces the reference's surfdisp96 (src/extensions/surfdisp96.f:55-360 and the routines it
-// calls) for a batch of models.  Mapping: ONE WAVEFRONT LANE = ONE CANDIDATE MODEL, one
-// 64-lane wavefront per workgroup, grid = ceil(B/64).  No MFMA: the work is a scalar FP64
-// recurrence (5-vector x 5x5 compound matrix per layer for Rayleigh, 2-vector for Love) inside
-// a data-dependent root search.
+// calls) for a batch of models.  No MFMA: the work is a scalar FP64 recurrence (5-vector x 5x5
+// compound matrix per layer for Rayleigh, 2-vector for Love) inside a data-dependent root search.
+// Two kernels return identical bits:
+//   swd_kernel<1|2>     one wavefront lane = one model (batches that fill the chip by themselves);
+//   swd_group_kernel    G lanes = one model, J such groups evaluating the trial velocities the search
+//                       will most probably ask for next (everything smaller) -- see the block comment
+//                       above it; bh_swd_plan picks the mapping and the look-ahead per launch.
 //
 // Design points
 //   * EVALUATION-SYNCHRONOUS STATE MACHINE.  The reference's control flow is
 //       for period: bracket-step until sign change; refine (bisection / inverse Neville)
 //     and the number of secular-function evaluations differs per model and per period.  A
 //     literal SIMT translation would make every lane wait for the slowest lane in every inner
-//     loop.  Here each lane keeps an explicit search state (period index, which root, bracket,
+//     loop.  Here each model keeps an explicit search state (period index, which root, bracket,
 //     Neville table, continuation tag) and the wavefront's loop body is exactly ONE secular
-//     evaluation for all lanes followed by a short per-lane state transition.  Lanes drift
-//     apart in period index freely; the wave ends when its slowest lane has used up its own
-//     total, not the sum of per-period maxima.
+//     evaluation for all its models followed by a state transition.  Models drift apart in
+//     period index freely; the wave ends when its slowest model has used up its own total, not
+//     the sum of per-period maxima.
 //   * The model (thickness, vp, vs, rho), rounded to binary32 as the f2py boundary of the
-//     reference does, is staged once through LDS in [array][layer][lane]
-//     order (bank-conflict free: lane = bank) from coalesced global loads of the layer-major
-//     (vp, vs, rho, h) arrays; the per-lane Neville tables x[11], y[11] and the period table
-//     live in LDS as well.
+//     reference does, is staged once through LDS from coalesced global loads
+//     of the layer-major (vp, vs, rho, h) arrays; the Neville tables x[11], y[11] and the period
+//     table live in LDS as well.
 //   * Rounding points, the search sequence (start value, 0.005 km/s stepping, direction logic,
-//     Neville/bisection decisions, the 1e-6 stop test, which point is returned) and the
-//     binary32 arithmetic of the start value and of the group-velocity formula follow the
-//     reference exactly; only the device sin/cos/exp differ from the host
-//     libm in the last ulp.
+//     Neville/bisection decisions, the 1e-6 stop test, which point is returned), the binary32
+//     arithmetic of the start value and of the group-velocity formula follow the reference exactly
+//     (SURVEY.md App. A), and sin/cos/exp (and log/powf of the flattening transform) are
+//     restatements of the host libm the reference links (bh_libm.h): results are bit-identical.
 #include "../../include/bh_engine.h"
 #include "bh_device.h"
 #include <cstdlib>
@@ -944,9 +946,10 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
 // Every floating-point operation and its order are those of kernel 1: the kernels return
 // identical bits.  All dispersion targets of a call go into one launch (blockIdx.y = target),
 // so Rayleigh and Love wavefronts share the chip.
-// The workgroup is ONE wavefront: LDS operations of a wavefront execute in order, so the
-// __syncthreads() below only pin the compiler's ordering (the barrier instruction itself is
-// elided for a single-wave workgroup).
+// A workgroup is GROUP_WPB independent wavefronts that only share the LDS copy of the libm tables;
+// after start-up there is no barrier: LDS operations of a wavefront execute in order, wave_sync()
+// only pins the compiler's ordering.  Look-ahead, Love's in-group trials, the processing order and the
+// two depth classes of ragged batches are described at their code.
 // =================================================================================================
 constexpr int CA_STRIDE = 26;
 constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used): up to 4 trials share a row
