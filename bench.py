@@ -26,8 +26,10 @@ N > 1: one process per GPU (torchrun), independent batches per rank, no data-pat
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the Rayleigh dispersion
 kernel `swd_group_kernel`, Rayleigh + Love wavefronts in one launch): achieved = algorithmic bytes per launch / its average launch duration
 measured with HIP events on the launch stream during the timed region.  `cpu_baseline` is the
-oracle (the bit-exact CPU restatement of the reference, kind "port") timed on this box's host
-cores on a bounded sample of the same workload.
+reference's own Fortran / C++ (oracle/_ref, built from /root/reference where it exists; kind "reference")
+driven by a process pool on this box's host cores on a bounded sample of the same workload;
+`cpu_baseline_port` is the oracle (the bit-exact CPU restatement, OpenMP) on the same sample -- the two
+agree within a few per cent.  Without oracle/_ref the port is the baseline (kind "port").
 """
 import argparse
 import json
@@ -93,6 +95,72 @@ def observed_data(eng, spec, truth, nrs):
             y = eng.rf_batch(nlay, h, vp, vs, rho, s["p"], s["gauss"], s["nsamp"], s["fsamp"], s["tshift"],
                              s["waveno"], s["n"])
             s["yobs"] = y[0] + nrs.normal(0, 0.005, s["n"])
+
+
+_REF_JOB = None   # (nlay, h, vp, vs, rho [model-major], spec, noise): inherited by forked workers
+
+
+def _ref_slice(bounds):
+    """One worker process: the COMPILED REFERENCE (oracle/_ref: surfdisp96.f, rfmini) on models lo..hi of
+    the job, forward models through the reference's own code, likelihood through the dense restatement
+    of Targets.py (oracle/like_oracle.c).  The Fortran keeps SAVE state: one process per worker."""
+    from oracle import refshim as R, oracle as O
+    from bayhunter_amd import engine as E
+    nlay, ht, vpt, vst, rhot, spec, noise = _REF_JOB
+    lo, hi = bounds
+    acc = 0.0
+    for b in range(lo, hi):
+        i = b % nlay.size
+        L = int(nlay[i])
+        for t, s in enumerate(spec):
+            if s["kind"] == E.TARGET_SWD:
+                thk = np.zeros(100, np.float32); a = np.zeros(100, np.float32); bb = np.zeros(100, np.float32); r = np.zeros(100, np.float32)
+                thk[:L], a[:L], bb[:L], r[:L] = ht[i, :L], vpt[i, :L], vst[i, :L], rhot[i, :L]
+                per = np.zeros(60); per[:s["n"]] = s["x"]
+                cg = np.zeros(60)
+                R.surfdisp96(thk, a, bb, r, L, 0, s["iwave"], 1, s["igr"], s["n"], per, cg)
+                ymod = cg[:s["n"]]
+            else:
+                z = np.concatenate(([0.0], np.cumsum(ht[i, :L - 1])))
+                kap = vpt[i, 0] / vst[i, 0]
+                rf = R.synrf(z, vpt[i, :L].copy(), vst[i, :L].copy(), rhot[i, :L].copy(), np.full(L, 500.0), np.full(L, 225.0),
+                             s["p"], s["gauss"], s["nsamp"], s["fsamp"], s["tshift"], vst[i, 0], (2 - kap ** 2) / (2 - 2 * kap ** 2), "P")
+                ymod = np.asarray(rf[-1] if isinstance(rf, tuple) else rf)[:s["n"]]
+            acc += float(O.loglike_dense(s["law"], ymod, s["yobs"], noise[i, 2 * t], noise[i, 2 * t + 1], yerr=s.get("yerr")))
+    return acc
+
+
+def cpu_baseline_reference(spec, batch, noise, workload):
+    """The compiled reference on this box's host cores (process pool), bounded to ~20 s of CPU work."""
+    global _REF_JOB
+    import multiprocessing as mp
+    nlay, h, vp, vs, rho = batch
+    _REF_JOB = (nlay, np.ascontiguousarray(h.T), np.ascontiguousarray(vp.T), np.ascontiguousarray(vs.T),
+                np.ascontiguousarray(rho.T), spec, noise)
+    t0 = time.perf_counter()
+    _ref_slice((0, 8))
+    per_model = (time.perf_counter() - t0) / 8
+    ncpu = os.cpu_count() or 1
+    ctx = mp.get_context("fork")
+
+    def rate(nproc, n):
+        per = max(1, n // nproc)
+        bounds = [(k * per, (k + 1) * per) for k in range(nproc)]
+        with ctx.Pool(nproc) as pool:
+            pool.map(_ref_slice, [(0, 1)] * nproc)            # workers up, libraries loaded
+            t0 = time.perf_counter()
+            pool.map(_ref_slice, bounds)
+            return per * nproc / (time.perf_counter() - t0)
+
+    cands = [c for c in sorted({8, 16, 32, 64, max(1, ncpu // 2), ncpu}) if c <= ncpu]
+    probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
+    best = max(probe, key=probe.get)
+    n = int(max(4 * best, min(20.0 / per_model, 8.0 * probe[best])))
+    value = rate(best, n)
+    return {"value": value, "unit": "evals/s", "cores": best, "kind": "reference",
+            "sample": "%d models of the %s batch: forward models by the reference's own surfdisp96.f / rfmini compiled with "
+                      "amdflang / g++ -O2 (oracle/_ref), dense likelihood as in Targets.py; %d worker processes (best of %s; "
+                      "os.cpu_count() = %d); 1-process rate %.1f evals/s" % (n, workload, best, sorted(probe), ncpu, 1.0 / per_model)}
 
 
 def cpu_baseline(spec, batch, noise, workload):
@@ -344,6 +412,16 @@ def main():
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (ex,)}
+            try:   # the reference's own compiled code, where oracle/_ref was built (it travels with the repo)
+                from oracle import refshim
+                if refshim.available() and args.workload in ("c2", "c3", "c2g"):
+                    # north_star: "next to the reference CPU Fortran path timed on the same box's host cores":
+                    # the reference's own compiled code is the baseline, the port is kept beside it
+                    ref = cpu_baseline_reference(spec, batches[0], noise, args.workload)
+                    out["cpu_baseline_port"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = ref
+            except Exception as ex:
+                out["cpu_baseline_reference_error"] = repr(ex)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
