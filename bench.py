@@ -97,7 +97,12 @@ def observed_data(eng, spec, truth, nrs):
             s["yobs"] = y[0] + nrs.normal(0, 0.005, s["n"])
 
 
-_REF_JOB = None   # (nlay, h, vp, vs, rho [model-major], spec, noise): inherited by forked workers
+_REF_JOB = None   # (nlay, h, vp, vs, rho [model-major], spec, noise) of a reference-baseline worker
+
+
+def _ref_init(job):
+    global _REF_JOB
+    _REF_JOB = job
 
 
 def _ref_slice(bounds):
@@ -137,22 +142,24 @@ def cpu_baseline_reference(spec, batch, noise, workload):
     nlay, h, vp, vs, rho = batch
     _REF_JOB = (nlay, np.ascontiguousarray(h.T), np.ascontiguousarray(vp.T), np.ascontiguousarray(vs.T),
                 np.ascontiguousarray(rho.T), spec, noise)
+    _ref_slice((0, 1))
     t0 = time.perf_counter()
     _ref_slice((0, 8))
     per_model = (time.perf_counter() - t0) / 8
     ncpu = os.cpu_count() or 1
-    ctx = mp.get_context("fork")
+    # fresh interpreters (no fork of a process that holds a HIP context and OpenMP threads)
+    ctx = mp.get_context("spawn")
 
     def rate(nproc, n):
         per = max(1, n // nproc)
         bounds = [(k * per, (k + 1) * per) for k in range(nproc)]
-        with ctx.Pool(nproc) as pool:
+        with ctx.Pool(nproc, initializer=_ref_init, initargs=(_REF_JOB,)) as pool:
             pool.map(_ref_slice, [(0, 1)] * nproc)            # workers up, libraries loaded
             t0 = time.perf_counter()
             pool.map(_ref_slice, bounds)
             return per * nproc / (time.perf_counter() - t0)
 
-    cands = [c for c in sorted({8, 16, 32, 64, max(1, ncpu // 2), ncpu}) if c <= ncpu]
+    cands = [c for c in (8, 16, 32, 64) if c <= ncpu] or [ncpu]
     probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
     best = max(probe, key=probe.get)
     n = int(max(4 * best, min(20.0 / per_model, 8.0 * probe[best])))
