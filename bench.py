@@ -150,24 +150,28 @@ def cpu_baseline_reference(spec, batch, noise, workload):
     # fresh interpreters (no fork of a process that holds a HIP context and OpenMP threads)
     ctx = mp.get_context("spawn")
 
-    def rate(nproc, n):
+    def rate(nproc, n, reps=1):
         per = max(1, n // nproc)
         bounds = [(k * per, (k + 1) * per) for k in range(nproc)]
         with ctx.Pool(nproc, initializer=_ref_init, initargs=(_REF_JOB,)) as pool:
             pool.map(_ref_slice, [(0, 1)] * nproc)            # workers up, libraries loaded
-            t0 = time.perf_counter()
-            pool.map(_ref_slice, bounds)
-            return per * nproc / (time.perf_counter() - t0)
+            best_dt = None
+            for _ in range(reps):                             # the box is shared: keep the least disturbed pass
+                t0 = time.perf_counter()
+                pool.map(_ref_slice, bounds, chunksize=1)
+                dt = time.perf_counter() - t0
+                best_dt = dt if best_dt is None else min(best_dt, dt)
+            return per * nproc / best_dt
 
     cands = [c for c in (8, 16, 32, 64) if c <= ncpu] or [ncpu]
     probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
     best = max(probe, key=probe.get)
     n = int(max(4 * best, min(20.0 / per_model, 8.0 * probe[best])))
-    value = rate(best, n)
+    value = rate(best, n, reps=3)
     return {"value": value, "unit": "evals/s", "cores": best, "kind": "reference",
             "sample": "%d models of the %s batch: forward models by the reference's own surfdisp96.f / rfmini compiled with "
                       "amdflang / g++ -O2 (oracle/_ref), dense likelihood as in Targets.py; %d worker processes (best of %s; "
-                      "os.cpu_count() = %d); 1-process rate %.1f evals/s" % (n, workload, best, sorted(probe), ncpu, 1.0 / per_model)}
+                      "os.cpu_count() = %d), best of 3 passes; 1-process rate %.1f evals/s" % (n, workload, best, sorted(probe), ncpu, 1.0 / per_model)}
 
 
 def cpu_baseline(spec, batch, noise, workload):
@@ -196,7 +200,7 @@ def cpu_baseline(spec, batch, noise, workload):
     probe_rates = {c: rate(c, max(64, int(0.4 * c / per_model / 8))) for c in cands}
     best = max(probe_rates, key=probe_rates.get)
     n = int(max(4 * best, min(20.0 / per_model, 8.0 * probe_rates[best])))   # ~20 s of CPU work, <= ~8 s wall
-    value = rate(best, n)
+    value = max(rate(best, n) for _ in range(3))                              # shared box: least disturbed pass
     return {"value": value, "unit": "evals/s", "cores": best, "kind": "port",
             "sample": "%d models of the %s batch, all targets + dense logL, OpenMP over models with %d threads "
                       "(best of %s; os.cpu_count() = %d); 1-thread rate %.1f evals/s"
