@@ -62,15 +62,18 @@ __device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, 
         return d;
     }
     Philox ph;
-    uint32_t r[4], q[4], t[4];
+    // every draw gets its own 64 bits of Philox output: draws of one iteration must be independent of
+    // each other (a normal deviate correlated with the choice of the move makes the walk drift)
+    uint32_t r[4], q[4], t[4], n[4];
     ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 0u, r);
     ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 1u, q);
     ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 2u, t);
+    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 3u, n);
     d.u_move = u01(r[0], r[1]); d.u_index = u01(r[2], r[3]);
     d.u_z = u01(q[0], q[1]); d.u_accept = u01(q[2], q[3]);
     d.u_noise = u01(t[0], t[1]);
-    const double a = 1.0 - u01(t[2], t[3]); // (0, 1]
-    const double bq = u01(r[0] ^ 0x9E3779B9u, q[1]);
+    const double a = 1.0 - u01(n[0], n[1]); // (0, 1]
+    const double bq = u01(n[2], n[3]);
     d.normal = sqrt(-2.0 * log(a)) * cospi(2.0 * bq); // Box-Muller
     return d;
 }

@@ -31,17 +31,17 @@ def _u01(hi, lo):
 def draws(seed, C, iiter):
     """-> [6, C]: u_move, u_index, u_z, u_accept, u_noise, normal for iteration `iiter`."""
     key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    ctr = np.zeros((3, C, 4), dtype=np.uint32)
+    ctr = np.zeros((4, C, 4), dtype=np.uint32)
     ctr[:, :, 0] = np.arange(C, dtype=np.uint32)
     ctr[:, :, 1] = np.uint32(iiter & 0xFFFFFFFF)
-    ctr[:, :, 2] = np.arange(3, dtype=np.uint32)[:, None]
-    r, q, t = philox4x32_10(ctr, key)
+    ctr[:, :, 2] = np.arange(4, dtype=np.uint32)[:, None]
+    r, q, t, n = philox4x32_10(ctr, key)
     out = np.zeros((6, C))
     out[0], out[1] = _u01(r[:, 0], r[:, 1]), _u01(r[:, 2], r[:, 3])
     out[2], out[3] = _u01(q[:, 0], q[:, 1]), _u01(q[:, 2], q[:, 3])
     out[4] = _u01(t[:, 0], t[:, 1])
-    a = 1.0 - _u01(t[:, 2], t[:, 3])
-    b = _u01(r[:, 0] ^ np.uint32(0x9E3779B9), q[:, 1])
+    a = 1.0 - _u01(n[:, 0], n[:, 1])
+    b = _u01(n[:, 2], n[:, 3])
     out[5] = np.sqrt(-2.0 * np.log(a)) * np.cos(2.0 * np.pi * b)
     return out
 
