@@ -11,6 +11,10 @@
 #include <stdint.h>
 
 #define BH_WAVE 64
+// debug counter block of the dispersion kernels: BH_COUNTER_WORDS counters + 4 words per traced wavefront
+#define BH_COUNTER_WORDS 16
+#define BH_TRACE_WAVES 16384
+#define BH_DEBUG_WORDS (BH_COUNTER_WORDS + 4 * BH_TRACE_WAVES)
 
 // ---- IEEE division with the denominator-only work factored out ----------------------------------
 // hipcc expands the f64 `a / b` to   d = div_scale(b), n = div_scale(a), r = rcp(d),
@@ -92,7 +96,10 @@ struct SwdMultiArgs {
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
 double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
-int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream); // look-ahead per target in a.t[i].look; 0 ok, -1 too deep for LDS
+int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
+// v2 of the group kernel: Rayleigh targets on `stream`, Love targets on `stream_love` (fork / join through the two events)
+int bh_launch_swd_group2(const SwdMultiArgs &a, int G, hipStream_t stream, hipStream_t stream_love, hipEvent_t ev_fork, hipEvent_t ev_join);
+size_t bh_swd_group2_lds_bytes(int G, int J, int rows, int Kmax, int maxmode, int iwave); // look-ahead per target in a.t[i].look; 0 ok, -1 too deep for LDS
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

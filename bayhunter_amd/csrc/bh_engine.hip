@@ -38,6 +38,10 @@ struct bh_engine {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;             // receiver-function kernels run here, next to the dispersion kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_love = nullptr;        // Love dispersion wavefronts run here, next to the Rayleigh ones
+    hipEvent_t ev_fork_l = nullptr, ev_join_l = nullptr;
+    bool swd_v1 = true;                    // BH_SWD_V2 env selects the second-generation group kernel (swd_group2.inc; A/B testing)
+    int look_r = 0, look_l = 0;            // BH_SWD_LOOK_R / BH_SWD_LOOK_L env (experiment switches): trials per round by wave type
     bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
     std::string err;
     // staging / workspace
@@ -92,6 +96,7 @@ int ensure(bh_engine *e, DevBuf &b, size_t bytes)
     if (b.p) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->aux) HIPCHK(e, hipStreamSynchronize(e->aux));
+        if (e->aux_love) HIPCHK(e, hipStreamSynchronize(e->aux_love));
         HIPCHK(e, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -238,10 +243,10 @@ int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
 {
     *out = nullptr;
     if (!e->counting) return BH_OK;
-    int rc = ensure(e, e->counter, 8 * sizeof(unsigned long long));
+    int rc = ensure(e, e->counter, BH_DEBUG_WORDS * sizeof(unsigned long long));
     if (rc) return rc;
     if (!e->neval_pending) {
-        HIPCHK(e, hipMemsetAsync(e->counter.p, 0, 8 * sizeof(unsigned long long), st));
+        HIPCHK(e, hipMemsetAsync(e->counter.p, 0, BH_COUNTER_WORDS * sizeof(unsigned long long), st));
         e->neval_pending = true;
     }
     *out = (unsigned long long *)e->counter.p;
@@ -344,9 +349,15 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         }
         t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
     }
+    for (int t = 0; t < a.ntargets; ++t) {
+        if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
+        if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
+    }
     ev_begin(e, 0, st);
-    const int lrc = bh_launch_swd_group(a, G, st);
+    const int lrc = e->swd_v1 ? bh_launch_swd_group(a, G, st)
+                              : bh_launch_swd_group2(a, G, st, e->aux_love, e->ev_fork_l, e->ev_join_l);
     ev_end(e, 0, st);
+    if (lrc == -2) return fail(e, BH_EHIP, "stream fork for the Love launch");
     if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
@@ -425,7 +436,10 @@ int bh_engine_create(int device, bh_engine **out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->aux_love, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork_l, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join_l, hipEventDisableTiming) != hipSuccess) {
         delete e;
         return BH_EHIP;
     }
@@ -436,6 +450,9 @@ int bh_engine_create(int device, bh_engine **out)
         e->love_inlook = std::atoi(g);
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
     }
+    if (std::getenv("BH_SWD_V2")) e->swd_v1 = false;
+    if (const char *g = std::getenv("BH_SWD_LOOK_R")) e->look_r = std::atoi(g);
+    if (const char *g = std::getenv("BH_SWD_LOOK_L")) e->look_l = std::atoi(g);
     if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
     if (std::getenv("BH_NO_ORDER")) e->no_order = true;
     *out = e;
@@ -486,6 +503,9 @@ void bh_engine_destroy(bh_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->ev_fork_l) (void)hipEventDestroy(e->ev_fork_l);
+    if (e->ev_join_l) (void)hipEventDestroy(e->ev_join_l);
+    if (e->aux_love) (void)hipStreamDestroy(e->aux_love);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -545,6 +565,15 @@ int bh_debug_counters(bh_engine *e, uint64_t out[8])
     if (!e->counter.p) return fail(e, BH_EINVAL, "counting was never enabled");
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, e->counter.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+int bh_debug_trace(bh_engine *e, uint64_t *out, int nwaves)
+{
+    if (!e || !out || nwaves < 0 || nwaves > BH_TRACE_WAVES) return BH_EINVAL;
+    if (!e->counter.p) return fail(e, BH_EINVAL, "counting was never enabled");
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, (uint64_t *)e->counter.p + BH_COUNTER_WORDS, (size_t)4 * nwaves * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return BH_OK;
 }
 

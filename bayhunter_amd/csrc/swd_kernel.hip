@@ -478,8 +478,13 @@ enum : int {
 template <int XSC> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
     int XS = XSC;
-    // constants
-    double cc, cm, betmxd, dc, onea, one, twopi, pct;
+    // constants of the reference's driver (compile-time: they cost no registers)
+    static constexpr double one = 1.0e-2;
+    static constexpr double onea = (double)1.5f;
+    static constexpr double dc = (double)0.005f;     // abs(dble(0.005)) with a default-real literal
+    static constexpr double twopi = 2.0 * 3.141592653589793;
+    static constexpr double pct = (double)0.01f;     // `0.01*ss1` with a default-real literal (:623-626)
+    double cm, betmxd;
     bool group;
     int K;
     int mode;            // highest mode wanted (1 = fundamental)
@@ -538,15 +543,10 @@ struct SearchT {
             }
             if (bi > betmx) betmx = bi;
         }
-        one = 1.0e-2;
-        onea = (double)1.5f;
-        dc = fabs((double)0.005f);
-        twopi = 2.0 * 3.141592653589793;
-        pct = (double)0.01f; // `0.01*ss1` with a default-real literal (:623-626)
         float cc1 = (jsol == 0) ? betmn : gtsolh_f32(md.Af(jmn), md.Bf(jmn));
         cc1 = 0.95f * cc1;
         cc1 = 0.90f * cc1;
-        cc = (double)cc1;
+        const double cc = (double)cc1;
         cm = cc;
         betmxd = (double)betmx;
         group = igr > 0;
@@ -840,6 +840,238 @@ struct SearchT {
             ceval = c2;
             st = ST_STEP;
         }
+    }
+
+    // ---- advance() for SIMT execution ---------------------------------------------------------------
+    // The same transition as advance(), written as straight-line selects: in a wavefront whose models are
+    // at different points of their searches every `if` of advance() is an exec-mask region that all lanes
+    // walk through (measured: ~2000 cycles per transition); here only the two rare, expensive steps stay
+    // behind a branch -- the Neville interpolation (divisions, LDS table) and the end of a root search
+    // (result store, set-up of the next period).  Every value is produced by the operations of advance().
+    __device__ __forceinline__ void advance2(double del)
+    {
+        ++evals;
+        const bool sF = st == ST_FIRST, sS = st == ST_STEP, sN0 = st == ST_NEV0, sNF = st == ST_NEVF;
+        const bool isN = st >= ST_NEV0;
+        // -- first value of a search (:421-423) / a bracket step (:447-449)
+        double n_del1 = sF ? del : del1;
+        del1st = (sF && ifirst == 1) ? del : del1st;
+        int n_idir = sF ? ((ifirst != 1 && signs_differ(del1st, n_del1)) ? -1 : +1) : idir;
+        del2 = sS ? del : del2;
+        const bool brk = sS && signs_differ(del1, del);   // bracketed: enter nevill with (c1,c2,del1,del2)
+        const bool nb = sS && !brk;
+        double n_c1 = nb ? c2 : c1;
+        n_del1 = nb ? del : n_del1;
+        const bool failS = nb && (n_c1 < cm || n_c1 >= betmxd + dc);
+        const bool step = sF || (nb && !failS);             // label 1000 of getsol: next bracket step (:437-446)
+        double c2n = (n_idir > 0) ? n_c1 + dc : n_c1 - dc;
+        const bool redir = step && c2n <= clow;
+        n_idir = redir ? +1 : n_idir;
+        n_c1 = redir ? clow : n_c1;
+        c2n = redir ? clow + dc : c2n;
+        // -- inside nevill (:582-660)
+        del3 = isN ? del : del3;
+        int n_nev = sN0 ? 1 : nev, n_mnev = sN0 ? 1 : mnev;
+        const bool t4 = isN && !sNF;                          // label 100
+        int n_nctrl = sN0 ? 1 : nctrl;
+        n_nctrl = t4 ? n_nctrl + 1 : n_nctrl;
+        const bool fin100 = t4 && n_nctrl >= 100;
+        const bool outside = t4 && !fin100 && (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)); // estimate left the bracket
+        const bool t5 = sNF || (t4 && !fin100 && !outside);
+        const double s13 = del1 - del3, s32 = del3 - del2;
+        const bool sd31 = signs_differ(del3, del1);
+        const bool upd2 = t5 && sd31, upd1 = t5 && !sd31;
+        const double b_c2 = upd2 ? c3 : c2, b_del2 = upd2 ? del3 : del2;
+        const double b_c1 = upd1 ? c3 : n_c1, b_del1 = upd1 ? del3 : n_del1;
+        const bool conv = t5 && (fabs(b_c1 - b_c2) <= 1.0e-6 * b_c1);
+        const bool t5c = t5 && !conv;
+        n_nev = (outside || (t5c && signs_differ(s13, s32))) ? 0 : n_nev;
+        const double ss1 = fabs(b_del1), s1 = pct * ss1;
+        const double ss2 = fabs(b_del2), s2 = pct * ss2;
+        bool halve = (s1 > ss2 || s2 > ss1 || n_nev == 0);
+        double c3n = c3;
+        if (t5c && !halve) { // inverse Neville interpolation (:626-655)
+            if (n_nev == 2) {
+                xl[n_mnev * XS] = c3;
+                yl[n_mnev * XS] = del3;
+            } else {
+                xl[0] = b_c1;
+                yl[0] = b_del1;
+                xl[XS] = b_c2;
+                yl[XS] = b_del2;
+                n_mnev = 1;
+            }
+            const double ym = yl[n_mnev * XS];
+            for (int kk = 1; kk <= n_mnev; ++kk) {
+                const int j = n_mnev - kk;
+                const double yj = yl[j * XS];
+                const double denom = ym - yj;
+                if (fabs(denom) < 1.0e-10 * fabs(ym)) {
+                    halve = true;
+                    break;
+                }
+                xl[j * XS] = (-yj * xl[(j + 1) * XS] + ym * xl[j * XS]) / denom;
+            }
+            if (!halve) {
+                c3n = xl[0];
+                n_nev = 2;
+                n_mnev = n_mnev + 1;
+                if (n_mnev > 10) n_mnev = 10;
+            }
+        }
+        const bool mid = brk || outside || (t5c && halve);  // the next point is the middle of the bracket
+        const double midc = 0.5 * (b_c1 + b_c2);
+        c3n = mid ? midc : c3n;
+        n_nev = (t5c && halve) ? 1 : n_nev;
+        n_mnev = (t5c && halve) ? 1 : n_mnev;
+        // -- commit
+        c1 = b_c1; del1 = b_del1;
+        c2 = step ? c2n : b_c2;
+        del2 = b_del2;
+        idir = n_idir; nev = n_nev; mnev = n_mnev; nctrl = n_nctrl;
+        const bool refine = brk || outside || t5c;
+        c3 = refine ? c3n : c3;
+        ceval = step ? c2n : (refine ? c3n : ceval);
+        st = step ? (int)ST_STEP : (brk ? (int)ST_NEV0 : (outside ? (int)ST_NEVF : (t5c ? (int)ST_NEVL : st)));
+        const bool fin = fin100 || conv;                      // getsol after nevill (:468-471)
+        c1 = fin ? c3 : c1;
+        const bool ended = fin || failS;
+        if (ended) end_of_search((fin && !(c1 > betmxd)) ? 6 : 2);
+    }
+
+    // A root search ended: 6 = found c1, 2 = failed.  (The driver's part, surfdisp96.f:276-354.)
+    __device__ void end_of_search(int todo)
+    {
+        bool period_done = false;
+        double c1b = 0.0; // the "c1" the driver uses after the (optional) second search
+        if (root == 0) {
+            if (todo == 2) { // no root: err (fundamental mode only), zero-fill, next mode (:313-354)
+                fail_mode();
+                if (iq >= mode) {
+                    active = false;
+                } else {
+                    iq = iq + 1;
+                    k = 0;
+                    next_search();
+                }
+            } else {
+                ck = c1;
+                if (mode > 1) cper[k * XS] = c1;
+                if (group) { // second root at the slightly longer period (:282-287)
+                    root = 1;
+                    t1 = (double)t1b;
+                    omega = twopi / t1;
+                    ifirst = 0;
+                    clow = ((mode > 1) ? cbper[k * XS] : 0.0) + one * dc; // cb(k) of the previous mode
+                    c1 = c1 - onea * dc;
+                    st = ST_FIRST;
+                    ceval = c1;
+                } else {
+                    period_done = true;
+                }
+            }
+        } else {
+            c1b = (todo == 2) ? ck : c1; // second root failed: reuse the first (:291-293)
+            if (mode > 1) cbper[k * XS] = c1b;
+            period_done = true;
+        }
+        if (period_done) {
+            const float cc0 = (float)ck;
+            double out;
+            if (!group) {
+                out = (double)cc0;
+            } else { // all binary32 (:305)
+                const float cc1s = (float)c1b;
+                const float gvel =
+                    (1.0f / t1a - 1.0f / t1b) / (1.0f / (t1a * cc0) - 1.0f / (t1b * cc1s));
+                out = (double)gvel;
+            }
+            if (writer) vel[k] = out;
+            k = k + 1;
+            next_search();
+        }
+    }
+
+    // The trial velocities of the next round, candidate(0..n-1), computed incrementally; lane keeps those
+    // with index ia / ib.  Same operations as candidate().
+    __device__ __forceinline__ void candidates(int n, int ia, int ib, double &qa, double &qb) const
+    {
+        const bool stepping = (st == ST_FIRST || st == ST_STEP);
+        const bool up = (st == ST_FIRST) || (idir > 0);
+        double q = ceval, lo = c1, hi = c2;
+        const double w = c2 - c1;
+        qa = q;
+        qb = q;
+        for (int j = 1; j < n; ++j) {
+            const double qs = up ? q + dc : q - dc;
+            const double t = del1 * (c2 - q) + del2 * (q - c1); // (c2 - c1) * linear model at q
+            const bool neg_lin = (t < 0.0) != (w < 0.0);
+            const bool differs = neg_lin != (del1 < 0.0);
+            lo = differs ? lo : q;
+            hi = differs ? q : hi;
+            const double qr = 0.5 * (lo + hi);
+            q = stepping ? qs : qr;
+            qa = (j == ia) ? q : qa;
+            qb = (j == ib) ? q : qb;
+        }
+    }
+
+    // candidate(0..n-1) written to q[0..n-1] (LDS): the requests of the next round.
+    __device__ __forceinline__ void candidates_store(int n, double *qout) const
+    {
+        const bool stepping = (st == ST_FIRST || st == ST_STEP);
+        const bool up = (st == ST_FIRST) || (idir > 0);
+        double q = ceval, lo = c1, hi = c2;
+        const double w = c2 - c1;
+        qout[0] = q;
+        for (int j = 1; j < n; ++j) {
+            const double qs = up ? q + dc : q - dc;
+            const double t = del1 * (c2 - q) + del2 * (q - c1); // (c2 - c1) * linear model at q
+            const bool neg_lin = (t < 0.0) != (w < 0.0);
+            const bool differs = neg_lin != (del1 < 0.0);
+            lo = differs ? lo : q;
+            hi = differs ? q : hi;
+            const double qr = 0.5 * (lo + hi);
+            q = stepping ? qs : qr;
+            qout[j] = q;
+        }
+    }
+
+    // ---- parking: everything advance() changes, in ST_SLOTS doubles (the group kernel keeps the
+    // search state of a model in LDS between two state transitions, not in registers) ----------
+    static constexpr int ST_SLOTS = 18;
+    __device__ __forceinline__ void park(double *p) const
+    {
+        const unsigned w0 = (unsigned)st | ((unsigned)ifirst << 3) | ((idir > 0 ? 1u : 0u) << 4) | ((unsigned)nev << 5) |
+                            ((unsigned)mnev << 7) | ((unsigned)root << 11) | ((active ? 1u : 0u) << 12) |
+                            ((unsigned)errflag << 13) | ((unsigned)iq << 14);
+        const unsigned w1 = (unsigned)k | ((unsigned)nctrl << 8) | ((unsigned)ift << 16);
+        double2 *q = reinterpret_cast<double2 *>(p);
+        q[0] = make_double2(c1, c2);
+        q[1] = make_double2(del1, del2);
+        q[2] = make_double2(c3, del3);
+        q[3] = make_double2(clow, del1st);
+        q[4] = make_double2(ck, t1);
+        q[5] = make_double2(omega, ceval);
+        q[6] = make_double2(cm, betmxd);
+        q[7] = make_double2(__hiloint2double((int)__float_as_uint(t1b), (int)__float_as_uint(t1a)),
+                            __hiloint2double((int)w1, (int)w0));
+        q[8] = make_double2(__hiloint2double(0, (int)evals), 0.0);
+    }
+    __device__ __forceinline__ void unpark(const double *p)
+    {
+        const double2 *q = reinterpret_cast<const double2 *>(p);
+        const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7];
+        c1 = a0.x; c2 = a0.y; del1 = a1.x; del2 = a1.y; c3 = a2.x; del3 = a2.y; clow = a3.x; del1st = a3.y;
+        ck = a4.x; t1 = a4.y; omega = a5.x; ceval = a5.y; cm = a6.x; betmxd = a6.y;
+        t1a = __uint_as_float((unsigned)__double2loint(a7.x));
+        t1b = __uint_as_float((unsigned)__double2hiint(a7.x));
+        const unsigned w0 = (unsigned)__double2loint(a7.y), w1 = (unsigned)__double2hiint(a7.y);
+        st = (int)(w0 & 7u); ifirst = (int)((w0 >> 3) & 1u); idir = ((w0 >> 4) & 1u) ? 1 : -1;
+        nev = (int)((w0 >> 5) & 3u); mnev = (int)((w0 >> 7) & 15u); root = (int)((w0 >> 11) & 1u);
+        active = ((w0 >> 12) & 1u) != 0u; errflag = (int)((w0 >> 13) & 1u); iq = (int)((w0 >> 14) & 31u);
+        k = (int)(w1 & 255u); nctrl = (int)((w1 >> 8) & 255u); ift = (int)(w1 >> 16);
+        evals = (unsigned)__double2loint(q[8].x);
     }
 };
 using SearchRt = SearchT<0>;
@@ -1172,7 +1404,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
     const bool prof = (A.neval != nullptr);
     long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
+    const unsigned long long w_start = prof ? wall_clock64() : 0ull, c_start = prof ? clock64() : 0ull;
+    unsigned int nrounds = 0;
     while (__ballot(S.active) != 0ull) {
+        ++nrounds;
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (prof) t0 = clock64();
         const double omg = S.omega;
@@ -1397,10 +1632,23 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
             atomicAdd(A.neval + o, (unsigned long long)tA);
             atomicAdd(A.neval + o + 1, (unsigned long long)tB);
             atomicAdd(A.neval + o + 2, (unsigned long long)tS);
-            atomicAdd(A.neval + 7, 1ull);
+            const unsigned long long widx = atomicAdd(A.neval + 7, 1ull);
+            if (widx < BH_TRACE_WAVES) { // development aid: one record per wavefront (tools/gpu_trace.py)
+                unsigned long long *r = A.neval + BH_COUNTER_WORDS + 4 * widx;
+                unsigned hwid, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                hwid = (hwid & 0xffffu) | ((xcc & 0xfu) << 16);
+                r[0] = w_start;
+                r[1] = wall_clock64();
+                r[2] = clock64() - c_start;
+                r[3] = (unsigned long long)nrounds | ((unsigned long long)ifunc << 32) | ((unsigned long long)hwid << 36);
+            }
         }
     }
 }
+
+#include "swd_group2.inc"
 
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
@@ -1741,5 +1989,144 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
     const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
     const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
     hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+    return 0;
+}
+
+// ---- group kernel v2 (swd_group2.inc): Love and Rayleigh targets are separate launches (own register budget,
+// own LDS size), the Love launch goes to `stream_love` between ev_fork / ev_join so that both run side by side.
+size_t bh_swd_group2_lds_bytes(int G, int J, int rows, int Kmax, int maxmode, int iwave)
+{
+    return LIBM_TAB_PAD + G2_PER_BYTES + g2_shared_lds_bytes(G, J, Kmax, maxmode, iwave) + G2_WPB * g2_wave_lds_bytes(G, J, rows, iwave);
+}
+
+namespace {
+// per wavefront, so that three Rayleigh workgroups (or two + two of Love's smaller ones) share a CU's 160 KB
+constexpr size_t G2_WAVE_LDS_TARGET = 160 * 1024 / 3 / G2_WPB; // a wavefront's share of its workgroup's LDS
+constexpr size_t G2_WG_LDS_CAP = 160 * 1024;
+
+int launch_group2_family(const SwdMultiArgs &a0, int iwave, int G0, hipStream_t stream)
+{
+    SwdMultiArgs a = a0;
+    a.ntargets = 0;
+    int kmax = 0, maxmode = 1;
+    for (int t = 0; t < a0.ntargets; ++t)
+        if (a0.t[t].iwave == iwave) {
+            a.t[a.ntargets++] = a0.t[t];
+            kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
+            maxmode = a0.t[t].mode > maxmode ? a0.t[t].mode : maxmode;
+        }
+    if (a.ntargets == 0) return 0;
+    const bool two = a0.split != nullptr && a0.Lcut < a0.Lmax;
+    if (!two) a.split = nullptr;
+    size_t wave_lds = 0, shared_lds = 0;
+    int nwaves = 1;
+    static const size_t lds_target = std::getenv("BH_SWD_LDS_TARGET") ? (size_t)std::atol(std::getenv("BH_SWD_LDS_TARGET")) : G2_WAVE_LDS_TARGET; // experiment switch
+    for (int cls = two ? 0 : 1; cls <= 1; ++cls) {
+        const int rows = (two && cls == 1) ? a0.Lcut : a0.Lmax;
+        int G = G0;
+        auto trials = [&](int g, int t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && g * J > BH_WAVE) --J;
+            return J;
+        };
+        auto wave_bytes = [&](int g) { // a wavefront's own block
+            size_t w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const size_t l = g2_wave_lds_bytes(g, trials(g, t), rows, iwave);
+                w = l > w ? l : w;
+            }
+            return w;
+        };
+        auto shared_bytes = [&](int g) { // the workgroup's shared block
+            size_t w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const size_t l = g2_shared_lds_bytes(g, trials(g, t), kmax, maxmode, iwave);
+                w = l > w ? l : w;
+            }
+            return w;
+        };
+        auto wg_bytes = [&](int g) { return LIBM_TAB_PAD + G2_PER_BYTES + shared_bytes(g) + G2_WPB * wave_bytes(g); };
+        auto waves = [&](int g) {
+            long w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                w += (a.B + mpw - 1) / mpw;
+            }
+            return w;
+        };
+        auto most_models = [&](int g) {
+            int m = 1;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                m = mpw > m ? mpw : m;
+            }
+            return m;
+        };
+        // a batch that leaves most of the chip idle anyway: one lane per layer of the deepest model of the class
+        for (int Gwide = rows - 1 > 16 ? 16 : rows - 1; Gwide > G; --Gwide) {
+            bool same = waves(Gwide) <= 512;
+            for (int t = 0; t < a.ntargets; ++t) same = same && trials(Gwide, t) == trials(G, t);
+            if (same) {
+                G = Gwide;
+                break;
+            }
+        }
+        // fewer models per wavefront (more lanes per model) until the parked layers fit: first the residency
+        // target, at the latest a CU's 160 KB
+        while (most_models(G) > 1 && wg_bytes(G) > G2_WPB * lds_target) G += 1;
+        while (G < BH_WAVE && wg_bytes(G) > G2_WG_LDS_CAP) G += 1;
+        if (wg_bytes(G) > G2_WG_LDS_CAP) return -1;
+        a.rows[cls] = rows;
+        a.lanes[cls] = G;
+        const size_t wb = wave_bytes(G), sb = shared_bytes(G);
+        wave_lds = wb > wave_lds ? wb : wave_lds;
+        shared_lds = sb > shared_lds ? sb : shared_lds;
+        for (int t = 0; t < a.ntargets; ++t) {
+            const int mpw = BH_WAVE / (G * trials(G, t));
+            const int nx = (a.B + mpw - 1) / mpw;
+            nwaves = nx > nwaves ? nx : nwaves;
+        }
+    }
+    if (!two) {
+        a.rows[0] = a.rows[1];
+        a.lanes[0] = a.lanes[1];
+    }
+    const dim3 grid((nwaves + G2_WPB - 1) / G2_WPB, a.ntargets, two ? 2 : 1);
+    const size_t lds = LIBM_TAB_PAD + G2_PER_BYTES + shared_lds + G2_WPB * wave_lds;
+    if (lds > 64 * 1024) { // beyond the default limit of dynamic LDS per workgroup: opt in (deep models)
+        static size_t allowed[3] = {0, 0, 0};
+        if (lds > allowed[iwave]) {
+            const hipError_t he = (iwave == 1)
+                ? hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_WG_LDS_CAP)
+                : hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_WG_LDS_CAP);
+            if (he != hipSuccess) return -1;
+            allowed[iwave] = G2_WG_LDS_CAP;
+        }
+    }
+    if (iwave == 1)
+        hipLaunchKernelGGL(swd_group2_kernel<1>, grid, dim3(BH_WAVE * G2_WPB), lds, stream, a, (int)shared_lds, (int)wave_lds);
+    else
+        hipLaunchKernelGGL(swd_group2_kernel<2>, grid, dim3(BH_WAVE * G2_WPB), lds, stream, a, (int)shared_lds, (int)wave_lds);
+    return 0;
+}
+} // namespace
+
+int bh_launch_swd_group2(const SwdMultiArgs &a, int G, hipStream_t stream, hipStream_t stream_love,
+                         hipEvent_t ev_fork, hipEvent_t ev_join)
+{
+    bool love = false, ray = false;
+    for (int t = 0; t < a.ntargets; ++t) {
+        love = love || a.t[t].iwave == 1;
+        ray = ray || a.t[t].iwave == 2;
+    }
+    const bool fork = love && ray && stream_love != nullptr && stream_love != stream;
+    if (fork) {
+        if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(stream_love, ev_fork, 0) != hipSuccess) return -2;
+    }
+    if (launch_group2_family(a, 2, G, stream) != 0) return -1;
+    if (launch_group2_family(a, 1, G, fork ? stream_love : stream) != 0) return -1;
+    if (fork) {
+        if (hipEventRecord(ev_join, stream_love) != hipSuccess || hipStreamWaitEvent(stream, ev_join, 0) != hipSuccess) return -2;
+    }
     return 0;
 }

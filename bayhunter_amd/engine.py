@@ -108,6 +108,7 @@ def load_library():
     L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bh_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.bh_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.bh_swd_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_ssize_t,
                                C.c_ssize_t, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.bh_rf_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
@@ -121,7 +122,7 @@ def load_library():
     L.bh_chain_propose.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int]
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
-                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 1:
@@ -132,7 +133,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
-                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept")
 
 
@@ -234,6 +235,14 @@ class Engine(object):
         out = (C.c_uint64 * 8)()
         self._check(self._L.bh_debug_counters(self._h, out))
         return [int(v) for v in out]
+
+    def debug_trace(self):
+        """Development aid: [nwaves, 4] uint64 records of the last counted dispersion launch
+        (start, end in 100 MHz ticks, core cycles, rounds | wave type << 32 | HW_ID << 36)."""
+        n = min(self.debug_counters()[7], 16384)
+        out = (C.c_uint64 * (4 * max(n, 1)))()
+        self._check(self._L.bh_debug_trace(self._h, out, n))
+        return np.frombuffer(out, dtype=np.uint64).reshape(-1, 4)[:n].copy()
 
     def last_neval(self):
         v = C.c_uint64(0)

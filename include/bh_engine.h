@@ -270,6 +270,9 @@ int bh_last_neval(bh_engine *e, uint64_t *neval);
 /* development aid: raw counter block of the last counted call ([0] evaluations, [1..3]
  * Rayleigh wave-cycles in phase A / B / state update, [4..6] the same for Love, [7] wavefronts) */
 int bh_debug_counters(bh_engine *e, uint64_t out[8]);
+/* development aid: one record of 4 words per traced wavefront of the last counted dispersion launch
+ * (start, end [100 MHz ticks], core cycles, rounds | wave type << 32 | HW_ID << 36); counter [7] = wavefronts */
+int bh_debug_trace(bh_engine *e, uint64_t *out, int nwaves);
 
 #ifdef __cplusplus
 }
