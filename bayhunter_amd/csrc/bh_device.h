@@ -97,9 +97,6 @@ int bh_swd_pick_group(int B, int ntargets, int Lmax);
 double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
-// v2 of the group kernel: Rayleigh targets on `stream`, Love targets on `stream_love` (fork / join through the two events)
-int bh_launch_swd_group2(const SwdMultiArgs &a, int G, hipStream_t stream, hipStream_t stream_love, hipEvent_t ev_fork, hipEvent_t ev_join);
-size_t bh_swd_group2_lds_bytes(int G, int J, int rows, int Kmax, int maxmode, int iwave); // look-ahead per target in a.t[i].look; 0 ok, -1 too deep for LDS
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

@@ -38,9 +38,6 @@ struct bh_engine {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;             // receiver-function kernels run here, next to the dispersion kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t aux_love = nullptr;        // Love dispersion wavefronts run here, next to the Rayleigh ones
-    hipEvent_t ev_fork_l = nullptr, ev_join_l = nullptr;
-    bool swd_v1 = true;                    // BH_SWD_V2 env selects the second-generation group kernel (swd_group2.inc; A/B testing)
     int look_r = 0, look_l = 0;            // BH_SWD_LOOK_R / BH_SWD_LOOK_L env (experiment switches): trials per round by wave type
     bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
     std::string err;
@@ -96,7 +93,6 @@ int ensure(bh_engine *e, DevBuf &b, size_t bytes)
     if (b.p) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->aux) HIPCHK(e, hipStreamSynchronize(e->aux));
-        if (e->aux_love) HIPCHK(e, hipStreamSynchronize(e->aux_love));
         HIPCHK(e, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -354,10 +350,8 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
     }
     ev_begin(e, 0, st);
-    const int lrc = e->swd_v1 ? bh_launch_swd_group(a, G, st)
-                              : bh_launch_swd_group2(a, G, st, e->aux_love, e->ev_fork_l, e->ev_join_l);
+    const int lrc = bh_launch_swd_group(a, G, st);
     ev_end(e, 0, st);
-    if (lrc == -2) return fail(e, BH_EHIP, "stream fork for the Love launch");
     if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
@@ -436,10 +430,7 @@ int bh_engine_create(int device, bh_engine **out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->aux_love, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork_l, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join_l, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete e;
         return BH_EHIP;
     }
@@ -450,7 +441,6 @@ int bh_engine_create(int device, bh_engine **out)
         e->love_inlook = std::atoi(g);
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
     }
-    if (std::getenv("BH_SWD_V2")) e->swd_v1 = false;
     if (const char *g = std::getenv("BH_SWD_LOOK_R")) e->look_r = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOK_L")) e->look_l = std::atoi(g);
     if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
@@ -503,9 +493,6 @@ void bh_engine_destroy(bh_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
-    if (e->ev_fork_l) (void)hipEventDestroy(e->ev_fork_l);
-    if (e->ev_join_l) (void)hipEventDestroy(e->ev_join_l);
-    if (e->aux_love) (void)hipStreamDestroy(e->aux_love);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }

@@ -1,0 +1,809 @@
+// bayhunter_amd/csrc/swd_common.h -- device code shared by the dispersion kernels (swd_kernel.hip: one lane per
+// model; swd_group_kernel.hip: G lanes per model): the glibc-exact libm front-end, the layer terms and recursions
+// of the Love / Rayleigh secular functions (surfdisp96.f:710-1068) and the per-model search state machine
+// (surfdisp96.f:172-357, :390-482, :557-686).  Included inside each file's anonymous namespace.
+#pragma once
+
+struct LibmTabs {
+    const uint64_t *exp_tab; // [256]  in LDS
+    const double *sc_tab;    // [440]  in LDS
+};
+constexpr int LIBM_TAB_BYTES = 256 * 8 + 440 * 8;
+
+__device__ __forceinline__ LibmTabs stage_libm_tables(unsigned char *lds, int lane, int nthreads = BH_WAVE)
+{
+    uint64_t *et = reinterpret_cast<uint64_t *>(lds);
+    uint64_t *st = et + 256;
+    for (int i = lane; i < 256; i += nthreads) et[i] = bhp_exp_tab[i];
+    for (int i = lane; i < 440; i += nthreads) st[i] = bhp_sincos_tab_bits[i];
+    return LibmTabs{et, reinterpret_cast<const double *>(st)};
+}
+__device__ __forceinline__ void bh_sincos(double x, double *sn, double *cs, const LibmTabs &T)
+{
+    if (!bhp_sincos_bl(x, sn, cs, T.sc_tab)) sincos(x, sn, cs); // |x| >= 1.05e8, inf, nan: device library
+}
+__device__ __forceinline__ double bh_exp(double x, const LibmTabs &T)
+{
+    double r = bhp_exp_core(x, T.exp_tab); // branch-free main path; meaningless outside its domain
+    if (!bhp_exp_in_domain(x))             // rare: |x| < 2^-54 -> 1 + x like glibc; |x| >= 512, nan -> device library
+        r = ((((unsigned)__double2hiint(x) >> 20) & 0x7ffu) < 0x3c9u) ? 1.0 + x : exp(x);
+    return r;
+}
+
+
+constexpr int NEV_MAX = 11; // Neville table entries: order grows to m <= 10 (surfdisp96.f:655)
+
+__device__ __forceinline__ bool signs_differ(double x, double y)
+{
+    return ((__double_as_longlong(x) ^ __double_as_longlong(y)) < 0);
+}
+
+// LDS views -----------------------------------------------------------------------------------
+// Model arrays in LDS as [array][layer][column]; S = number of columns (models) per wave.
+template <int S>
+struct ModelLdsT {
+    const float *d, *a, *b, *rho; // column pre-offset
+    __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
+    __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
+    __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }
+    __device__ __forceinline__ double D(int m) const { return (double)d[m * S]; }
+    __device__ __forceinline__ double A(int m) const { return (double)a[m * S]; }
+    __device__ __forceinline__ double Bv(int m) const { return (double)b[m * S]; }
+    __device__ __forceinline__ double R(int m) const { return (double)rho[m * S]; }
+};
+using ModelLds = ModelLdsT<BH_WAVE>;
+struct ModelLdsRt { // same, with the column count known only at run time
+    const float *d, *a, *b, *rho;
+    int S;
+    __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
+    __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
+    __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }
+    __device__ __forceinline__ double D(int m) const { return (double)d[m * S]; }
+    __device__ __forceinline__ double A(int m) const { return (double)a[m * S]; }
+    __device__ __forceinline__ double Bv(int m) const { return (double)b[m * S]; }
+    __device__ __forceinline__ double R(int m) const { return (double)rho[m * S]; }
+};
+
+// ---- range tracking for the shared-reciprocal divisions ------------------------------------------
+// The fast division route (bh_device.h) returns the bits of a plain IEEE division as long as the
+// operands lie in [2^-400, 2^400].  Checking that with a branch inside the layer recursion costs
+// more than it saves (an exec-mask branch is ~100 cycles on this chip), so the recursion only
+// TRACKS the smallest and largest magnitude it divided (two cheap min/max per operand, no
+// branch); after the whole recursion one test decides whether the value can be trusted, and the
+// (never observed in practice) out-of-range case re-runs the recursion with plain divisions.
+struct DivRange {
+    double lo, hi;
+    __device__ __forceinline__ void reset() { lo = 1.0; hi = 1.0; }
+    __device__ __forceinline__ void see(double a) { lo = fmin(lo, a); hi = fmax(hi, a); } // a >= 0
+    __device__ __forceinline__ bool ok() const
+    {
+        return lo >= 3.8725919148493183e-121 /* 2^-400 */ && hi <= 2.5822498780869086e+120 /* 2^400 */;
+    }
+};
+
+// One layer of the Love recursion (surfdisp96.f:758-767) given the layer terms.
+// EXACT = true: the reference's operations verbatim.  EXACT = false: the three divisions take
+// the shared-reciprocal route (rx = bh_rcp_refined(xmu)) and report their operand range.
+template <bool EXACT>
+__device__ __forceinline__ void love_step(double &e1, double &e2, double cosq, double y, double z,
+                                          double xmu, double rx, DivRange &dr)
+{
+    const double e10 = e1 * cosq + e2 * xmu * z;
+    double e20;
+    if (EXACT) {
+        e20 = e1 * y / xmu + e2 * cosq;
+    } else {
+        const double num = e1 * y;
+        dr.see(fabs(num));
+        dr.see(xmu);
+        e20 = bh_quot(num, xmu, rx) + e2 * cosq;
+    }
+    const double a10 = fabs(e10), a20 = fabs(e20);
+    double xnor = fmax(a10, a20);
+    if (xnor < 1.0e-40) xnor = 1.0;
+    if (EXACT) {
+        e1 = e10 / xnor;
+        e2 = e20 / xnor;
+    } else {
+        dr.see(fmin(a10, a20));
+        dr.see(xnor);
+        const double r = bh_rcp_refined(xnor);
+        e1 = bh_quot(e10, xnor, r);
+        e2 = bh_quot(e20, xnor, r);
+    }
+}
+
+// ---- Love: SH Thomson-Haskell (surfdisp96.f:710-769) ----------------------------------------
+template <bool EXACT>
+__device__ double love_secular(double wvno, double omega, const ModelLds &md, int mmax, int llw,
+                               int mtop, DivRange &dr, const LibmTabs &LT)
+{
+    double beta1 = md.Bv(mmax - 1);
+    double rho1 = md.R(mmax - 1);
+    double xkb = omega / beta1;
+    double wvnop = wvno + xkb;
+    double wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double e1 = rho1 * rb;
+    double e2 = 1.0 / (beta1 * beta1);
+    for (int m = mtop - 2; m >= 0; --m) {
+        if (m <= mmax - 2 && m >= llw - 1) {
+            beta1 = md.Bv(m);
+            rho1 = md.R(m);
+            const double dm = md.D(m);
+            const double xmu = rho1 * beta1 * beta1;
+            xkb = omega / beta1;
+            wvnop = wvno + xkb;
+            wvnom = fabs(wvno - xkb);
+            rb = sqrt(wvnop * wvnom);
+            const double q = dm * rb;
+            double cosq, y, z;
+            if (wvno < xkb) {
+                double sinq;
+                bh_sincos(q, &sinq, &cosq, LT);
+                y = sinq / rb;
+                z = -rb * sinq;
+            } else if (wvno == xkb) {
+                cosq = 1.0;
+                y = dm;
+                z = 0.0;
+            } else {
+                double fac = 0.0;
+                if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
+                cosq = (1.0 + fac) * 0.5;
+                const double sinq = (1.0 - fac) * 0.5;
+                y = sinq / rb;
+                z = rb * sinq;
+            }
+            love_step<EXACT>(e1, e2, cosq, y, z, xmu, EXACT ? 0.0 : bh_rcp_refined(xmu), dr);
+        }
+    }
+    return e1;
+}
+
+// ---- Rayleigh: eigenfunction products (surfdisp96.f:874-991, `var`) --------------------------
+struct LayerTerms {
+    double a0, cpcq, cpy, cpz, cqw, cqx, xy, xz, wy, wz, w, cosp;
+};
+
+__device__ __forceinline__ void layer_products(double p, double q, double ra, double rb,
+                                               double wvno, double xka, double xkb, double dpth,
+                                               LayerTerms &o, const LibmTabs &LT)
+{
+    // Two exec-mask regions per wave type (propagating: sincos; evanescent: exp) instead of the
+    // Fortran's three-way ifs -- branches are the expensive thing on this chip.  The measure-zero
+    // case wvno == xk? takes the evanescent arithmetic (p = 0, exp(-0) = 1 gives cos = 1 exactly)
+    // and has w/x resp. y/z overridden by selects, which are the values of surfdisp96.f:938-940.
+    double cosp, cosq, w, x, y, z;
+    double pex = 0.0, sex = 0.0;
+    if (wvno < xka) {
+        double sinp;
+        bh_sincos(p, &sinp, &cosp, LT);
+        w = sinp / ra;
+        x = -ra * sinp;
+    } else {
+        pex = p;
+        const double fac = (p < 16.0) ? bh_exp((p < 16.0) ? -2.0 * p : -32.0, LT) : 0.0;
+        cosp = (1.0 + fac) * 0.5;
+        const double sinp = (1.0 - fac) * 0.5;
+        const bool eq = (wvno == xka);
+        w = eq ? dpth : sinp / ra;
+        x = eq ? 0.0 : ra * sinp;
+        cosp = eq ? 1.0 : cosp;
+        pex = eq ? 0.0 : pex;
+    }
+    if (wvno < xkb) {
+        double sinq;
+        bh_sincos(q, &sinq, &cosq, LT);
+        y = sinq / rb;
+        z = -rb * sinq;
+    } else {
+        sex = q;
+        const double fac = (q < 16.0) ? bh_exp((q < 16.0) ? -2.0 * q : -32.0, LT) : 0.0;
+        cosq = (1.0 + fac) * 0.5;
+        const double sinq = (1.0 - fac) * 0.5;
+        const bool eq = (wvno == xkb);
+        y = eq ? dpth : sinq / rb;
+        z = eq ? 0.0 : rb * sinq;
+        cosq = eq ? 1.0 : cosq;
+        sex = eq ? 0.0 : sex;
+    }
+    const double exa = pex + sex;
+    const double a0 = (exa < 60.0) ? bh_exp((exa < 60.0) ? -exa : -60.0, LT) : 0.0;
+    o.a0 = a0;
+    o.cpcq = cosp * cosq;
+    o.cpy = cosp * y;
+    o.cpz = cosp * z;
+    o.cqw = cosq * w;
+    o.cqx = cosq * x;
+    o.xy = x * y;
+    o.xz = x * z;
+    o.wy = w * y;
+    o.wz = w * z;
+    o.w = w;
+    o.cosp = cosp;
+}
+
+// The 19 distinct entries of the 5x5 Dunkin compound matrix CA of one layer
+// (surfdisp96.f:1024-1068, `dnka`), formed with the reference's operation order.  Stored as
+//   c[0..4]  = ca11 ca12 ca13 ca14 ca15          (ca55 = ca11, ca45 = ca12, ca25 = ca14)
+//   c[5..7]  = ca21 ca23 ca24                    (ca54 = ca21), ca22 = ca44 = c[8]
+//   c[8]     = ca22 (= cpcq)
+//   c[9..11] = ca41 ca42 ca43                    (ca52 = ca41)
+//   c[12..13]= ca51 ca53
+//   c[14..18]= ca31 ca32 ca33 ca34 ca35
+struct Ca19 {
+    double c[19];
+};
+
+__device__ __forceinline__ void rayleigh_ca19(Ca19 &o, double wvno2, double gam, double gammk,
+                                              double rho, const LayerTerms &v)
+{
+    const double two = 2.0;
+    const double gamm1 = gam - 1.0;
+    const double twgm1 = gam + gamm1;
+    const double gmgmk = gam * gammk;
+    const double gmgm1 = gam * gamm1;
+    const double gm1sq = gamm1 * gamm1;
+    const double rho2 = rho * rho;
+    const double a0pq = v.a0 - v.cpcq;
+    const double ca11 = v.cpcq - two * gmgm1 * a0pq - gmgmk * v.xz - wvno2 * gm1sq * v.wy;
+    const double ca12 = (wvno2 * v.cpy - v.cqx) / rho;
+    const double ca13 = -(twgm1 * a0pq + gammk * v.xz + wvno2 * gamm1 * v.wy) / rho;
+    const double ca14 = (v.cpz - wvno2 * v.cqw) / rho;
+    const double ca15 = -(two * wvno2 * a0pq + v.xz + wvno2 * wvno2 * v.wy) / rho2;
+    const double ca21 = (gmgmk * v.cpz - gm1sq * v.cqw) * rho;
+    const double ca22 = v.cpcq;
+    const double ca23 = gammk * v.cpz - gamm1 * v.cqw;
+    const double ca24 = -v.wz;
+    const double ca41 = (gm1sq * v.cpy - gmgmk * v.cqx) * rho;
+    const double ca42 = -v.xy;
+    const double ca43 = gamm1 * v.cpy - gammk * v.cqx;
+    const double ca51 =
+        -(two * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * v.xz + gm1sq * gm1sq * v.wy) * rho2;
+    const double ca53 =
+        -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * v.xz + gamm1 * gm1sq * v.wy) * rho;
+    const double t = -two * wvno2;
+    o.c[0] = ca11; o.c[1] = ca12; o.c[2] = ca13; o.c[3] = ca14; o.c[4] = ca15;
+    o.c[5] = ca21; o.c[6] = ca23; o.c[7] = ca24; o.c[8] = ca22;
+    o.c[9] = ca41; o.c[10] = ca42; o.c[11] = ca43;
+    o.c[12] = ca51; o.c[13] = ca53;
+    o.c[14] = t * ca53;
+    o.c[15] = t * ca43;
+    o.c[16] = v.a0 + two * (v.cpcq - ca11);
+    o.c[17] = t * ca23;
+    o.c[18] = t * ca13;
+}
+
+// normc (surfdisp96.f:995-1020): divide the 5-vector by its max-norm (floor 1e-40); the log()
+// the Fortran takes of the norm is never used.  max is order-independent, so a tree is used.
+// EXACT = false: the five divisions share one refined reciprocal and report their range.
+template <bool EXACT>
+__device__ __forceinline__ void normalize5(const double ee0, const double ee1, const double ee2,
+                                           const double ee3, const double ee4, double e[5],
+                                           DivRange &dr)
+{
+    const double a0 = fabs(ee0), a1 = fabs(ee1), a2 = fabs(ee2), a3 = fabs(ee3), a4 = fabs(ee4);
+    double t1 = fmax(fmax(fmax(a0, a1), fmax(a2, a3)), a4);
+    if (t1 < 1.0e-40) t1 = 1.0;
+    if (EXACT) {
+        e[0] = ee0 / t1;
+        e[1] = ee1 / t1;
+        e[2] = ee2 / t1;
+        e[3] = ee3 / t1;
+        e[4] = ee4 / t1;
+    } else {
+        dr.see(fmin(fmin(fmin(a0, a1), fmin(a2, a3)), a4));
+        dr.see(t1);
+        const double r = bh_rcp_refined(t1);
+        e[0] = bh_quot(ee0, t1, r);
+        e[1] = bh_quot(ee1, t1, r);
+        e[2] = bh_quot(ee2, t1, r);
+        e[3] = bh_quot(ee3, t1, r);
+        e[4] = bh_quot(ee4, t1, r);
+    }
+}
+
+// e <- normalise(e * CA): ee(i) = sum_j e(j)*ca(j,i) accumulated from 0.0 in j order
+// (surfdisp96.f:836-842), then normc (:995-1020; its log() result is never used).
+template <bool EXACT>
+__device__ __forceinline__ void rayleigh_apply(double e[5], const double *c, DivRange &dr)
+{
+    const double ca11 = c[0], ca12 = c[1], ca13 = c[2], ca14 = c[3], ca15 = c[4];
+    const double ca21 = c[5], ca23 = c[6], ca24 = c[7], ca22 = c[8];
+    const double ca41 = c[9], ca42 = c[10], ca43 = c[11], ca51 = c[12], ca53 = c[13];
+    const double ca31 = c[14], ca32 = c[15], ca33 = c[16], ca34 = c[17], ca35 = c[18];
+    const double ca25 = ca14, ca44 = ca22, ca45 = ca12, ca52 = ca41, ca54 = ca21, ca55 = ca11;
+    double ee0 = 0.0, ee1 = 0.0, ee2 = 0.0, ee3 = 0.0, ee4 = 0.0;
+    ee0 = ee0 + e[0] * ca11; ee0 = ee0 + e[1] * ca21; ee0 = ee0 + e[2] * ca31; ee0 = ee0 + e[3] * ca41; ee0 = ee0 + e[4] * ca51;
+    ee1 = ee1 + e[0] * ca12; ee1 = ee1 + e[1] * ca22; ee1 = ee1 + e[2] * ca32; ee1 = ee1 + e[3] * ca42; ee1 = ee1 + e[4] * ca52;
+    ee2 = ee2 + e[0] * ca13; ee2 = ee2 + e[1] * ca23; ee2 = ee2 + e[2] * ca33; ee2 = ee2 + e[3] * ca43; ee2 = ee2 + e[4] * ca53;
+    ee3 = ee3 + e[0] * ca14; ee3 = ee3 + e[1] * ca24; ee3 = ee3 + e[2] * ca34; ee3 = ee3 + e[3] * ca44; ee3 = ee3 + e[4] * ca54;
+    ee4 = ee4 + e[0] * ca15; ee4 = ee4 + e[1] * ca25; ee4 = ee4 + e[2] * ca35; ee4 = ee4 + e[3] * ca45; ee4 = ee4 + e[4] * ca55;
+    normalize5<EXACT>(ee0, ee1, ee2, ee3, ee4, e, dr);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void rayleigh_layer(double e[5], double wvno2, double gam, double gammk,
+                                               double rho, const LayerTerms &v, DivRange &dr)
+{
+    Ca19 ca;
+    rayleigh_ca19(ca, wvno2, gam, gammk, rho, v);
+    rayleigh_apply<EXACT>(e, ca.c, dr);
+}
+
+// ---- Rayleigh: Dunkin compound-matrix secular function (surfdisp96.f:773-871) -----------------
+template <bool EXACT>
+__device__ double rayleigh_secular(double wvno, double omga, const ModelLds &md, int mmax, int llw,
+                                   int mtop, DivRange &dr, const LibmTabs &LT)
+{
+    double e[5];
+    LayerTerms v;
+    double omega = omga;
+    if (omega < 1.0e-4) omega = 1.0e-4;
+    const double wvno2 = wvno * wvno;
+    {
+        const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
+        const double xka = omega / ah;
+        const double xkb = omega / bh;
+        double wvnop = wvno + xka;
+        double wvnom = fabs(wvno - xka);
+        const double ra = sqrt(wvnop * wvnom);
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        const double rb = sqrt(wvnop * wvnom);
+        const double t = bh / omega;
+        const double gammk = 2.0 * t * t;
+        const double gam = gammk * wvno2;
+        const double gamm1 = gam - 1.0;
+        const double rho1 = md.R(mmax - 1);
+        e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+        e[1] = -rho1 * ra;
+        e[2] = rho1 * (gamm1 - gammk * ra * rb);
+        e[3] = rho1 * rb;
+        e[4] = wvno2 - ra * rb;
+    }
+    for (int m = mtop - 2; m >= 0; --m) {
+        if (m <= mmax - 2 && m >= llw - 1) {
+            const double am = md.A(m), bm = md.Bv(m);
+            const double xka = omega / am;
+            const double xkb = omega / bm;
+            const double t = bm / omega;
+            const double gammk = 2.0 * t * t;
+            const double gam = gammk * wvno2;
+            double wvnop = wvno + xka;
+            double wvnom = fabs(wvno - xka);
+            const double ra = sqrt(wvnop * wvnom);
+            wvnop = wvno + xkb;
+            wvnom = fabs(wvno - xkb);
+            const double rb = sqrt(wvnop * wvnom);
+            const double dpth = md.D(m);
+            const double rho1 = md.R(m);
+            const double p = ra * dpth;
+            const double q = rb * dpth;
+            layer_products(p, q, ra, rb, wvno, xka, xkb, dpth, v, LT);
+            rayleigh_layer<EXACT>(e, wvno2, gam, gammk, rho1, v, dr);
+        }
+    }
+    double result = e[0];
+    if (llw != 1) { // water layer on top (surfdisp96.f:850-866); unreachable from BayHunter
+        const double xka = omega / md.A(0);
+        const double wvnop = wvno + xka;
+        const double wvnom = fabs(wvno - xka);
+        const double ra = sqrt(wvnop * wvnom);
+        const double dpth = md.D(0);
+        const double rho1 = md.R(0);
+        const double p = ra * dpth;
+        const double znul = 1.0e-5;
+        layer_products(p, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
+        const double w0 = -rho1 * v.w;
+        result = v.cosp * e[0] + w0 * e[1];
+    }
+    return result;
+}
+
+// ---- half-space Rayleigh velocity, binary32 throughout (surfdisp96.f:367-388) -----------------
+__device__ float gtsolh_f32(float a, float b)
+{
+    float c = 0.95f * b;
+    for (int i = 0; i < 5; ++i) {
+        const float gamma = b / a;
+        const float kappa = c / b;
+        const float k2 = kappa * kappa;
+        const float gk = gamma * kappa;
+        const float gk2 = gk * gk;
+        const float fac1 = sqrtf(1.0f - gk2);
+        const float fac2 = sqrtf(1.0f - k2);
+        const float tk = 2.0f - k2;
+        const float fr = tk * tk - 4.0f * fac1 * fac2;
+        float frp = -4.0f * (2.0f - k2) * kappa + 4.0f * fac2 * gamma * gamma * kappa / fac1 +
+                    4.0f * fac1 * kappa / fac2;
+        frp = frp / b;
+        c = c - fr / frp;
+    }
+    return c;
+}
+
+// continuation tags: what the pending secular evaluation is for
+enum : int {
+    ST_FIRST = 0, // del1 at the start value c1                      (surfdisp96.f:421-423)
+    ST_STEP = 1,  // del2 at c2 = c1 +- dc                           (:447-449)
+    ST_NEV0 = 2,  // first midpoint inside nevill                    (:582-583)
+    ST_NEVL = 3,  // midpoint / Neville estimate, then top of loop   (:586-...)
+    ST_NEVF = 4   // forced midpoint after the estimate left the bracket (:594-598)
+};
+
+// ---- the per-model search state machine -------------------------------------------------------
+// Everything the reference's driver (surfdisp96.f:172-357), getsol (:390-482) and nevill
+// (:557-686) keep between two secular-function evaluations, for the fundamental mode.
+// `advance(del)` consumes the value of the secular function at `ceval` and either finishes the
+// model or leaves the next phase velocity to evaluate in `ceval` (with `omega` current).
+template <int XSC> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+struct SearchT {
+    int XS = XSC;
+    // constants of the reference's driver (compile-time: they cost no registers)
+    static constexpr double one = 1.0e-2;
+    static constexpr double onea = (double)1.5f;
+    static constexpr double dc = (double)0.005f;     // abs(dble(0.005)) with a default-real literal
+    static constexpr double twopi = 2.0 * 3.141592653589793;
+    static constexpr double pct = (double)0.01f;     // `0.01*ss1` with a default-real literal (:623-626)
+    double cm, betmxd;
+    bool group;
+    int K;
+    int mode;            // highest mode wanted (1 = fundamental)
+    double *cper, *cbper; // LDS, only for mode > 1: c(k) / cb(k) of surfdisp96.f:85, element k at [k*XS]
+    const double *per; // LDS
+    double *xl, *yl;   // LDS Neville tables, element j at [j*XS]
+    double *vel;       // this model's output row (global)
+    bool writer;       // this lane stores results (one lane per model)
+    // state
+    int k, root, st, ifirst, idir, nev, mnev, nctrl, errflag, iq, ift;
+    bool active;
+    double c1, c2, clow, del1, del2, del1st, c3, del3, ck, t1, omega, ceval;
+    float t1a, t1b;
+    unsigned int evals;
+
+    __device__ __forceinline__ void set_period(int kk)
+    {
+        const float h32 = 0.005f;
+        double tt = per[kk];
+        if (group) {
+            t1a = (float)(tt / (double)(1.0f + h32));
+            t1b = (float)(tt / (double)(1.0f - h32));
+            tt = (double)t1a;
+        } else {
+            t1a = (float)tt;
+        }
+        t1 = tt;
+        omega = twopi / t1;
+    }
+
+    // driver set-up (surfdisp96.f:124-217): extremal velocities, start value
+    template <class MD>
+    __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
+                         double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
+                         double *cper_ = nullptr, double *cbper_ = nullptr)
+    {
+        float betmx = -1.e20f, betmn = 1.e20f;
+        int jmn = 0, jsol = 1;
+        // Input sanity.  The reference's loops are bounded only through the model's velocities: with a NaN
+        // or an absurd value in the model it walks the velocity axis (practically) for ever.  A GPU kernel
+        // must end: such a model is reported in-band as failed (err = 1, zeros) without being searched.
+        bool sane = true;
+        for (int i = 0; i < mmax; ++i) {
+            const float bi = md.Bf(i), ai = md.Af(i);
+            const float di = md.Df(i), ri = (float)md.R(i);
+            sane = sane && (ai > 0.0f) && (ai <= 100.0f) && (bi >= 0.0f) && (bi <= 100.0f) && (ri > 0.0f) && (ri < 1.0e6f) &&
+                   (i == mmax - 1 || (di >= 0.0f && di < 1.0e7f));
+            if (bi > 0.01f && bi < betmn) {
+                betmn = bi;
+                jmn = i;
+                jsol = 1;
+            } else if (bi <= 0.01f && ai < betmn) {
+                betmn = ai;
+                jmn = i;
+                jsol = 0;
+            }
+            if (bi > betmx) betmx = bi;
+        }
+        float cc1 = (jsol == 0) ? betmn : gtsolh_f32(md.Af(jmn), md.Bf(jmn));
+        cc1 = 0.95f * cc1;
+        cc1 = 0.90f * cc1;
+        const double cc = (double)cc1;
+        cm = cc;
+        betmxd = (double)betmx;
+        group = igr > 0;
+        K = K_;
+        per = per_;
+        xl = xl_;
+        yl = yl_;
+        vel = vel_;
+        writer = writer_;
+        mode = mode_;
+        cper = cper_;
+        cbper = cbper_;
+        if (mode > 1)
+            for (int i = 0; i < K; ++i) { // do 450: c() = cb() = 0 (every lane of the group writes the same)
+                cper[i * XS] = 0.0;
+                cbper[i * XS] = 0.0;
+            }
+        iq = 1;
+        ift = 999;
+        k = 0; root = 0; st = ST_FIRST; ifirst = 1;
+        active = valid && K > 0 && sane;
+        errflag = 0;
+        if (valid && !sane) {
+            errflag = 1;
+            if (writer_)
+                for (int i = 0; i < K_; ++i) vel_[i] = 0.0;
+        }
+        c1 = cc; c2 = 0.0; clow = cc; del1 = del2 = del1st = 0.0;
+        c3 = del3 = ck = 0.0;
+        idir = 1; nev = 1; mnev = 1; nctrl = 1;
+        t1a = t1b = 0.f;
+        t1 = 1.0; omega = 1.0;
+        evals = 0;
+        if (active) set_period(0);
+        ceval = c1;
+    }
+
+    // label 1700/1750: the current mode found no root at period k
+    __device__ __forceinline__ void fail_mode()
+    {
+        if (iq == 1) errflag = 1; // higher modes fail silently (:313)
+        ift = k;
+        if (writer)
+            for (int i = k; i < K; ++i) vel[i] = 0.0;
+    }
+
+    // Set up the root search of period k of mode iq (initial guess logic, :253-272), moving on to
+    // the next mode when the period list is exhausted or a previous mode already failed here.
+    __device__ void next_search()
+    {
+        for (;;) {
+            bool over = (k >= K);
+            if (!over && k >= ift) { // `if(k.ge.ift) go to 1700`
+                fail_mode();
+                over = true;
+            }
+            if (!over) break;
+            if (iq >= mode) {
+                active = false;
+                return;
+            }
+            iq = iq + 1;
+            k = 0;
+        }
+        set_period(k);
+        root = 0;
+        if (mode == 1) { // fundamental mode only: c(k-1) is still in a register
+            ifirst = 0;
+            c1 = ck - onea * dc;
+            clow = cm;
+        } else if (k == 0) {
+            c1 = cper[0] + one * dc; // iq > 1 here (iq == 1, k == 0 is set up by init)
+            clow = c1;
+            ifirst = 1;
+        } else if (iq > 1) {
+            ifirst = 0;
+            clow = cper[k * XS] + one * dc;
+            c1 = cper[(k - 1) * XS];
+            if (c1 < clow) c1 = clow;
+        } else {
+            ifirst = 0;
+            c1 = cper[(k - 1) * XS] - onea * dc;
+            clow = cm;
+        }
+        st = ST_FIRST;
+        ceval = c1;
+    }
+
+    // Look-ahead: candidate 0 is the pending request; candidate r > 0 is the phase velocity the r-th
+    // request from now will most probably be for -- further bracket steps while stepping (:437-449),
+    // further halvings towards the side on which a straight line through the bracket ends puts the
+    // root while refining (:600-660).  Purely a guess about which values will be asked for: a value
+    // is only ever consumed by advance() if it was computed for exactly the (ceval, omega) requested.
+    __device__ __forceinline__ double candidate(int r) const
+    {
+        double q = ceval;
+        if (st == ST_FIRST || st == ST_STEP) {
+            const bool up = (st == ST_FIRST) || (idir > 0);
+            for (int j = 0; j < r; ++j) q = up ? q + dc : q - dc;
+        } else {
+            double lo = c1, hi = c2; // the function keeps the sign of del1 at `lo`
+            const double w = c2 - c1;
+            for (int j = 0; j < r; ++j) {
+                const double t = del1 * (c2 - q) + del2 * (q - c1); // (c2 - c1) * linear model at q
+                const bool neg_lin = (t < 0.0) != (w < 0.0);
+                const bool differs = neg_lin != (del1 < 0.0);
+                lo = differs ? lo : q;
+                hi = differs ? q : hi;
+                q = 0.5 * (lo + hi);
+            }
+        }
+        return q;
+    }
+
+    __device__ void advance(double del)
+    {
+        ++evals;
+        // `todo`: 0 nothing, 1 prepare next bracket step, 2 root search failed (iret = -1),
+        // 3 refinement finished with c3, 4 nevill top-of-loop, 5 nevill post-bracket section,
+        // 6 root found
+        int todo = 0;
+        switch (st) {
+        case ST_FIRST:
+            del1 = del;
+            if (ifirst == 1) del1st = del1;
+            idir = (ifirst != 1 && signs_differ(del1st, del1)) ? -1 : +1;
+            todo = 1;
+            break;
+        case ST_STEP:
+            del2 = del;
+            if (signs_differ(del1, del2)) { // bracketed: enter nevill with (c1,c2,del1,del2)
+                c3 = 0.5 * (c1 + c2);
+                ceval = c3;
+                st = ST_NEV0;
+            } else {
+                c1 = c2;
+                del1 = del2;
+                if (c1 < cm || c1 >= betmxd + dc) todo = 2;
+                else todo = 1;
+            }
+            break;
+        case ST_NEV0:
+            del3 = del;
+            nev = 1;
+            nctrl = 1;
+            mnev = 1;
+            todo = 4;
+            break;
+        case ST_NEVL:
+            del3 = del;
+            todo = 4;
+            break;
+        case ST_NEVF:
+            del3 = del;
+            todo = 5;
+            break;
+        }
+        if (todo == 4) { // label 100 of nevill
+            nctrl = nctrl + 1;
+            if (nctrl >= 100) {
+                todo = 3;
+            } else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {
+                nev = 0;
+                c3 = 0.5 * (c1 + c2);
+                ceval = c3;
+                st = ST_NEVF;
+                todo = 0;
+            } else {
+                todo = 5;
+            }
+        }
+        if (todo == 5) {
+            const double s13 = del1 - del3;
+            const double s32 = del3 - del2;
+            if (signs_differ(del3, del1)) {
+                c2 = c3;
+                del2 = del3;
+            } else {
+                c1 = c3;
+                del1 = del3;
+            }
+            if (fabs(c1 - c2) <= 1.0e-6 * c1) {
+                todo = 3;
+            } else {
+                if (signs_differ(s13, s32)) nev = 0;
+                const double ss1 = fabs(del1), s1 = pct * ss1;
+                const double ss2 = fabs(del2), s2 = pct * ss2;
+                bool halve = (s1 > ss2 || s2 > ss1 || nev == 0);
+                if (!halve) {
+                    if (nev == 2) {
+                        xl[mnev * XS] = c3;
+                        yl[mnev * XS] = del3;
+                    } else {
+                        xl[0] = c1;
+                        yl[0] = del1;
+                        xl[XS] = c2;
+                        yl[XS] = del2;
+                        mnev = 1;
+                    }
+                    const double ym = yl[mnev * XS];
+                    for (int kk = 1; kk <= mnev; ++kk) {
+                        const int j = mnev - kk;
+                        const double yj = yl[j * XS];
+                        const double denom = ym - yj;
+                        if (fabs(denom) < 1.0e-10 * fabs(ym)) {
+                            halve = true;
+                            break;
+                        }
+                        xl[j * XS] = (-yj * xl[(j + 1) * XS] + ym * xl[j * XS]) / denom;
+                    }
+                    if (!halve) {
+                        c3 = xl[0];
+                        nev = 2;
+                        mnev = mnev + 1;
+                        if (mnev > 10) mnev = 10;
+                    }
+                }
+                if (halve) {
+                    c3 = 0.5 * (c1 + c2);
+                    nev = 1;
+                    mnev = 1;
+                }
+                ceval = c3;
+                st = ST_NEVL;
+                todo = 0;
+            }
+        }
+        if (todo == 3) { // getsol after nevill (:468-471)
+            c1 = c3;
+            todo = (c1 > betmxd) ? 2 : 6;
+        }
+        if (todo == 2 || todo == 6) { // a root search ended: 6 = found c1, 2 = failed
+            bool period_done = false;
+            double c1b = 0.0; // the "c1" the driver uses after the (optional) second search
+            if (root == 0) {
+                if (todo == 2) { // no root: err (fundamental mode only), zero-fill, next mode (:313-354)
+                    fail_mode();
+                    if (iq >= mode) {
+                        active = false;
+                    } else {
+                        iq = iq + 1;
+                        k = 0;
+                        next_search();
+                    }
+                } else {
+                    ck = c1;
+                    if (mode > 1) cper[k * XS] = c1;
+                    if (group) { // second root at the slightly longer period (:282-287)
+                        root = 1;
+                        t1 = (double)t1b;
+                        omega = twopi / t1;
+                        ifirst = 0;
+                        clow = ((mode > 1) ? cbper[k * XS] : 0.0) + one * dc; // cb(k) of the previous mode
+                        c1 = c1 - onea * dc;
+                        st = ST_FIRST;
+                        ceval = c1;
+                    } else {
+                        period_done = true;
+                    }
+                }
+            } else {
+                c1b = (todo == 2) ? ck : c1; // second root failed: reuse the first (:291-293)
+                if (mode > 1) cbper[k * XS] = c1b;
+                period_done = true;
+            }
+            if (period_done) {
+                const float cc0 = (float)ck;
+                double out;
+                if (!group) {
+                    out = (double)cc0;
+                } else { // all binary32 (:305)
+                    const float cc1s = (float)c1b;
+                    const float gvel =
+                        (1.0f / t1a - 1.0f / t1b) / (1.0f / (t1a * cc0) - 1.0f / (t1b * cc1s));
+                    out = (double)gvel;
+                }
+                if (writer) vel[k] = out;
+                k = k + 1;
+                next_search();
+            }
+            todo = 0;
+        }
+        if (todo == 1) { // label 1000 of getsol: next bracket step (:437-446)
+            c2 = (idir > 0) ? c1 + dc : c1 - dc;
+            if (c2 <= clow) {
+                idir = +1;
+                c1 = clow;
+                c2 = c1 + dc;
+                // dc > 0, so the retried c2 = clow + dc is above clow: no further loop
+            }
+            ceval = c2;
+            st = ST_STEP;
+        }
+    }
+};
+using SearchRt = SearchT<0>;
+

@@ -1,0 +1,604 @@
+// bayhunter_amd/csrc/swd_group_kernel.hip -- Rayleigh/Love dispersion with G lanes per model (small batches).
+// Same search, same bits as swd_kernel.hip (one lane per model); see the block comment at the kernel.
+// Built with -mllvm -disable-machine-licm (Makefile): the round loop carries ~60 distinct f64 constants of the
+// glibc-exact sincos / exp; hoisted out of the loop they cost more registers than the kernel has.
+#include "../../include/bh_engine.h"
+#include "bh_device.h"
+#include <cstdlib>
+#define BH_HD __device__ __forceinline__
+#define BH_TAB static __device__ const
+#include "bh_libm.h"
+
+namespace {
+#include "swd_common.h"
+
+// =================================================================================================
+// Kernel 2: G lanes = one model (64/G models per wavefront), G chosen at launch time.
+// For batches that cannot fill the chip with one lane per model (B = 4096 gives only 64
+// wavefronts for 1024 SIMDs) the work of ONE secular evaluation is spread over the G lanes of
+// the model's group:
+//   phase A  lane li computes the layer terms of layers li, li+G, ... (the transcendental-heavy
+//            part: sqrt, sin/cos or exp, the compound-matrix entries) and parks them in LDS;
+//   phase B  the strictly sequential bottom-up recursion over the parked layers.
+//            Rayleigh, G >= 5: lane li owns component (li mod 5) of the 5-vector: it forms
+//            ee(i) = sum_j e(j)*ca(j,i) from column i of the parked matrix, the five values are
+//            exchanged through LDS, every lane takes the max-norm, divides its own component and
+//            the normalised vector is exchanged again.  Otherwise (Love, or G < 5) every lane of
+//            the group runs the whole recursion redundantly.
+//            Either way all lanes of a group end up with the same secular value and step the
+//            same search state; no broadcast is needed.
+// Every floating-point operation and its order are those of kernel 1: the kernels return
+// identical bits.  All dispersion targets of a call go into one launch (blockIdx.y = target),
+// so Rayleigh and Love wavefronts share the chip.
+// A workgroup is GROUP_WPB independent wavefronts that only share the LDS copy of the libm tables;
+// after start-up there is no barrier: LDS operations of a wavefront execute in order, wave_sync()
+// only pins the compiler's ordering.  Look-ahead, Love's in-group trials, the processing order and the
+// two depth classes of ragged batches are described at their code.
+// =================================================================================================
+constexpr int CA_STRIDE = 26;
+constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used): up to 4 trials share a row
+
+// Phase B of the group kernel, Rayleigh.  `cam` = this model's parked layers (column-major
+// 5x5 each), e = half-space vector on entry / surface vector on exit.
+//   PAR5   lane owns component `col`: one dot product per layer, the five results are exchanged
+//          with ds_bpermute (faster than an LDS write/read round trip: 56 vs 116 cycles) and every
+//          lane normalises all five itself -- one exchange per layer, no branch.
+//   !PAR5  every lane runs the full 5x5 product (used for G < 5 and for the exact re-run).
+//   RAGGED the wavefront holds models with different layer counts (or a water layer): layers a
+//          model does not have are masked with selects; the uniform case has no masking at all.
+template <bool PAR5, bool RAGGED, bool EXACT>
+__device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *cam, int col,
+                                                     int gbase, int mtop, int mmax, int llw,
+                                                     DivRange &dr)
+{
+    // uniform wavefronts: the layer count is the same in every lane -> scalar loop control
+    const int mstart = (RAGGED ? mtop : __builtin_amdgcn_readfirstlane(mmax)) - 2;
+    if (PAR5) {
+        // software-pipelined: the column of layer m-1 is fetched while layer m is exchanged
+        const double *cc = cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE + 5 * col;
+        double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4];
+#pragma unroll 3
+        for (int m = mstart; m >= 0; --m) {
+            const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+            const double *cn = cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE + 5 * col;
+            const double n0 = cn[0], n1 = cn[1], n2 = cn[2], n3 = cn[3], n4 = cn[4];
+            double ee = 0.0;
+            ee = ee + e[0] * c0;
+            ee = ee + e[1] * c1;
+            ee = ee + e[2] * c2;
+            ee = ee + e[3] * c3;
+            ee = ee + e[4] * c4;
+            const double v0 = __shfl(ee, gbase + 0), v1 = __shfl(ee, gbase + 1), v2 = __shfl(ee, gbase + 2),
+                         v3 = __shfl(ee, gbase + 3), v4 = __shfl(ee, gbase + 4);
+            double en[5];
+            DivRange d2 = dr;
+            normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);
+            if (on) dr = d2;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+        }
+    } else {
+        for (int m = mstart; m >= 0; --m) {
+            const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+            const double *cc = cam + (size_t)m * CA_STRIDE;
+            double ee[5], en[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc = acc + e[j] * cc[5 * i + j];
+                ee[i] = acc;
+            }
+            DivRange d2 = dr;
+            normalize5<EXACT>(ee[0], ee[1], ee[2], ee[3], ee[4], en, d2);
+            if (on) dr = d2;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
+        }
+    }
+}
+
+// Phase B of the group kernel, Love: parked per layer (cosq, y, z, xmu, rcp(xmu)).
+template <bool RAGGED, bool EXACT>
+__device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
+                                                 int mmax, int llw, DivRange &dr)
+{
+    const int mstart = (RAGGED ? mtop : __builtin_amdgcn_readfirstlane(mmax)) - 2;
+    // software-pipelined: the terms of layer m-1 are fetched while layer m is processed
+    const double2 *src = reinterpret_cast<const double2 *>(cam + (size_t)(mstart > 0 ? mstart : 0) * CA_STRIDE);
+    double2 p0 = src[0], p1 = src[1], p2 = src[2];
+#pragma unroll 3
+    for (int m = mstart; m >= 0; --m) {
+        const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
+        const double2 *nx = reinterpret_cast<const double2 *>(cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE);
+        const double2 q0 = nx[0], q1 = nx[1], q2 = nx[2];
+        double n1 = e1, n2 = e2;
+        DivRange d2 = dr;
+        love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
+        if (on) {
+            e1 = n1;
+            e2 = n2;
+            dr = d2;
+        }
+        p0 = q0; p1 = q1; p2 = q2;
+    }
+}
+ // doubles per parked layer: 25 (Rayleigh, column-major 5x5) / 4 (Love)
+
+__device__ __forceinline__ void park_ca25(double *dst, const Ca19 &c)
+{
+    // column i (0-based) at dst[5*i + j] = ca(j+1, i+1)
+    const double ca11 = c.c[0], ca12 = c.c[1], ca13 = c.c[2], ca14 = c.c[3], ca15 = c.c[4];
+    const double ca21 = c.c[5], ca23 = c.c[6], ca24 = c.c[7], ca22 = c.c[8];
+    const double ca41 = c.c[9], ca42 = c.c[10], ca43 = c.c[11], ca51 = c.c[12], ca53 = c.c[13];
+    const double ca31 = c.c[14], ca32 = c.c[15], ca33 = c.c[16], ca34 = c.c[17], ca35 = c.c[18];
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    d2[0] = make_double2(ca11, ca21);  d2[1] = make_double2(ca31, ca41);   // col 1: 11 21 31 41 51
+    d2[2] = make_double2(ca51, ca12);  d2[3] = make_double2(ca22, ca32);   // col 2: 12 22 32 42 52
+    d2[4] = make_double2(ca42, ca41);  d2[5] = make_double2(ca13, ca23);   // (ca52 = ca41) col 3: 13 23 33 43 53
+    d2[6] = make_double2(ca33, ca43);  d2[7] = make_double2(ca53, ca14);   // col 4: 14 24 34 44 54
+    d2[8] = make_double2(ca24, ca34);  d2[9] = make_double2(ca22, ca21);   // (ca44 = ca22, ca54 = ca21)
+    d2[10] = make_double2(ca15, ca14); d2[11] = make_double2(ca35, ca12);  // col 5: 15 25 35 45 55
+    d2[12] = make_double2(ca11, 0.0);                                      // (ca25=ca14, ca45=ca12, ca55=ca11)
+}
+
+// Wavefronts per workgroup: they are independent (no barrier after start-up) and only share one LDS
+// copy of the libm tables, which is what lets 8 wavefronts fit a CU's 160 KB of LDS.
+constexpr int GROUP_WPB = 2;
+constexpr int LIBM_TAB_PAD = (LIBM_TAB_BYTES + 15) & ~15;
+
+// LDS ordering inside ONE wavefront: its LDS instructions execute in order, so a write by one lane is
+// visible to a later read by another lane of the same wavefront; only the compiler must not reorder.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
+{
+    const int cls = (A.split != nullptr) ? (int)blockIdx.z : 1; // 0 = the deep models of a ragged batch, 1 = the rest
+    const int G = A.lanes[cls];
+    const SwdTarget T = A.t[blockIdx.y];
+    int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
+    while (J > 1 && G * J > BH_WAVE) --J;
+    // Love only: further trials INSIDE a lane group.  Its recursion is scalar (every lane of the group
+    // would repeat it), so lane l runs trial l mod JL instead; only the layer terms cost JL passes.
+    const int JL = (T.iwave == 1 && T.inlook > 1) ? T.inlook : 1;
+    const int LPM = G * J;         // lanes per model: J groups of G lanes, group r evaluates candidate r
+    const int MPW = BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    const int lane = threadIdx.x & (BH_WAVE - 1);
+    const int wave = threadIdx.x / BH_WAVE;
+    const int wid = blockIdx.x * GROUP_WPB + wave; // wavefront index inside this target's row of the grid
+    // the workgroup's shared copy of the libm tables, then one private region per wavefront
+    // this launch's range of the processing order (see SwdMultiArgs::split)
+    int lo = 0, hi = A.B;
+    if (A.split != nullptr) {
+        const int ndeep = A.split[0];
+        if (cls == 0) hi = ndeep;
+        else lo = ndeep;
+    }
+    if (lo + (int)blockIdx.x * GROUP_WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
+    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * GROUP_WPB);
+    __syncthreads();
+    if (lo + wid * MPW >= hi) return;
+    unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
+    const bool spare = lane >= MPW * LPM;
+    const int g = spare ? 0 : lane / LPM;        // model slot inside the wave
+    const int rr = spare ? 0 : (lane % LPM) / G; // which candidate this lane's group evaluates
+    const int li = spare ? 0 : lane % G;         // this lane's index inside its group
+    const int slot = g * J + rr;                 // group index inside the wave
+    const int sidx = lo + wid * MPW + g; // position in the processing order
+    const bool valid = sidx < hi;
+    const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
+    const int Lmax = A.rows[cls]; // LDS rows per model of this class (>= every layer count it meets)
+    const int K = T.K;
+    const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
+
+    // LDS carve-up of the wavefront's region (all offsets multiples of 16 B)
+    double *ca = reinterpret_cast<double *>(smem);                 // [MPW*J][Lmax][CA_STRIDE]
+    double *xs = ca + (size_t)MPW * J * Lmax * CA_STRIDE;          // [11][MPW]
+    double *ys = xs + NEV_MAX * MPW;
+    double *per = ys + NEV_MAX * MPW;                              // [K]
+    float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
+    unsigned char *after = reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15);
+    double *cpl = reinterpret_cast<double *>(after); // [2][Kmax][MPW], only if a target has mode > 1
+
+    for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
+    // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
+    // layer-major input), binary32 rounding like the f2py boundary
+    for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
+        const int l = idx / MPW, mg = idx % MPW;
+        const int sb = lo + wid * MPW + mg;
+        const int b = sb < hi ? (A.perm ? A.perm[sb] : sb) : 0;
+        float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
+        if (sb < hi && l < A.nlay[b]) {
+            const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
+            fd = (float)T.h[o];
+            fa = (float)T.vp[o];
+            fb = (float)T.vs[o];
+            fr = (float)T.rho[o];
+        }
+        mdl[(0 * Lmax + l) * MPW + mg] = fd;
+        mdl[(1 * Lmax + l) * MPW + mg] = fa;
+        mdl[(2 * Lmax + l) * MPW + mg] = fb;
+        mdl[(3 * Lmax + l) * MPW + mg] = fr;
+    }
+    const int mmax = valid ? A.nlay[ib] : 2;
+    int mtop = mmax;
+    for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    mtop = __builtin_amdgcn_readfirstlane(mtop);
+    wave_sync();
+    ModelLdsRt md;
+    md.S = MPW;
+    md.d = mdl + 0 * Lmax * MPW + g;
+    md.a = mdl + 1 * Lmax * MPW + g;
+    md.b = mdl + 2 * Lmax * MPW + g;
+    md.rho = mdl + 3 * Lmax * MPW + g;
+    const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
+    double *cam = ca + (size_t)slot * Lmax * CA_STRIDE; // this group's parked layers
+    const bool par5 = (G >= 5) && !(Gflags & 0x100);
+    const int gbase = slot * G; // first lane of this group
+    // one layer count for the whole wavefront and no water layer: the recursion needs no masking
+    const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
+    const int col = li % 5;                          // the 5-vector component this lane owns
+
+    SearchRt S;
+    S.XS = MPW;
+    S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g);
+
+    // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
+    // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
+    double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
+    const bool prof = (A.neval != nullptr);
+    long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
+    const unsigned long long w_start = prof ? wall_clock64() : 0ull, c_start = prof ? clock64() : 0ull;
+    unsigned int nrounds = 0;
+    while (__ballot(S.active) != 0ull) {
+        ++nrounds;
+        // All lanes take part in the evaluation (finished models compute on stale values).
+        if (prof) t0 = clock64();
+        const double omg = S.omega;
+        const int cb = rr * JL + (li % JL); // the trial this lane carries through the recursion
+        const double cev = (J * JL == 1) ? S.ceval : S.candidate(cb);
+        const double wvno = omg / cev;
+        double del;
+        if (ifunc == 2) {
+            double omega = omg;
+            if (omega < 1.0e-4) omega = 1.0e-4;
+            const double wvno2 = wvno * wvno;
+            if (omega != c_omega) {
+                c_omega = omega;
+                if (li <= mmax - 2) {
+                    const double am = md.A(li), bm = md.Bv(li);
+                    c_xka = omega / am;
+                    c_xkb = omega / bm;
+                    const double t = bm / omega;
+                    c_gammk = 2.0 * t * t;
+                }
+                const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
+                h_xka = omega / ah;
+                h_xkb = omega / bh;
+                const double t = bh / omega;
+                h_gammk = 2.0 * t * t;
+            }
+            // ---- phase A: layer terms, one layer per lane (strided by G) -----------------------
+            for (int m = li; m <= mmax - 2; m += G) {
+                if (m >= llw - 1) {
+                    double xka, xkb, gammk;
+                    if (m == li) {
+                        xka = c_xka;
+                        xkb = c_xkb;
+                        gammk = c_gammk;
+                    } else { // deep models: further rounds are computed on the fly
+                        const double am = md.A(m), bm = md.Bv(m);
+                        xka = omega / am;
+                        xkb = omega / bm;
+                        const double t = bm / omega;
+                        gammk = 2.0 * t * t;
+                    }
+                    const double gam = gammk * wvno2;
+                    double wvnop = wvno + xka;
+                    double wvnom = fabs(wvno - xka);
+                    const double ra = sqrt(wvnop * wvnom);
+                    wvnop = wvno + xkb;
+                    wvnom = fabs(wvno - xkb);
+                    const double rb = sqrt(wvnop * wvnom);
+                    const double dpth = md.D(m);
+                    const double rho1 = md.R(m);
+                    LayerTerms v;
+                    layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v, LT);
+                    Ca19 c;
+                    rayleigh_ca19(c, wvno2, gam, gammk, rho1, v);
+                    park_ca25(cam + (size_t)m * CA_STRIDE, c);
+                }
+            }
+            // half-space E vector (surfdisp96.f:800-808), redundantly in every lane
+            double e[5];
+            {
+                const double xka = h_xka, xkb = h_xkb, gammk = h_gammk;
+                double wvnop = wvno + xka;
+                double wvnom = fabs(wvno - xka);
+                const double ra = sqrt(wvnop * wvnom);
+                wvnop = wvno + xkb;
+                wvnom = fabs(wvno - xkb);
+                const double rb = sqrt(wvnop * wvnom);
+                const double gam = gammk * wvno2;
+                const double gamm1 = gam - 1.0;
+                const double rho1 = md.R(mmax - 1);
+                e[0] = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+                e[1] = -rho1 * ra;
+                e[2] = rho1 * (gamm1 - gammk * ra * rb);
+                e[3] = rho1 * rb;
+                e[4] = wvno2 - ra * rb;
+            }
+            wave_sync();
+            if (prof) t1c = clock64();
+            // ---- phase B: the sequential recursion, bottom-up over the parked layers -----------
+            {
+                double e0[5] = {e[0], e[1], e[2], e[3], e[4]};
+                DivRange dr;
+                dr.reset();
+                if (par5) {
+                    if (ragged) rayleigh_chain_group<true, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<true, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                } else {
+                    if (ragged) rayleigh_chain_group<false, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<false, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                }
+                if (!dr.ok() && S.active) { // out-of-range operand somewhere: verbatim re-run (whole groups agree)
+                    e[0] = e0[0]; e[1] = e0[1]; e[2] = e0[2]; e[3] = e0[3]; e[4] = e0[4];
+                    rayleigh_chain_group<false, true, true>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                }
+            }
+            del = e[0];
+            if (llw != 1) { // water layer on top (surfdisp96.f:850-866)
+                const double xka = omega / md.A(0);
+                const double wvnop = wvno + xka;
+                const double wvnom = fabs(wvno - xka);
+                const double ra = sqrt(wvnop * wvnom);
+                const double dpth = md.D(0);
+                const double rho1 = md.R(0);
+                const double znul = 1.0e-5;
+                LayerTerms v;
+                layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
+                const double w0 = -rho1 * v.w;
+                del = v.cosp * e[0] + w0 * e[1];
+            }
+            wave_sync();
+        } else {
+            const double omega = omg;
+            if (omega != c_omega) {
+                c_omega = omega;
+                if (li <= mmax - 2) c_xkb = omega / md.Bv(li);
+                const double beta1 = md.Bv(mmax - 1);
+                h_xkb = omega / beta1;
+                h_gammk = 1.0 / (beta1 * beta1); // e2 of the half-space (surfdisp96.f:731)
+            }
+            // ---- phase A (Love): cosq, y, z, xmu per layer, for each of the group's JL trials ----------
+            for (int jj = 0; jj < JL; ++jj) {
+                const double wv = (JL == 1) ? wvno : omg / S.candidate(rr * JL + jj);
+                for (int m = li; m <= mmax - 2; m += G) {
+                    if (m >= llw - 1) {
+                        const double beta1 = md.Bv(m);
+                        const double rho1 = md.R(m);
+                        const double dm = md.D(m);
+                        const double xmu = rho1 * beta1 * beta1;
+                        const double xkb = (m == li) ? c_xkb : omega / beta1;
+                        const double wvnop = wv + xkb;
+                        const double wvnom = fabs(wv - xkb);
+                        const double rb = sqrt(wvnop * wvnom);
+                        const double q = dm * rb;
+                        double cosq, y, z;
+                        if (wv < xkb) {
+                            double sinq;
+                            bh_sincos(q, &sinq, &cosq, LT);
+                            y = sinq / rb;
+                            z = -rb * sinq;
+                        } else if (wv == xkb) {
+                            cosq = 1.0;
+                            y = dm;
+                            z = 0.0;
+                        } else {
+                            double fac = 0.0;
+                            if (q < 16.0) fac = bh_exp(-2.0 * q, LT);
+                            cosq = (1.0 + fac) * 0.5;
+                            const double sinq = (1.0 - fac) * 0.5;
+                            y = sinq / rb;
+                            z = rb * sinq;
+                        }
+                        double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE + LOVE_TERMS * jj);
+                        dst[0] = make_double2(cosq, y);
+                        dst[1] = make_double2(z, xmu);
+                        dst[2] = make_double2(bh_rcp_refined(xmu), 0.0);
+                    }
+                }
+            }
+            double e1, e2;
+            {
+                const double rho1 = md.R(mmax - 1);
+                const double xkb = h_xkb;
+                const double wvnop = wvno + xkb;
+                const double wvnom = fabs(wvno - xkb);
+                const double rb = sqrt(wvnop * wvnom);
+                e1 = rho1 * rb;
+                e2 = h_gammk;
+            }
+            wave_sync();
+            if (prof) t1c = clock64();
+            {
+                const double s1 = e1, s2 = e2;
+                DivRange dr;
+                dr.reset();
+                const double *camt = cam + LOVE_TERMS * (li % JL); // this lane's trial
+                if (ragged) love_chain_group<true, false>(e1, e2, camt, mtop, mmax, llw, dr);
+                else love_chain_group<false, false>(e1, e2, camt, mtop, mmax, llw, dr);
+                if (!dr.ok() && S.active) {
+                    e1 = s1;
+                    e2 = s2;
+                    love_chain_group<true, true>(e1, e2, camt, mtop, mmax, llw, dr);
+                }
+            }
+            del = e1;
+            wave_sync();
+        }
+        if (prof) t2c = clock64();
+        // Every lane of the model can read all J (velocity, value) pairs; the search consumes them for
+        // as long as its next request is the very velocity (at the same omega) the next group evaluated.
+        {
+            bool live = S.active;
+            const int Jtot = J * JL;
+            for (int j = 0; j < Jtot; ++j) {
+                double dj = del;
+                if (Jtot > 1) {
+                    const int src = (g * J + j / JL) * G + (j % JL); // a lane that carried trial j
+                    const double cj = __shfl(cev, src);
+                    dj = __shfl(del, src);
+                    // trial 0 IS the pending request (consumed unconditionally, also when a broken model
+                    // has driven the search to NaN); a later trial only if the search now asks for it
+                    if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
+                }
+                if (__ballot(live) == 0ull) break;
+                if (live) S.advance(dj);
+            }
+        }
+        if (prof) {
+            const long long t3 = clock64();
+            tA += t1c - t0;
+            tB += t2c - t1c;
+            tS += t3 - t2c;
+        }
+    }
+    if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
+    if (prof) {
+        unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) {
+            atomicAdd(A.neval, tot);
+            // development aid: wave-cycles per phase, [1..3] Rayleigh A/B/state, [4..6] Love
+            const int o = (ifunc == 2) ? 1 : 4;
+            atomicAdd(A.neval + o, (unsigned long long)tA);
+            atomicAdd(A.neval + o + 1, (unsigned long long)tB);
+            atomicAdd(A.neval + o + 2, (unsigned long long)tS);
+            const unsigned long long widx = atomicAdd(A.neval + 7, 1ull);
+            if (widx < BH_TRACE_WAVES) { // development aid: one record per wavefront (tools/gpu_trace.py)
+                unsigned long long *r = A.neval + BH_COUNTER_WORDS + 4 * widx;
+                unsigned hwid, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                hwid = (hwid & 0xffffu) | ((xcc & 0xfu) << 16);
+                r[0] = w_start;
+                r[1] = wall_clock64();
+                r[2] = clock64() - c_start;
+                r[3] = (unsigned long long)nrounds | ((unsigned long long)ifunc << 32) | ((unsigned long long)hwid << 36);
+            }
+        }
+    }
+}
+
+size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
+{
+    const int MPW = BH_WAVE / (G * J);
+    return ((size_t)MPW * J * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
+            (size_t)((Kmax + 1) & ~1)) * sizeof(double) +
+           (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) +
+           (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
+}
+
+} // namespace
+
+// LDS of one workgroup = shared libm tables + GROUP_WPB wavefront regions
+size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
+{
+    return LIBM_TAB_PAD + GROUP_WPB * ((group_lds_bytes(G, J, Lmax, Kmax, maxmode) + 15) & ~(size_t)15);
+}
+
+// A wavefront's LDS region small enough for 8 wavefronts (4 workgroups) per CU of 160 KB
+constexpr size_t WAVE_LDS_TARGET = (160 * 1024 / 4 - LIBM_TAB_PAD) / GROUP_WPB;
+constexpr size_t WG_LDS_CAP = 64 * 1024;
+
+int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
+{
+    int kmax = 0, maxmode = 1;
+    for (int t = 0; t < a0.ntargets; ++t) {
+        kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
+        maxmode = a0.t[t].mode > maxmode ? a0.t[t].mode : maxmode;
+    }
+    static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
+    SwdMultiArgs a = a0;
+    const bool two = a0.split != nullptr && a0.Lcut < a0.Lmax;
+    if (!two) a.split = nullptr;
+    size_t wave_lds = 0;
+    int nwaves = 1;
+    for (int cls = two ? 0 : 1; cls <= 1; ++cls) {
+        const int rows = (two && cls == 1) ? a0.Lcut : a0.Lmax;
+        // fewer models per wavefront (more lanes per model) until the parked layers fit: first the
+        // residency target, at the latest the 64 KB a workgroup may ask for
+        int G = G0;
+        auto trials = [&](int g, int t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && g * J > BH_WAVE) --J;
+            return J;
+        };
+        auto wave_bytes = [&](int g) {
+            size_t w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const size_t l = (group_lds_bytes(g, trials(g, t), rows, kmax, maxmode) + 15) & ~(size_t)15;
+                w = l > w ? l : w;
+            }
+            return w;
+        };
+        auto waves = [&](int g) {
+            long w = 0;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                w += (a.B + mpw - 1) / mpw;
+            }
+            return w;
+        };
+        auto most_models = [&](int g) {
+            int m = 1;
+            for (int t = 0; t < a.ntargets; ++t) {
+                const int mpw = BH_WAVE / (g * trials(g, t));
+                m = mpw > m ? mpw : m;
+            }
+            return m;
+        };
+        // a batch that leaves half the chip idle anyway: one lane per layer of the deepest model of the
+        // class (a single pass over the layers) instead of lanes for the typical depth
+        // (only where that costs neither look-ahead nor residency)
+        for (int Gwide = rows - 1 > 16 ? 16 : rows - 1; Gwide > G; --Gwide) {
+            bool same = waves(Gwide) <= 256;
+            for (int t = 0; t < a.ntargets; ++t) same = same && trials(Gwide, t) == trials(G, t);
+            if (same) {
+                G = Gwide;
+                break;
+            }
+        }
+        while (most_models(G) > 1 && wave_bytes(G) > WAVE_LDS_TARGET) G += 1;
+        while (G < BH_WAVE && LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) G += 1;
+        if (LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) return -1;
+        a.rows[cls] = rows;
+        a.lanes[cls] = G;
+        const size_t wb = wave_bytes(G);
+        wave_lds = wb > wave_lds ? wb : wave_lds;
+        for (int t = 0; t < a.ntargets; ++t) {
+            const int mpw = BH_WAVE / (G * trials(G, t));
+            const int nx = (a.B + mpw - 1) / mpw; // worst case: the whole batch is in this class
+            nwaves = nx > nwaves ? nx : nwaves;
+        }
+    }
+    if (!two) {
+        a.rows[0] = a.rows[1];
+        a.lanes[0] = a.lanes[1];
+    }
+    const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
+    const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
+    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+    return 0;
+}
+
