@@ -546,12 +546,12 @@ int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family
     return BH_OK;
 }
 
-int bh_debug_counters(bh_engine *e, uint64_t out[8])
+int bh_debug_counters(bh_engine *e, uint64_t out[16])
 {
     if (!e || !out) return BH_EINVAL;
     if (!e->counter.p) return fail(e, BH_EINVAL, "counting was never enabled");
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, e->counter.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(out, e->counter.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return BH_OK;
 }
 

@@ -10,7 +10,7 @@
 //                          keep, move counters, proposal-width adaptation every 1000 iterations
 //                          (:425-450, :584-587).
 // The forward models + likelihood between the two are bh_evaluate_batch on device pointers.
-// Random numbers: Philox4x32-10, counter = (chain, iteration, purpose), key = seed -- every draw is
+// Random numbers: Philox4x32-10, counter = (global chain index, iteration, purpose), key = seed -- every draw is
 // a pure function of its coordinates, so results do not depend on scheduling.  (The reference uses
 // one Mersenne-Twister stream per chain; trajectories therefore agree statistically, not draw by
 // draw.  The draw-by-draw replay of the reference is bayhunter_amd/chains.py.)  For testing, the
@@ -64,11 +64,14 @@ __device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, 
     Philox ph;
     // every draw gets its own 64 bits of Philox output: draws of one iteration must be independent of
     // each other (a normal deviate correlated with the choice of the move makes the walk drift)
+    // the counter carries the chain's GLOBAL index (cfg.chain_offset + c): a job sharded over ranks with one
+    // job-wide seed draws, for every chain, the numbers the unsharded job would draw
     uint32_t r[4], q[4], t[4], n[4];
-    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 0u, r);
-    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 1u, q);
-    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 2u, t);
-    ph.gen(cfg.seed, (uint32_t)c, (uint32_t)iiter, 3u, n);
+    const uint32_t gc = (uint32_t)(cfg.chain_offset + (int64_t)c);
+    ph.gen(cfg.seed, gc, (uint32_t)iiter, 0u, r);
+    ph.gen(cfg.seed, gc, (uint32_t)iiter, 1u, q);
+    ph.gen(cfg.seed, gc, (uint32_t)iiter, 2u, t);
+    ph.gen(cfg.seed, gc, (uint32_t)iiter, 3u, n);
     d.u_move = u01(r[0], r[1]); d.u_index = u01(r[2], r[3]);
     d.u_z = u01(q[0], q[1]); d.u_accept = u01(q[2], q[3]);
     d.u_noise = u01(t[0], t[1]);

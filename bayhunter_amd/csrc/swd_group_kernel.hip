@@ -476,9 +476,17 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
     if (prof) {
         unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        unsigned long long lps = tot * (unsigned long long)(valid ? mmax - 1 : 0);
+        for (int off = 32; off > 0; off >>= 1) {
+            tot += __shfl_xor(tot, off);
+            lps += __shfl_xor(lps, off);
+        }
         if (lane == 0) {
+            // [0] secular evaluations; per wave type ([8] Rayleigh / [9] Love) evaluations and ([10] / [11]) layer-
+            // propagator steps = evaluations x finite layers of the model (the flop model of SURVEY.md 8(d))
             atomicAdd(A.neval, tot);
+            atomicAdd(A.neval + (ifunc == 2 ? 8 : 9), tot);
+            atomicAdd(A.neval + (ifunc == 2 ? 10 : 11), lps);
             // development aid: wave-cycles per phase, [1..3] Rayleigh A/B/state, [4..6] Love
             const int o = (ifunc == 2) ? 1 : 4;
             atomicAdd(A.neval + o, (unsigned long long)tA);

@@ -120,9 +120,18 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     }
     if (valid) A.err[ib] = S.errflag;
     if (A.neval != nullptr) {
-        unsigned long long tot = S.evals;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-        if (lane == 0) atomicAdd(A.neval, tot);
+        // [0] secular evaluations; per wave type ([8] Rayleigh / [9] Love) evaluations and ([10] / [11]) layer-
+        // propagator steps = evaluations x finite layers of the model (the flop model of SURVEY.md 8(d))
+        unsigned long long tot = S.evals, lps = (unsigned long long)S.evals * (unsigned long long)(valid ? mmax - 1 : 0);
+        for (int off = 32; off > 0; off >>= 1) {
+            tot += __shfl_xor(tot, off);
+            lps += __shfl_xor(lps, off);
+        }
+        if (lane == 0) {
+            atomicAdd(A.neval, tot);
+            atomicAdd(A.neval + (IFUNC == 2 ? 8 : 9), tot);
+            atomicAdd(A.neval + (IFUNC == 2 ? 10 : 11), lps);
+        }
     }
 }
 

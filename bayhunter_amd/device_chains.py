@@ -36,18 +36,32 @@ from .Targets import JointTarget
 
 
 class DeviceChains(object):
-    def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=0, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None):
-        """betas / ladder / swap_every: parallel tempering (no counterpart in the reference).  `betas[c]` is
-        the inverse temperature chain c starts with, `ladder[c]` the id of the temperature ladder it
-        belongs to (ids are global across ranks); every `swap_every` iterations neighbouring temperatures
-        of each ladder are exchanged (`parallel.tempering_exchange`; chains keep their states and swap
-        betas, so nothing but (logL, beta, ladder) of each chain crosses GPUs).  Posterior samples are the
-        snapshots of chains that hold beta = 1 at that time (`samples(..., cold_only=True)`)."""
+    def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None):
+        """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
+        torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
+        (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
+        order) and every chain's random stream and initial state depend on (seed, global index) only -- N ranks x C
+        chains walk exactly the trajectories of one rank with N*C chains.
+        betas / ladder / swap_every: parallel tempering (no counterpart in the reference).  `betas[c]` is the
+        inverse temperature chain c starts with, `ladder[c]` the id of the temperature ladder it belongs to (ids
+        are global across ranks); every `swap_every` iterations neighbouring temperatures of each ladder are
+        exchanged (`parallel.tempering_exchange`, decisions drawn from the job seed: identical on every rank;
+        chains keep their states and swap betas, so nothing but (logL, beta, ladder) of each chain crosses GPUs).
+        Posterior samples are the snapshots of the chains that hold beta = 1 at that time
+        (`samples(cold_only=True)`, and what `save()` writes).
+        device: CUDA device index; default = the engine's (`JointTarget(..., engine=)`), else 0."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
+        if self.targets._engine is None and device is not None:
+            from .engine import default_engine
+            self.targets._engine = default_engine(int(device))   # kernels and tensors on the same GPU
         self.engine = self.targets.engine
+        if device is None:
+            device = self.engine.device
+        if int(device) != int(self.engine.device):
+            raise EngineError("DeviceChains(device=%d) but the targets' engine runs on GPU %d" % (device, self.engine.device))
         self.priors = dict(DEFAULT_PRIORS)
         self.priors.update(modelpriors or {})
         self.initparams = dict(DEFAULT_INITPARAMS)
@@ -63,10 +77,15 @@ class DeviceChains(object):
         self.iiter = -self.iter_phase1
         self.thinning = max(1, int(np.ceil(float(self.iter_phase2) / float(ip["maxmodels"]))))
         self.swap_every, self.dist, self.nswaps, self.sweep, self.seed = int(swap_every), dist, 0, 0, int(seed)
+        from .parallel import chain_layout, chain_seeds
+        off, tot = chain_layout(self.C, dist)
+        if chain_offset is not None:
+            off = int(chain_offset)
+        self.chain_offset, self.C_global = off, max(tot, off + self.C)
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
 
         # ---- initial state through the reference-order host code --------------------------------
-        seeds = np.random.RandomState((int(seed) ^ (int(seed) >> 32)) & 0xFFFFFFFF).randint(0, 2 ** 31 - 1, size=self.C)
-        host = ChainBatch(self.targets, seeds, ip, pr)
+        host = ChainBatch(self.targets, chain_seeds(seed, off, self.C), ip, pr)
         self.noisepriors = host.noisepriors
         self.targets._register()  # constant target data + laws live on the device from here on
 
@@ -93,9 +112,11 @@ class DeviceChains(object):
             else:
                 cfg.noise_lo[i], cfg.noise_hi[i] = p
         cfg.seed = int(seed) & (2 ** 64 - 1)
+        cfg.chain_offset = off
         self.cfg = cfg
 
-        dev = torch.device("cuda", device)
+        dev = torch.device("cuda", int(device))
+        self.dev = dev
         Cn, ML, nt = self.C, self.ML, self.nt
         f64 = dict(dtype=torch.float64, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -159,7 +180,7 @@ class DeviceChains(object):
         self.engine.synchronize()
         newb, nacc = tempering_exchange(self.t["like"], self.t["beta"], self.ladder, self.sweep, self.seed, self.dist)
         self.t["beta"].copy_(newb)
-        self.torch.cuda.synchronize()
+        self.torch.cuda.synchronize(self.dev)
         self.sweep += 1
         self.nswaps += nacc
 
@@ -191,9 +212,13 @@ class DeviceChains(object):
         self.engine.synchronize()
         return {k: (None if v is None else v.cpu().numpy()) for k, v in self.t.items()}
 
-    def samples(self, phase="p2"):
-        """Thinned samples of every chain: dict of arrays with leading axes [nsnap, C]; `models` in the
-        reference's row layout [vs_1..vs_n NaN.., z_1..z_n NaN..] (2*maxlayers wide)."""
+    def samples(self, phase="p2", cold_only=False, gather=False):
+        """Thinned samples: dict of arrays with leading axes [nsnap, C]; `models` in the reference's row layout
+        [vs_1..vs_n NaN.., z_1..z_n NaN..] (2*maxlayers wide).
+        gather: all chains of a sharded job (global chain order) instead of this rank's, on every rank.
+        cold_only (tempered runs): one column per LADDER -- at every snapshot the state of the chain holding
+        beta = 1; implies gather (the cold chain of a ladder moves between chains, hence between ranks);
+        the ladder ids are returned as out["ladder"]."""
         S = self.snap[phase]
         ns, Cn, ML = len(S), self.C, self.ML
         models = np.full((ns, Cn, 2 * ML), np.nan, dtype=np.float32)
@@ -212,17 +237,31 @@ class DeviceChains(object):
         out["noise"] = np.array([r["noise"].T for r in S], dtype=np.float32).reshape(ns, Cn, 2 * self.nt)
         if ns and S[0]["beta"] is not None:
             out["beta"] = np.array([r["beta"] for r in S]).reshape(ns, Cn)   # cold samples: out["beta"] == 1
+        if not (gather or cold_only):
+            return out
+        from .parallel import gather_chain_axis, cold_samples
+        out = {k: gather_chain_axis(v, 1, self.dist) for k, v in out.items()}
+        if cold_only and "beta" in out:
+            ladder = gather_chain_axis(self.ladder, 0, self.dist)
+            ids, out = cold_samples(out, ladder)
+            out["ladder"] = ids
         return out
 
     def save(self, savepath=None):
-        """c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy per chain, the reference's result files."""
+        """c%03d_p{1,2}{models,likes,misfits,noise,vpvs}.npy, the reference's per-chain result files
+        (src/SingleChain.py:646-690), written by rank 0 for ALL chains of the job with their global numbers
+        (end-of-run all-gather of the thinned snapshots).  Tempered runs: one file set per ladder, holding the
+        beta = 1 samples only (hot chains are not posterior samples)."""
+        from .parallel import write_chain_files
         savepath = op.join(savepath or self.initparams["savepath"], "data")
-        os.makedirs(savepath, exist_ok=True)
+        tempered = self.t["beta"] is not None
         for tag in ("p1", "p2"):
             if not self.snap[tag]:
                 continue
-            s = self.samples(tag)
-            for c in range(self.C):
-                for k in ("models", "likes", "misfits", "noise", "vpvs"):
-                    np.save(op.join(savepath, "c%.3d_%s%s" % (c, tag, k)), s[k][:, c])
+            s = self.samples(tag, cold_only=tempered, gather=True)      # collective: every rank takes part
+            if self.rank == 0:
+                ids = s["ladder"] if tempered else np.arange(s["models"].shape[1])
+                write_chain_files(savepath, tag, s, ids)
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.barrier()
         return savepath

@@ -58,7 +58,7 @@ class ChainConfig(C.Structure):
                 ("vpvsmin", C.c_double), ("vpvsmax", C.c_double), ("mantle_vs", C.c_double), ("mantle_vpvs", C.c_double),
                 ("acc_lo", C.c_double), ("acc_hi", C.c_double),
                 ("noise_lo", C.c_double * (2 * BH_MAX_TARGETS)), ("noise_hi", C.c_double * (2 * BH_MAX_TARGETS)),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("chain_offset", C.c_int64)]
 
 
 CHAIN_STATE_FIELDS = ("n", "vs", "z", "vpvs", "noise", "like", "misfits", "propdist", "proposed", "accepted", "naccepted",
@@ -125,7 +125,7 @@ def load_library():
                  "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 1:
+    if L.bh_abi_version() != 2:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
@@ -232,7 +232,7 @@ class Engine(object):
         return tot, fam
 
     def debug_counters(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self._L.bh_debug_counters(self._h, out))
         return [int(v) for v in out]
 

@@ -123,3 +123,64 @@ def tempering_exchange(local_logL, local_beta, local_ladder, sweep, seed, dist=N
     else:
         mine = slice(0, local.shape[0])
     return torch.as_tensor(newb[mine], dtype=lb.dtype, device=lb.device), nacc
+
+
+# ---- sharded chains: global numbering, result gather, cold-chain assembly -------------------------
+def chain_layout(n_local, dist=None):
+    """(offset of this rank's first chain, total chains of the job): ranks own contiguous blocks of the
+    global chain list in rank order (block sizes may differ)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0, int(n_local)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    counts = all_gather_rows(torch.tensor([[int(n_local)]], dtype=torch.int64, device=dev), dist).cpu().numpy().ravel()
+    return int(counts[:dist.get_rank()].sum()), int(counts.sum())
+
+
+def chain_seeds(seed, offset, n_local):
+    """Per-chain seeds of the initial-state generator, a function of the job seed and the GLOBAL chain index
+    (so that a sharded job starts every chain where the unsharded job would)."""
+    rs = np.random.RandomState((int(seed) ^ (int(seed) >> 32)) & 0xFFFFFFFF)
+    return rs.randint(0, 2 ** 31 - 1, size=int(offset) + int(n_local))[int(offset):]
+
+
+def gather_chain_axis(a, axis, dist=None):
+    """numpy array with a chain axis (this rank's chains) -> the same array for ALL chains of the job, on every
+    rank (all-gather; RCCL when the process group is nccl, gloo otherwise)."""
+    import torch
+    a = np.asarray(a)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return a
+    moved = np.ascontiguousarray(np.moveaxis(a, axis, 0))
+    t = torch.from_numpy(moved.reshape(moved.shape[0], -1))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    out = all_gather_rows(t, dist).cpu().numpy()
+    return np.moveaxis(out.reshape((out.shape[0],) + moved.shape[1:]), 0, axis)
+
+
+def cold_samples(samples, ladder):
+    """Posterior samples of a tempered run: for every ladder and every snapshot the state of the chain that
+    holds beta = 1 (the largest beta of the ladder) at that time.  `samples`: dict of arrays [nsnap, C, ...]
+    incl. "beta" [nsnap, C]; `ladder` [C] ladder id of every chain.  Returns (ladder ids, dict of arrays
+    [nsnap, n_ladders, ...])."""
+    ladder = np.asarray(ladder)
+    ids = np.unique(ladder)
+    beta = np.asarray(samples["beta"])
+    ns = beta.shape[0]
+    pick = np.zeros((ns, ids.size), dtype=np.int64)
+    for k, lid in enumerate(ids):
+        idx = np.flatnonzero(ladder == lid)
+        pick[:, k] = idx[np.argmax(beta[:, idx], axis=1)]
+    rows = np.arange(ns)[:, None]
+    return ids, {k: np.asarray(v)[rows, pick] for k, v in samples.items()}
+
+
+def write_chain_files(datapath, tag, samples, ids):
+    """c%03d_<tag>{models,likes,misfits,noise,vpvs}.npy, one set per column of `samples` ([nsnap, n, ...]),
+    numbered by `ids` -- the reference's per-chain result files (src/SingleChain.py:646-690)."""
+    import os
+    os.makedirs(datapath, exist_ok=True)
+    for j, cid in enumerate(ids):
+        for k in ("models", "likes", "misfits", "noise", "vpvs"):
+            np.save(os.path.join(datapath, "c%.3d_%s%s" % (int(cid), tag, k)), np.asarray(samples[k])[:, j])

@@ -163,7 +163,7 @@ def cpu_baseline_reference(spec, batch, noise, workload):
                 best_dt = dt if best_dt is None else min(best_dt, dt)
             return per * nproc / best_dt
 
-    cands = [c for c in (8, 16, 32, 64) if c <= ncpu] or [ncpu]
+    cands = sorted({c for c in (8, 16, 32, 64, 96, 128, 192, 256, ncpu) if c <= ncpu}) or [ncpu]
     probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
     best = max(probe, key=probe.get)
     n = int(max(4 * best, min(20.0 / per_model, 8.0 * probe[best])))
@@ -230,8 +230,9 @@ def run_chains(args, eng, rank, world, dist, dev):
     kw = {}
     if args.workload == "c5":   # one temperature per rank (geometric ladder 1..30 over 8 rungs), ladders = chains
         ladder = 1.0 / np.geomspace(1.0, 30.0, 8)
-        kw = dict(betas=np.full(C, ladder[rank % 8]), ladder=np.arange(C), swap_every=100, dist=dist if world > 1 else None)
-    dc = DeviceChains(jt, C, init, priors, seed=20260927 + rank, device=dev.index, **kw)
+        kw = dict(betas=np.full(C, ladder[rank % 8]), ladder=np.arange(C) + C * (rank // 8), swap_every=100)
+    # ONE job seed on every rank: the chains' streams follow their global index, the exchange decisions the job seed
+    dc = DeviceChains(jt, C, init, priors, seed=20260927, device=dev.index, dist=dist if world > 1 else None, **kw)
     import torch
     def fence():
         eng.synchronize(); torch.cuda.synchronize()
@@ -269,18 +270,51 @@ def run_chains(args, eng, rank, world, dist, dev):
         print(json.dumps(out))
 
 
-def pmc_traffic(workload, B):
-    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be read
-    from inside the timed run: they come from the separate rocprofv3 --pmc passes of the same command
-    (tools/profile_round.sh), whose summary is committed as profiles/pmc_traffic.json; null when that
-    file is missing or was taken for another workload / batch."""
+def parity_check(spec, batch, noise, d_logL, d_misf, d_err, n=64):
+    """The outputs of the LAST timed step against the oracle on `n` models spread over the batch (the oracle as the
+    checker, after the timed region): max relative difference of logL and of the misfits, failure flags equal."""
+    from oracle import oracle as O
+    from bayhunter_amd import engine as E
+    nlay, h, vp, vs, rho = batch
+    B = nlay.size
+    idx = np.unique(np.linspace(0, B - 1, n).astype(int))
+    ht, vpt, vst, rhot = [np.ascontiguousarray(a.T[idx]) for a in (h, vp, vs, rho)]
+    logL = d_logL.cpu().numpy()[idx]
+    misf = d_misf.cpu().numpy()[idx]
+    err = d_err.cpu().numpy()[idx]
+    if any(s_["law"] == E.LAW_GAUSS for s_ in spec):      # the Gauss law is not in the oracle's batched entry point
+        ref_L = np.zeros(idx.size)
+        ref_m = None
+        for k in range(idx.size):
+            for t, s_ in enumerate(spec):
+                a = [nlay[idx[k]:idx[k] + 1], ht[k:k + 1], vpt[k:k + 1], vst[k:k + 1], rhot[k:k + 1]]
+                if s_["kind"] == E.TARGET_SWD:
+                    y = O.swd_batch(*a, s_["x"], s_["iwave"], s_["igr"])[0][0]
+                else:
+                    y = O.rf_batch(*a, s_["p"], s_["gauss"], s_["nsamp"], s_["fsamp"], s_["tshift"], s_["waveno"], s_["n"])[0]
+                ref_L[k] += O.loglike_dense(s_["law"], y, s_["yobs"], noise[idx[k], 2 * t], noise[idx[k], 2 * t + 1],
+                                            rinv=s_.get("rinv"), logdet_r=s_.get("logdet_r", 0.0))
+    else:
+        ref_L, ref_m = O.joint_batch(nlay[idx], ht, vpt, vst, rhot, spec, noise[idx], nthreads=0)
+    ok = err == 0
+    out = {"n": int(idx.size), "failure_flags_equal": bool(np.array_equal(ok, ref_L > -1e14)),
+           "max_rel_logL": float(np.max(np.abs(logL[ok] - ref_L[ok]) / np.abs(ref_L[ok]))) if ok.any() else None}
+    if ref_m is not None and ok.any():
+        out["max_rel_misfit"] = float(np.max(np.abs(misf[ok] - ref_m[ok]) / np.abs(ref_m[ok])))
+    return out
+
+
+def pmc_summary(workload, B):
+    """PMC figures of the dominant kernel for this workload and batch.  Counters cannot be read from inside the
+    timed run: they come from the separate rocprofv3 --pmc passes of the same command (tools/profile_round.sh),
+    whose summary is committed as profiles/pmc_summary.json; {} when there is no entry for this workload / batch."""
     try:
-        d = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        if d["workload"] == workload and int(d["batch"]) == int(B):
-            return {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "source": d["source"]}
+        d = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json")))[workload]
+        if int(d["batch"]) == int(B):
+            return d
     except Exception:
         pass
-    return None
+    return {}
 
 
 def main():
@@ -293,15 +327,26 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last step (after the timed region)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node; rank 0 of the re-executed script prints the one JSON line
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torchrun (one rank per GPU)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
     # Dry-run aid for boxes with ONE GPU: BH_BENCH_DRYRUN=1 puts every rank on GPU 0 and uses gloo, so
@@ -358,7 +403,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    neval = eng.last_neval() if args.warmup > 0 else 0   # secular evaluations of one step (last warmup)
+    counters = eng.debug_counters() if args.warmup > 0 else None   # evaluations / layer steps of one step (last warm-up)
     eng.set_instrumentation(timing=True, counting=False)
     eng.timing_reset()
     fence()
@@ -378,15 +423,37 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        # dominant kernel: the dispersion family (one Rayleigh + one Love launch per step);
-        # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model
+        # dominant kernel: the dispersion kernel (all dispersion targets of a step in one launch);
+        # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model and target
         K = spec[0]["n"]
         nswd = sum(1 for s in spec if s["kind"] == E.TARGET_SWD)
-        # One launch of the group kernel covers all dispersion targets of the step (each target's
-        # wavefronts read the model and write K velocities + an error flag per model).
         bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
         swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
         achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
+        pmc = pmc_summary(args.workload, B)
+        traffic = None
+        if "hbm_bytes_per_launch" in pmc:
+            traffic = {"hbm_bytes_per_launch": pmc["hbm_bytes_per_launch"], "source": pmc.get("source")}
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
+                "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
+                        "(SURVEY.md 8(d)): see binding"}
+        if counters is not None:
+            # flop model of SURVEY.md 8(d): layer-propagator steps, counted in the kernel PER WAVE TYPE, x flop-equivalents
+            ev_r, ev_l, lps_r, lps_l = counters[8], counters[9], counters[10], counters[11]
+            flop = lps_r * FLOP_PER_LPS[2] + lps_l * FLOP_PER_LPS[1]
+            tf = flop / (swd_ms_per_launch * 1e-3) / 1e12
+            roof["binding"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (flop-equivalents)",
+                               "frac": tf / FP64_VALU_PEAK_TF,
+                               "secular_evals_per_step": {"rayleigh": ev_r, "love": ev_l},
+                               "layer_steps_per_step": {"rayleigh": lps_r, "love": lps_l},
+                               "flop_equivalents_per_layer_step": {"rayleigh": FLOP_PER_LPS[2], "love": FLOP_PER_LPS[1]},
+                               "valu_busy": pmc.get("valu_busy"), "active_lane_frac": pmc.get("active_lane_frac"),
+                               "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
+                               "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (kernel time x 1024 SIMDs x clock), active_lane_frac = "
+                                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): separate rocprofv3 --pmc pass "
+                                       "(profiles/pmc_summary.json); null without one"}
         out = {
             "metric": "forward-model+logL evals/sec (batched 10-layer models)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -398,25 +465,16 @@ def main():
                                     "c3g": "c3 with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF"}[args.workload],
                        "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
                        "parallelism": "models sharded one batch per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, B),
-                         "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
-                         "kernel_ms_per_launch": swd_ms_per_launch,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "scalar FP64 recurrence: HBM is not the binding roof (SURVEY.md 8(d)); see fp64_valu"},
+            "roofline": roof,
             "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
             "gpu_ms_per_step": tot_ms / max(1, ncalls),
             "failed_models_last_step": n_failed, "logL_finite": finite,
         }
-        if neval:
-            # flop model of SURVEY.md 8(d): layer-propagator steps x flop-equivalents per step;
-            # the counter covers all dispersion launches of a step, split by the per-type ratio
-            lps = neval * (L - 1)
-            flop = lps * (0.5 * FLOP_PER_LPS[2] + 0.5 * FLOP_PER_LPS[1])
-            out["fp64_valu"] = {"secular_evals_per_step": neval, "layer_steps_per_step": lps,
-                                "achieved_tflops": flop / (fam_ms["swd"] / max(1, ncalls) * 1e-3) / 1e12,
-                                "peak_tflops": FP64_VALU_PEAK_TF,
-                                "note": "flop-equivalents (Rayleigh 320, Love 65 per layer step, ~equal eval counts)"}
+        if not args.no_parity:
+            try:
+                out["parity_check"] = parity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_logL, d_misf, d_err)
+            except Exception as ex:
+                out["parity_check"] = {"n": 0, "error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, args.workload)

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 1
+#define BH_ABI_VERSION 2
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -192,7 +192,7 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
  * bh_chain_accept: acceptance incl. the birth/death terms, state update, counters and the
  *   proposal-width adaptation every 1000 iterations (src/SingleChain.py:425-487, :558-589).
  * All arrays are DEVICE pointers, float64 unless noted; "[k][C]" = k rows of C chains (chain index
- * contiguous).  Random numbers are Philox4x32-10 keyed by `seed` with counter (chain, iteration,
+ * contiguous).  Random numbers are Philox4x32-10 keyed by `seed` with counter (global chain index, iteration,
  * purpose): reproducible and independent of scheduling, but a different stream from the
  * reference's per-chain Mersenne Twister -- chains agree with the reference statistically (the
  * draw-for-draw replay is the host driver bayhunter_amd/chains.py).  If state->inject is not
@@ -213,6 +213,8 @@ typedef struct bh_chain_config {
     double acc_lo, acc_hi;        /* initparams 'acceptance' [%] */
     double noise_lo[2 * BH_MAX_TARGETS], noise_hi[2 * BH_MAX_TARGETS]; /* equal = fixed */
     uint64_t seed;
+    int64_t chain_offset;         /* global index of this call's chain 0 (sharded jobs: the Philox counter
+                                     uses chain_offset + c, so that one job-wide seed gives every chain its own stream) */
 } bh_chain_config;
 
 typedef struct bh_chain_state {
@@ -267,9 +269,10 @@ int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
 int bh_timing_reset(bh_engine *e);
 int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3]);
 int bh_last_neval(bh_engine *e, uint64_t *neval);
-/* development aid: raw counter block of the last counted call ([0] evaluations, [1..3]
- * Rayleigh wave-cycles in phase A / B / state update, [4..6] the same for Love, [7] wavefronts) */
-int bh_debug_counters(bh_engine *e, uint64_t out[8]);
+/* raw counter block of the last counted call: [0] secular evaluations, [1..3] / [4..6] wave-cycles per phase
+ * (development aid), [7] wavefronts, [8] / [9] evaluations of the Rayleigh / Love targets, [10] / [11] their
+ * layer-propagator steps (evaluations x finite layers: the flop model of the roofline block in bench.py) */
+int bh_debug_counters(bh_engine *e, uint64_t out[16]);
 /* development aid: one record of 4 words per traced wavefront of the last counted dispersion launch
  * (start, end [100 MHz ticks], core cycles, rounds | wave type << 32 | HW_ID << 36); counter [7] = wavefronts */
 int bh_debug_trace(bh_engine *e, uint64_t *out, int nwaves);

@@ -28,11 +28,12 @@ def _u01(hi, lo):
     return (v >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def draws(seed, C, iiter):
-    """-> [6, C]: u_move, u_index, u_z, u_accept, u_noise, normal for iteration `iiter`."""
+def draws(seed, C, iiter, offset=0):
+    """-> [6, C]: u_move, u_index, u_z, u_accept, u_noise, normal for iteration `iiter` of the chains with
+    global indices offset .. offset + C - 1."""
     key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     ctr = np.zeros((4, C, 4), dtype=np.uint32)
-    ctr[:, :, 0] = np.arange(C, dtype=np.uint32)
+    ctr[:, :, 0] = (np.arange(C, dtype=np.uint64) + np.uint64(offset)).astype(np.uint32)
     ctr[:, :, 1] = np.uint32(iiter & 0xFFFFFFFF)
     ctr[:, :, 2] = np.arange(4, dtype=np.uint32)[:, None]
     r, q, t, n = philox4x32_10(ctr, key)

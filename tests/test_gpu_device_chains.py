@@ -212,3 +212,57 @@ def test_posterior_statistics_match_reference_order_chains():
     sem = np.sqrt(H.var(axis=0, ddof=1) / N + D.var(axis=0, ddof=1) / N)
     z = (D.mean(axis=0) - H.mean(axis=0)) / sem
     assert np.all(np.abs(z) < 4.5), z
+
+
+def test_baseline_config4_shape_tempered_transdimensional_ladder():
+    """BASELINE configs[4] at its own shape, on one GPU: 64 ladders x 8 temperatures (geometric 1..30), up to 20
+    layers (transdimensional), Rayleigh + Love phase dispersion + P receiver function.  Invariants (tempering has
+    no reference counterpart): beta = 1 everywhere without swaps is the plain run bit for bit; with the ladder every
+    ladder keeps its multiset of temperatures through all sweeps; swaps happen; the cold chains sit at a higher
+    likelihood than the hot ones; cold-only samples hold one column per ladder."""
+    g = golden("chain_golden.npz")
+    t1 = bh.RayleighDispersionPhase(g["xsw"], g["ysw"])
+    # a Love target on the same periods: synthetic observed data from the engine itself (no reference Love data
+    # in the chain fixture); the invariants below do not depend on what is observed
+    from bayhunter_amd.synth import true_model
+    nlay, h, vp, vs, rho = true_model(6)
+    yl, err = bh.default_engine(0).swd_batch(nlay, h, vp, vs, rho, g["xsw"], 1, 0)
+    assert err[0] == 0
+    t2 = bh.LoveDispersionPhase(g["xsw"], yl[0])
+    t3 = bh.PReceiverFunction(g["xrf"], g["yrf"])
+    t3.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
+    priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), rfnoise_corr=(0.35, 0.75),
+                  rfnoise_sigma=(1e-5, 0.05), swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1))
+    init = dict(iter_burnin=500, iter_main=200, acceptance=(40, 45), thickmin=0.1, lvz=None, hvz=None, rcond=None, maxmodels=20)
+    nl, nr = 64, 8
+    C = nl * nr
+    ladder = np.arange(C) % nl
+    betas = (1.0 / np.geomspace(1.0, 30.0, nr))[np.arange(C) // nl]
+
+    def targets():
+        return bh.JointTarget([t1, t2, t3])
+
+    plain = DeviceChains(targets(), C, init, priors, seed=31).run().state_host()
+    ones = DeviceChains(targets(), C, init, priors, seed=31, betas=np.ones(C), ladder=ladder, swap_every=0).run().state_host()
+    for k in ("n", "vs", "z", "like", "noise", "vpvs", "propdist", "accepted"):
+        assert np.array_equal(plain[k], ones[k]), k
+    assert plain["n"].max() > 6 and plain["n"].min() >= 1                     # transdimensional: depths differ
+    dc = DeviceChains(targets(), C, init, priors, seed=31, betas=betas, ladder=ladder, swap_every=25)
+    while dc.iiter < dc.iter_phase2:
+        if dc.iiter % dc.thinning == 0:
+            dc._snapshot()
+        dc.iterate()
+        if dc.iiter % 100 == 0:                                               # every ladder keeps its temperatures
+            b = dc.state_host()["beta"]
+            for lid in (0, 17, 63):
+                assert np.array_equal(np.sort(b[ladder == lid]), np.sort(betas[ladder == lid]))
+    st = dc.state_host()
+    assert dc.sweep == 700 // 25 and dc.nswaps > 200
+    for lid in range(nl):
+        assert np.array_equal(np.sort(st["beta"][ladder == lid]), np.sort(betas[ladder == lid]))
+    cold, hot = st["beta"] == 1.0, st["beta"] == betas.min()
+    assert cold.sum() == nl and hot.sum() == nl
+    assert np.median(st["like"][cold]) > np.median(st["like"][hot])
+    s = dc.samples("p2", cold_only=True)
+    assert s["models"].shape[:2] == (len(dc.snap["p2"]), nl) and (s["beta"] == 1.0).all()
+    assert s["models"].shape[2] == 2 * 21

@@ -105,3 +105,34 @@ def test_ragged_device_batch_any_depth_hint(engine, oracle, hint):
             assert np.array_equal(d_err.cpu().numpy(), oe) and np.array_equal(d_vel.cpu().numpy(), ov), (hint, iwave, igr)
     finally:
         engine.set_typical_layers(0)
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_the_bench_path_against_the_oracle(workload):
+    """The exact composition bench.py times (BASELINE configs[1] / [2]): `build_workload` -> `observed_data` ->
+    `set_targets` -> `evaluate_batch_dev` on HBM-resident layer-major arrays, device pointers for every output,
+    B = 4096 -- logL, misfits and failure flags of 128 models spread over the batch against the oracle's dense
+    restatement of Targets.py:314-347, at 1e-8 relative."""
+    import torch
+    import bench
+    eng = E.Engine(0)
+    B, L = 4096, 10
+    spec, batches, noise, truth, nrs = bench.build_workload(workload, B, L, seed=20260927)
+    bench.observed_data(eng, spec, truth, nrs)
+    eng.set_targets(spec)
+    nt = len(spec)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batches[1]]
+    d_noise = torch.from_numpy(noise).to(dev)
+    d_logL = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_misf = torch.zeros((B, nt + 1), dtype=torch.float64, device=dev)
+    d_err = torch.zeros(B, dtype=torch.int32, device=dev)
+    eng.evaluate_batch_dev(B, L, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                           B, 1, d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    chk = bench.parity_check(spec, batches[1], noise, d_logL, d_misf, d_err, n=128)
+    assert chk["n"] == 128 and chk["failure_flags_equal"]
+    assert chk["max_rel_logL"] <= 1e-8 and chk["max_rel_misfit"] <= 1e-8, chk
+    assert int((d_err != 0).sum().item()) < B // 20 and bool(torch.isfinite(d_logL).all().item())
+    eng.close()

@@ -135,3 +135,112 @@ def test_world_size_2_gloo():
     expect = parallel.swap_decisions([-50.0, -40.0, -45.0, -20.0, -60.0], 1.0 / np.geomspace(1, 8, 5), 1, 5)
     assert perm0 == expect.tolist()
     assert mine0 == (0, 3) and mine1 == (3, 5)
+
+
+# ---- sharded chains: global numbering, job-wide seed, gather, cold-chain assembly, result files ----------
+class ToyChains(object):
+    """A stand-in for DeviceChains without a GPU: one scalar state per chain, random-walk Metropolis on
+    logL(x) = -20 x^2 with tempered acceptance; every draw is a function of (job seed, GLOBAL chain index,
+    iteration), the sharding protocol is the product's (bayhunter_amd.parallel): chain_layout / chain_seeds /
+    tempering_exchange / gather_chain_axis / cold_samples / write_chain_files."""
+
+    def __init__(self, nlocal, seed, ladders, rungs, swap_every, dist_=None):
+        self.C, self.seed, self.dist, self.swap_every = nlocal, seed, dist_, swap_every
+        self.off, self.tot = parallel.chain_layout(nlocal, dist_)
+        gid = self.off + np.arange(nlocal)
+        self.gid = gid
+        self.ladder = gid % ladders                                   # ladders span the ranks
+        self.beta = None if rungs == 0 else (1.0 / np.geomspace(1.0, 6.0, rungs))[gid // ladders]
+        self.x = parallel.chain_seeds(seed, self.off, nlocal) / 2.0 ** 31 - 0.5
+        self.sweep, self.it, self.snap = 0, 0, []
+
+    @staticmethod
+    def logL(x):
+        return -20.0 * x * x
+
+    def step(self):
+        for c in range(self.C):
+            rs = np.random.RandomState([self.seed, int(self.gid[c]), self.it])
+            xn = self.x[c] + 0.3 * rs.normal()
+            b = 1.0 if self.beta is None else self.beta[c]
+            if np.log(rs.uniform()) < b * (self.logL(xn) - self.logL(self.x[c])):
+                self.x[c] = xn
+        self.it += 1
+        if self.beta is not None and self.it % self.swap_every == 0:
+            nb, _ = parallel.tempering_exchange(torch.tensor(self.logL(self.x)), torch.tensor(self.beta), self.ladder,
+                                                self.sweep, self.seed, self.dist)
+            self.beta = nb.numpy().copy()
+            self.sweep += 1
+        if self.it % 2 == 0:
+            self.snap.append((self.x.copy(), None if self.beta is None else self.beta.copy()))
+
+    def save(self, path):
+        ns = len(self.snap)
+        x = np.array([s[0] for s in self.snap])                       # [ns, C]
+        s = dict(models=np.stack((x, np.broadcast_to(self.gid, x.shape).astype(float)), axis=2).astype(np.float32),
+                 likes=self.logL(x).astype(np.float32), misfits=np.zeros((ns, self.C, 2), np.float32),
+                 noise=np.zeros((ns, self.C, 2), np.float32), vpvs=np.full((ns, self.C), 1.7, np.float32))
+        if self.beta is not None:
+            s["beta"] = np.array([q[1] for q in self.snap])
+        s = {k: parallel.gather_chain_axis(v, 1, self.dist) for k, v in s.items()}
+        ids = np.arange(s["models"].shape[1])
+        if self.beta is not None:
+            ids, s = parallel.cold_samples(s, parallel.gather_chain_axis(self.ladder, 0, self.dist))
+        rank = self.dist.get_rank() if self.dist is not None else 0
+        if rank == 0:
+            parallel.write_chain_files(path, "p2", s, ids)
+        return s
+
+
+def _toy_worker(rank, world, port, path, rungs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nl = 7 if rank == 0 else 5                                    # uneven blocks: 12 chains in all
+        tc = ToyChains(nl, seed=77, ladders=4, rungs=rungs, swap_every=3, dist_=dist)
+        assert (tc.off, tc.tot) == ((0, 12) if rank == 0 else (7, 12))
+        for _ in range(40):
+            tc.step()
+            if rungs:                                                 # every ladder keeps its set of temperatures
+                allb = parallel.gather_chain_axis(tc.beta, 0, dist)
+                alll = parallel.gather_chain_axis(tc.ladder, 0, dist)
+                for lid in range(4):
+                    assert np.allclose(np.sort(allb[alll == lid]), np.sort(1.0 / np.geomspace(1.0, 6.0, rungs)))
+        tc.save(path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rungs", [0, 3])
+def test_sharded_chains_write_what_the_single_rank_job_writes(tmp_path, rungs):
+    """2 ranks (7 + 5 chains) against 1 rank x 12 chains with the same job seed: same chains, same exchange
+    decisions, same files with global numbers; tempered: one file set per ladder holding the beta = 1 samples,
+    assembled across ranks (3 rungs, small logL gaps: swaps are not near-deterministic)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    two = str(tmp_path / "two")
+    procs = [ctx.Process(target=_toy_worker, args=(r, 2, port, two, rungs)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    one = str(tmp_path / "one")
+    tc = ToyChains(12, seed=77, ladders=4, rungs=rungs, swap_every=3)
+    for _ in range(40):
+        tc.step()
+    s = tc.save(one)
+    names = sorted(os.listdir(one))
+    assert names == sorted(os.listdir(two))
+    n_sets = 4 if rungs else 12
+    assert len(names) == 5 * n_sets and names[0] == "c000_p2likes.npy" and names[-1] == "c%03d_p2vpvs.npy" % (n_sets - 1)
+    for nme in names:
+        assert np.array_equal(np.load(os.path.join(one, nme)), np.load(os.path.join(two, nme))), nme
+    if rungs:
+        assert tc.sweep == 13 and (s["beta"] == 1.0).all()             # only cold samples are written
+        moved = np.load(os.path.join(one, "c000_p2models.npy"))[:, 1]   # global id of the chain that was cold
+        assert len(set(moved.tolist())) > 1                            # the cold chain really moved between chains
+    else:
+        ids = [int(np.load(os.path.join(two, "c%03d_p2models.npy" % c))[0, 1]) for c in range(12)]
+        assert ids == list(range(12))                                   # 12 distinct chains, numbered globally
