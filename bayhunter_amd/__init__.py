@@ -9,6 +9,7 @@ from .Targets import (ObservedData, ModeledData, Valuation, SingleTarget, JointT
                       RayleighDispersionPhase, RayleighDispersionGroup, LoveDispersionPhase,
                       LoveDispersionGroup, PReceiverFunction, SReceiverFunction, select_noise_laws)
 from .chains import ChainBatch, MCMC_Optimizer  # noqa: F401
+from .results import save_config, save_final_distribution, get_outliers  # noqa: F401
 
 
 def __getattr__(name):  # DeviceChains needs torch: imported on first use only

@@ -35,6 +35,11 @@ DEFAULT_INITPARAMS = dict(nchains=3, iter_burnin=2048 * 2, iter_main=2048, propd
 
 
 def _is_fixed(prior):
+    """A scalar prior = a fixed parameter.  The reference tests `type(p) in [int, float, np.float64]` for noise
+    (src/SingleChain.py:137) and `type(p) == float` for vp/vs (:153, :598); every scalar it does not recognise
+    (an int or numpy-scalar vp/vs, a float32 noise value) makes it fail on `p[0]` a few lines later, so each
+    configuration the reference RUNS is classified identically here -- the broader test only accepts what the
+    reference raises on."""
     return isinstance(prior, (int, float, np.floating)) and not isinstance(prior, bool)
 
 
@@ -327,6 +332,9 @@ class ChainBatch(object):
             t = thin.get(idx, rep["_thin"])
             for k in ("models", "likes", "misfits", "noise", "vpvs"):
                 np.save(op.join(savepath, "c%.3d_%s%s" % (idx, tag, k)), rep[k][::t])
+        from .results import save_config
+        save_config(self.targets, op.join(savepath, "%s_config.pkl" % self.initparams.get("station", "test")),
+                    priors=self.priors, initparams=self.initparams)
         return savepath
 
 
@@ -346,5 +354,11 @@ class MCMC_Optimizer(object):
         self.batch = ChainBatch(targets, seeds, self.initparams, self.priors)
 
     def mp_inversion(self, baywatch=False, dtsend=0.5, nthreads=0):
+        """All chains as one lock-step batch; writes the reference's result folder (per-chain files + the
+        configuration pickle `PlotFromStorage` opens).  `nthreads` / `dtsend` have no meaning here (no process
+        farm); BayWatch live streaming is not part of this package."""
+        if baywatch:
+            import warnings
+            warnings.warn("baywatch=True: live streaming to BayWatch is not provided by bayhunter_amd (ignored)")
         self.batch.run()
         return self.batch.save()

@@ -262,6 +262,10 @@ class DeviceChains(object):
             if self.rank == 0:
                 ids = s["ladder"] if tempered else np.arange(s["models"].shape[1])
                 write_chain_files(savepath, tag, s, ids)
+        if self.rank == 0:
+            from .results import save_config
+            save_config(self.targets, op.join(savepath, "%s_config.pkl" % self.initparams.get("station", "test")),
+                        priors=self.priors, initparams=self.initparams)
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
             self.dist.barrier()
         return savepath

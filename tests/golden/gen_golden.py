@@ -362,5 +362,44 @@ def main():
             print("%-22s %8d B" % (f, os.path.getsize(p)))
 
 
+def merge_fixture():
+    """tests/golden/merge_golden.npz: the reference's PlotFromStorage.save_final_distribution (src/Plotting.py:157-262)
+    on a folder of three chains' main-phase files -- the two recorded `exp` chains of chain_golden.npz and a copy of
+    the second one with halved likelihoods (the outlier at dev = 0.3) -- with maxmodels small enough that every
+    chain is sub-sampled (the module-level RandomState(333) of Plotting.py).  Inputs are in chain_golden.npz;
+    outputs: outlier list, outliers.dat text and the merged c_*.npy arrays."""
+    Targets, Models, SynthObs = import_reference()
+    utils = sys.modules["BayHunter.utils"]
+    Plotting = sys.modules["BayHunter.Plotting"]
+    g = np.load(os.path.join(HERE, "chain_golden.npz"))
+    tmp = tempfile.mkdtemp(prefix="bhmerge_")
+    data = os.path.join(tmp, "data")
+    os.makedirs(data)
+    for c, (key, scale) in enumerate((("exp_s11_", 1.0), ("exp_s12_", 1.0), ("exp_s12_", 0.5))):
+        for ph in ("p1", "p2"):
+            for nm in ("models", "likes", "misfits", "noise", "vpvs"):
+                a = g[key + "file_" + ph + nm]
+                if nm == "likes":
+                    a = (a * scale).astype(a.dtype)
+                np.save(os.path.join(data, "c%.3d_%s%s" % (c, ph, nm)), a)
+    t1 = Targets.RayleighDispersionPhase(g["xsw"], g["ysw"])
+    t2 = Targets.PReceiverFunction(g["xrf"], g["yrf"])
+    jt = Targets.JointTarget(targets=[t1, t2])
+    cfg = os.path.join(data, "gold_config.pkl")
+    utils.save_config(jt, cfg, priors=dict(layers=(1, 10)), initparams=dict(station="gold"))
+    obj = Plotting.PlotFromStorage(cfg)
+    obj.save_final_distribution(maxmodels=300, dev=0.3)
+    out = {"maxmodels": 300, "dev": 0.3, "outliers": np.asarray(obj.outliers, dtype=float),
+           "outliers_dat": np.array(open(os.path.join(data, "outliers.dat")).read())}
+    for nm in ("models", "likes", "misfits", "noise", "vpvs"):
+        out["c_" + nm] = np.load(os.path.join(data, "c_%s.npy" % nm))
+    np.savez_compressed(os.path.join(HERE, "merge_golden.npz"), **out)
+    shutil.rmtree(tmp)
+    print("merge_golden.npz: outliers", out["outliers"], "merged rows", out["c_likes"].size)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "merge":
+        merge_fixture()
+        sys.exit(0)
     main()
