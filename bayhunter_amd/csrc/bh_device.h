@@ -113,7 +113,6 @@ struct RfKernelArgs {
     ptrdiff_t sl, sb;
     double p_s_per_deg, gauss, fsamp, tshift, nsv;
     double *coef;  // workspace [B][bh_rf_coef_doubles(Lmax)]
-    double *spec;  // workspace [B][nsamp/2+1][2]
     double *rf;    // [B][ldr]
     int ldr;
 };

@@ -42,7 +42,7 @@ struct bh_engine {
     bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
     std::string err;
     // staging / workspace
-    DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, spec, ymod, noise, logL,
+    DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
         misfits, err_t, probe_in, probe_out, counter, sph, perm;
     // targets
     int nt = 0;
@@ -364,13 +364,12 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     if (B == 0) return BH_OK;
     int rc;
     if ((rc = ensure(e, e->coef, (size_t)B * bh_rf_coef_doubles(Lmax) * sizeof(double)))) return rc;
-    if ((rc = ensure(e, e->spec, (size_t)B * (nsamp / 2 + 1) * 2 * sizeof(double)))) return rc;
     RfKernelArgs a{};
     a.B = B; a.Lmax = Lmax; a.nsamp = nsamp; a.nkeep = nkeep; a.waveno = waveno;
     a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.qp = m.qp; a.qs = m.qs;
     a.sl = sl; a.sb = sb;
     a.p_s_per_deg = p; a.gauss = gauss; a.fsamp = fsamp; a.tshift = tshift; a.nsv = nsv;
-    a.coef = (double *)e->coef.p; a.spec = (double *)e->spec.p; a.rf = rf; a.ldr = ldr;
+    a.coef = (double *)e->coef.p; a.rf = rf; a.ldr = ldr;
     ev_begin(e, 1, st);
     bh_launch_rf(a, st);
     ev_end(e, 1, st);
@@ -481,7 +480,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
-                      &e->errb, &e->rf, &e->coef, &e->spec, &e->ymod, &e->noise, &e->logL, &e->misfits,
+                      &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
                       &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm})
         release(*b);
     for (auto &t : e->targets) {

@@ -4,23 +4,22 @@
 // (rfmini/synrf.cpp:16-55) -> calcresp/calcresp_core (rfmini/greens.cpp:400-756) -> compute_rf
 // (:343-398) -> iftr (:136-158) -> ccfork (rfmini/fork.cpp:11-60) for a batch of models.
 //
-// Three kernels per batch (all FP64 VALU, no MFMA -- complex 2x2 recursions, not contractions):
+// Two kernels per batch (all FP64 VALU, no MFMA -- complex 2x2 recursions, not contractions):
 //   rf_coef_kernel      lane = model.  Earth-flattening (rfmini/model.cpp:221-252), the
 //                       frequency-independent interface reflection/transmission matrices
 //                       (greens.cpp:19-112), the free-surface displacement matrix (:307-322) and
 //                       the Z/R -> P/SV rotation constants (:324-341), written to a per-model
-//                       coefficient record in HBM (L2-resident: 3.4 KB/model at 10 layers).
-//   rf_spectrum_kernel  lane = (model, frequency): the 1025 frequencies of a model are
-//                       independent (greens.cpp:528), so the Kennett/Mueller top-down
-//                       reflectivity recursion (:196-224) runs with one frequency per lane; a
-//                       workgroup covers 256 consecutive frequencies of ONE model, so its
-//                       coefficient record is wave-uniform (scalar loads).  The deconvolution +
-//                       Gauss filter + time shift (:343-398) is fused; the lane writes one complex
-//                       spectral sample (16 B, coalesced).  The Nyquist bin (j = nsamp/2) of 256
-//                       models at a time is handled by trailing workgroups (lane = model).
-//   rf_ifft_kernel      workgroup = model: Hermitian-extended inverse FFT of length nsamp staged
-//                       entirely in LDS (32 KB at nsamp = 2048 + 16 KB twiddles), only the first
-//                       nkeep real samples are written (rfmini_modrf.py:142).
+//                       coefficient record in HBM (L2-resident: 3.4 KB/model at 10 layers) -- and the
+//                       model's Nyquist bin (j = nsamp/2), the one frequency that does not fit the
+//                       nsamp/2 = 4 x 256 bins the next kernel's lanes share out.
+//   rf_synth_kernel     workgroup = model.  The nsamp/2 frequencies of a model are independent
+//                       (greens.cpp:528): lane t runs the Kennett/Mueller top-down reflectivity
+//                       recursion (:196-224) for bins t, t+256, ...; the coefficient record is
+//                       wave-uniform (scalar loads).  Deconvolution + Gauss filter + time shift
+//                       (:343-398) are fused and the sample goes, with its Hermitian mirror, straight
+//                       to its bit-reversed place in LDS: the spectrum never exists in HBM.  Then the
+//                       inverse FFT of length nsamp in LDS (32 KB at nsamp = 2048 + 16 KB twiddles);
+//                       only the first nkeep real samples are written (rfmini_modrf.py:142).
 #include "bh_device.h"
 
 namespace {
@@ -81,12 +80,13 @@ __device__ __forceinline__ cm2 operator+(const cm2 &x, const cm2 &y)
 
 // ---- per-model coefficient record (doubles) ---------------------------------------------------
 //  [0] nlay  [1] p (s/km)  [2] do_decomp  [3] bad (NaN propagation of t0 / decomp)
+//  (the last two doubles of the record: the model's Nyquist bin, re / im)
 //  [4..7] m11 m12 m21 m22 (rotation)   [8..15] 2*h matrix (4 complex)
 //  [16..23] free-surface ru (4 complex)
 //  [24 + 8*l ...]           layer l = 0..Lmax-1 : vp, vs, h (flattened), qp, qs, -, -, -
 //  [24 + 8*Lmax + 32*i ...] interface below layer i (i = 0..Lmax-2): rd, td, ru, tu (4 complex each)
 constexpr int REC_HEAD = 24;
-__host__ __device__ inline size_t rec_doubles(int Lmax) { return REC_HEAD + 8 * (size_t)Lmax + 32 * (size_t)Lmax; }
+__host__ __device__ inline size_t rec_doubles(int Lmax) { return REC_HEAD + 8 * (size_t)Lmax + 32 * (size_t)Lmax + 2; }
 
 __device__ __forceinline__ void store_cm2(double *p, const cm2 &m)
 {
@@ -143,6 +143,88 @@ __device__ void interface_coeffs(double u, double vp1, double vs1, double rho1, 
         tu.c22 = b2 * t7 * t4;
         tu.c12 = b2 * t7 * u * (t1 + c * (a2 * b1));
     }
+}
+
+// One frequency of one model: greens.cpp:528-585 + :343-398.  `rec` may be wave-uniform.
+__device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, int Lmax, int j,
+                                               double dw, double qg, double gauss, double tshift,
+                                               int waveno)
+{
+    const int nlay = (int)rec[0];
+    const double p2 = rec[1] * rec[1];
+    const double w = dw * j;
+    const double wref = 2. * M_PI * 1.0;
+    const double lgw = j ? log(w / wref) : 0.0;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    if (rec[3] != 0.0) return cd{nanv, nanv};
+
+    cm2 nb, q, g;
+    nb = q = g = cm2{C(0), C(0), C(0), C(0)};
+    const double *lay = rec + REC_HEAD;
+    const double *ifc = rec + REC_HEAD + 8 * Lmax;
+    for (int i = 1; i < nlay; ++i) {
+        const double *L = lay + 8 * (i - 1);
+        const double vp = L[0], vs = L[1], d = L[2], qp = L[3], qs = L[4];
+        // complex velocities with causal Q (greens.cpp:539-543), vertical slownesses, phases
+        const cd vpc = vp * cd{1. + lgw / (M_PI * qp), 1. / (2. * qp)};
+        const cd vsc = vs * cd{1. + lgw / (M_PI * qs), 1. / (2. * qs)};
+        const cd plc = csqrt_d(crecip(vpc * vpc) - p2);
+        const cd slc = csqrt_d(crecip(vsc * vsc) - p2);
+        const cd miwd = cd{0., -w * d};
+        const cd e11 = cexp_d(miwd * plc);
+        const cd e22 = cexp_d(miwd * slc);
+        // Mueller (1985) top-down recursion, greens.cpp:196-224
+        cm2 nt;
+        if (i == 1)
+            nt = load_cm2(rec + 16);
+        else {
+            const double *ic = ifc + 32 * (i - 2); // interface above layer i
+            nt = load_cm2(ic + 16) + (load_cm2(ic + 8) * nb) * q; // ru[i] + td[i]*nb[i-1]*q
+        }
+        const cd e12 = e11 * e22;
+        nb = cm2{nt.c11 * (e11 * e11), nt.c12 * e12, nt.c21 * e12, nt.c22 * (e22 * e22)};
+        const double *icn = ifc + 32 * (i - 1); // interface below layer i
+        const cm2 rdn = load_cm2(icn), tun = load_cm2(icn + 24);
+        const cm2 rn = rdn * nb;
+        const cm2 m = cm2{C(1.) - rn.c11, -rn.c12, -rn.c21, C(1.) - rn.c22};
+        const cd idet = crecip(m.c11 * m.c22 - m.c12 * m.c21);
+        const cm2 minv = cm2{idet * m.c22, -(idet * m.c12), -(idet * m.c21), idet * m.c11};
+        q = minv * tun;
+        if (i == 1)
+            g = cm2{e11 * q.c11, e11 * q.c12, e22 * q.c21, e22 * q.c22};
+        else {
+            const cm2 ge = cm2{g.c11 * e11, g.c12 * e22, g.c21 * e11, g.c22 * e22};
+            g = ge * q;
+        }
+    }
+    const cm2 hm = load_cm2(rec + 8); // already 2*h
+    cd cr, cz;
+    if (waveno == 0) {
+        cr = hm.c11 * g.c11 + hm.c12 * g.c21;
+        cz = hm.c21 * g.c11 + hm.c22 * g.c21;
+    } else {
+        cr = hm.c11 * g.c12 + hm.c12 * g.c22;
+        cz = hm.c21 * g.c12 + hm.c22 * g.c22;
+    }
+    // (the common factor exp(i w t0) of greens.cpp:583-585 cancels in cr*conj(cz)/|cz|^2)
+    if (rec[2] != 0.0) {
+        const cd cx = cz * rec[4] + cr * rec[5];
+        const cd cy = cz * rec[6] + cr * rec[7];
+        cz = cx;
+        cr = cy;
+    }
+    if (waveno == 1) {
+        const cd t = cz;
+        cz = cr;
+        cr = t;
+    }
+    const double denom = cz.re * cz.re + cz.im * cz.im;
+    const cd num = cr * conj(cz);
+    const cd v = cd{num.re / denom, num.im / denom};
+    double wa = w / gauss;
+    wa = (wa > 50.0) ? 50.0 : wa;
+    const cd cq = qg * cexp_d(cd{-0.25 * (wa * wa), -w * tshift});
+    return v * cq;
 }
 
 __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
@@ -250,140 +332,40 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
     }
     rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
     rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
-}
-
-// One frequency of one model: greens.cpp:528-585 + :343-398.  `rec` may be wave-uniform.
-__device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, int Lmax, int j,
-                                               double dw, double qg, double gauss, double tshift,
-                                               int waveno)
-{
-    const int nlay = (int)rec[0];
-    const double p2 = rec[1] * rec[1];
-    const double w = dw * j;
-    const double wref = 2. * M_PI * 1.0;
-    const double lgw = j ? log(w / wref) : 0.0;
-    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
-    if (rec[3] != 0.0) return cd{nanv, nanv};
-
-    cm2 nb, q, g;
-    nb = q = g = cm2{C(0), C(0), C(0), C(0)};
-    const double *lay = rec + REC_HEAD;
-    const double *ifc = rec + REC_HEAD + 8 * Lmax;
-    for (int i = 1; i < nlay; ++i) {
-        const double *L = lay + 8 * (i - 1);
-        const double vp = L[0], vs = L[1], d = L[2], qp = L[3], qs = L[4];
-        // complex velocities with causal Q (greens.cpp:539-543), vertical slownesses, phases
-        const cd vpc = vp * cd{1. + lgw / (M_PI * qp), 1. / (2. * qp)};
-        const cd vsc = vs * cd{1. + lgw / (M_PI * qs), 1. / (2. * qs)};
-        const cd plc = csqrt_d(crecip(vpc * vpc) - p2);
-        const cd slc = csqrt_d(crecip(vsc * vsc) - p2);
-        const cd miwd = cd{0., -w * d};
-        const cd e11 = cexp_d(miwd * plc);
-        const cd e22 = cexp_d(miwd * slc);
-        // Mueller (1985) top-down recursion, greens.cpp:196-224
-        cm2 nt;
-        if (i == 1)
-            nt = load_cm2(rec + 16);
-        else {
-            const double *ic = ifc + 32 * (i - 2); // interface above layer i
-            nt = load_cm2(ic + 16) + (load_cm2(ic + 8) * nb) * q; // ru[i] + td[i]*nb[i-1]*q
-        }
-        const cd e12 = e11 * e22;
-        nb = cm2{nt.c11 * (e11 * e11), nt.c12 * e12, nt.c21 * e12, nt.c22 * (e22 * e22)};
-        const double *icn = ifc + 32 * (i - 1); // interface below layer i
-        const cm2 rdn = load_cm2(icn), tun = load_cm2(icn + 24);
-        const cm2 rn = rdn * nb;
-        const cm2 m = cm2{C(1.) - rn.c11, -rn.c12, -rn.c21, C(1.) - rn.c22};
-        const cd idet = crecip(m.c11 * m.c22 - m.c12 * m.c21);
-        const cm2 minv = cm2{idet * m.c22, -(idet * m.c12), -(idet * m.c21), idet * m.c11};
-        q = minv * tun;
-        if (i == 1)
-            g = cm2{e11 * q.c11, e11 * q.c12, e22 * q.c21, e22 * q.c22};
-        else {
-            const cm2 ge = cm2{g.c11 * e11, g.c12 * e22, g.c21 * e11, g.c22 * e22};
-            g = ge * q;
-        }
-    }
-    const cm2 hm = load_cm2(rec + 8); // already 2*h
-    cd cr, cz;
-    if (waveno == 0) {
-        cr = hm.c11 * g.c11 + hm.c12 * g.c21;
-        cz = hm.c21 * g.c11 + hm.c22 * g.c21;
-    } else {
-        cr = hm.c11 * g.c12 + hm.c12 * g.c22;
-        cz = hm.c21 * g.c12 + hm.c22 * g.c22;
-    }
-    // (the common factor exp(i w t0) of greens.cpp:583-585 cancels in cr*conj(cz)/|cz|^2)
-    if (rec[2] != 0.0) {
-        const cd cx = cz * rec[4] + cr * rec[5];
-        const cd cy = cz * rec[6] + cr * rec[7];
-        cz = cx;
-        cr = cy;
-    }
-    if (waveno == 1) {
-        const cd t = cz;
-        cz = cr;
-        cr = t;
-    }
-    const double denom = cz.re * cz.re + cz.im * cz.im;
-    const cd num = cr * conj(cz);
-    const cd v = cd{num.re / denom, num.im / denom};
-    double wa = w / gauss;
-    wa = (wa > 50.0) ? 50.0 : wa;
-    const cd cq = qg * cexp_d(cd{-0.25 * (wa * wa), -w * tshift});
-    return v * cq;
-}
-
-__global__ __launch_bounds__(256) void rf_spectrum_kernel(RfKernelArgs A, int nbpm)
-{
-    const int half = A.nsamp / 2;
-    const int nfreq = half + 1;
+    // the Nyquist bin of this model (this lane wrote the record it reads)
     const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
     const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
-    const size_t recsz = rec_doubles(A.Lmax);
-    const int nmain = A.B * nbpm;
-    int ib, j;
-    if ((int)blockIdx.x < nmain) {
-        ib = blockIdx.x / nbpm; // wave-uniform
-        j = (blockIdx.x % nbpm) * 256 + threadIdx.x;
-        if (j >= half) return;
-    } else { // Nyquist bins, lane = model
-        ib = (blockIdx.x - nmain) * 256 + threadIdx.x;
-        j = half;
-        if (ib >= A.B) return;
-    }
-    const cd s = rf_one_frequency(A.coef + (size_t)ib * recsz, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
-    double2 *out = reinterpret_cast<double2 *>(A.spec) + (size_t)ib * nfreq + j;
-    *out = make_double2(s.re, s.im);
+    const cd ny = rf_one_frequency(rec, Lmax, A.nsamp / 2, dw, qg, A.gauss, A.tshift, A.waveno);
+    rec[rec_doubles(Lmax) - 2] = ny.re;
+    rec[rec_doubles(Lmax) - 1] = ny.im;
 }
 
-// Inverse FFT of the Hermitian-extended spectrum, length N = nsamp, all in LDS.
+// Spectrum of one model into LDS (bit-reversed, Hermitian-extended), inverse FFT of length N = nsamp in LDS:
 // iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) sum_k X[k] e^{+2 pi i k n / N}.
-__global__ __launch_bounds__(256) void rf_ifft_kernel(RfKernelArgs A, int logn)
+__global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = A.nsamp, half = N / 2, nfreq = half + 1;
+    const int N = A.nsamp, half = N / 2;
     double2 *x = reinterpret_cast<double2 *>(smem);       // [N]
     double2 *tw = x + N;                                   // [N/2]  e^{+2 pi i k / N}
     const int ib = blockIdx.x;
     const int tid = threadIdx.x;
-    const double2 *spec = reinterpret_cast<const double2 *>(A.spec) + (size_t)ib * nfreq;
+    const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
+    const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
+    const size_t recsz = rec_doubles(A.Lmax);
+    const double *rec = A.coef + (size_t)ib * recsz;
     for (int k = tid; k < half; k += 256) {
         double s, c;
         sincospi(2.0 * (double)k / (double)N, &s, &c);
         tw[k] = make_double2(c, s);
     }
-    // load in bit-reversed order with the Hermitian extension cx[i] = conj(cx[N-i]), i > N/2
-    for (int i = tid; i < N; i += 256) {
-        double2 v;
-        if (i <= half) v = spec[i];
-        else {
-            v = spec[N - i];
-            v.y = -v.y;
-        }
-        const int r = (int)(__brev((unsigned)i) >> (32 - logn));
-        x[r] = v;
+    const int shift = 32 - logn;
+    for (int j = tid; j < half; j += 256) {
+        const cd s = rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
+        x[(int)(__brev((unsigned)j) >> shift)] = make_double2(s.re, s.im);
+        if (j > 0) x[(int)(__brev((unsigned)(N - j)) >> shift)] = make_double2(s.re, -s.im); // cx[N-j] = conj(cx[j])
     }
+    if (tid == 0) x[(int)(__brev((unsigned)half) >> shift)] = make_double2(rec[recsz - 2], rec[recsz - 1]);
     __syncthreads();
     for (int s = 0; s < logn; ++s) {
         const int l = 1 << s;          // half-size of the butterflies of this stage
@@ -414,9 +396,6 @@ void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     int logn = 0;
     while ((1 << logn) < a.nsamp) ++logn;
     hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
-    const int nbpm = (half + 255) / 256;
-    const int grid = a.B * nbpm + (a.B + 255) / 256;
-    hipLaunchKernelGGL(rf_spectrum_kernel, dim3(grid), dim3(256), 0, stream, a, nbpm);
     const size_t lds = (size_t)a.nsamp * 16 + (size_t)half * 16;
-    hipLaunchKernelGGL(rf_ifft_kernel, dim3(a.B), dim3(256), lds, stream, a, logn);
+    hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logn);
 }
