@@ -31,7 +31,7 @@ def test_library_contains_gfx950_code_object():
     from bayhunter_amd import engine as E
     blob = open(E.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
-    assert b"swd_kernel" in blob and b"rf_spectrum_kernel" in blob and b"like_kernel" in blob
+    assert b"swd_kernel" in blob and b"rf_synth_kernel" in blob and b"swd_group_kernel" in blob and b"like_kernel" in blob
 
 
 def test_product_package_never_imports_the_oracle():
