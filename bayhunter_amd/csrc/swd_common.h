@@ -72,12 +72,21 @@ struct ModelLdsRt { // same, with the column count known only at run time
 // branch); after the whole recursion one test decides whether the value can be trusted, and the
 // (never observed in practice) out-of-range case re-runs the recursion with plain divisions.
 struct DivRange {
-    double lo, hi;
-    __device__ __forceinline__ void reset() { lo = 1.0; hi = 1.0; }
-    __device__ __forceinline__ void see(double a) { lo = fmin(lo, a); hi = fmax(hi, a); } // a >= 0
+    // Magnitudes are tracked through the HIGH dword of the (non-negative) operand: for non-negative doubles
+    // that word orders like the value, and two 32-bit integer min/max per operand cost a quarter of the two f64
+    // ones (which also drag a canonicalisation of the loop-carried bound along).  The bounds are one binade
+    // inside [2^-400, 2^400]; zero, denormals, infinities and NaNs (as operand or as bound) fail the test.
+    unsigned lo, hi;
+    __device__ __forceinline__ void reset() { lo = 0x3ff00000u; hi = 0x3ff00000u; }
+    __device__ __forceinline__ void see(double a) // a >= 0
+    {
+        const unsigned w = (unsigned)__double2hiint(a);
+        lo = min(lo, w);
+        hi = max(hi, w);
+    }
     __device__ __forceinline__ bool ok() const
     {
-        return lo >= 3.8725919148493183e-121 /* 2^-400 */ && hi <= 2.5822498780869086e+120 /* 2^400 */;
+        return lo >= 0x27000000u /* 2^-399 */ && hi < 0x58f00000u /* 2^400 */;
     }
 };
 

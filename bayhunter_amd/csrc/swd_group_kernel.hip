@@ -61,7 +61,7 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
         for (int m = mstart; m >= 0; --m) {
             const bool on = !RAGGED || (m <= mmax - 2 && m >= llw - 1);
             const double *cn = cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE + 5 * col;
-            const double n0 = cn[0], n1 = cn[1], n2 = cn[2], n3 = cn[3], n4 = cn[4];
+            double n0 = cn[0], n1 = cn[1], n2 = cn[2], n3 = cn[3], n4 = cn[4];
             double ee = 0.0;
             ee = ee + e[0] * c0;
             ee = ee + e[1] * c1;
@@ -70,6 +70,10 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
             ee = ee + e[4] * c4;
             const double v0 = __shfl(ee, gbase + 0), v1 = __shfl(ee, gbase + 1), v2 = __shfl(ee, gbase + 2),
                          v3 = __shfl(ee, gbase + 3), v4 = __shfl(ee, gbase + 4);
+            // keep the fetch of layer m-1 in THIS iteration (the compiler otherwise sinks it to the top of the next
+            // one and waits for it there: ~100 cycles of the ~600 a layer takes); LDS returns in order, so by the
+            // time the exchange above has arrived these have as well
+            asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4));
             double en[5];
             DivRange d2 = dr;
             normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""tools/summarize_profiles.py RAW_DIR TAG -- condense the rocprofv3 output of tools/profile_round.sh
-into the small text/CSV/JSON files that are committed under profiles/ (written to RAW_DIR/profiles_TAG/).
+"""tools/summarize_profiles.py RAW_DIR TAG -- condense the rocprofv3 output of tools/profile_round.sh into the
+small text / CSV / JSON files that are committed under profiles/ (written to RAW_DIR/profiles_TAG/).
 
-HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and
-WRITE_SIZE are collected in separate passes, are in KB per dispatch, and on gfx950 FETCH_SIZE counts
-wide (coalesced) reads at half size -> x2 for the read bytes."""
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are
+collected in separate passes, are in KB per dispatch, and on gfx950 FETCH_SIZE counts wide (coalesced) reads at half
+size -> x2 for the read bytes.  SQ counters are in units of 4 cycles per wavefront (quad-cycles), summed over XCDs."""
 import csv
 import glob
 import json
@@ -16,6 +16,8 @@ from collections import defaultdict
 raw, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(raw, "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
+CLOCK_HZ = 2.4e9     # peak engine clock (MI355X_MICROARCH.md); the busy figures below are fractions of peak issue
+NSIMD = 1024
 
 
 def find(pattern):
@@ -23,17 +25,22 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for wl in ("c2", "c3", "c2g", "c3g"):
+for wl in ("c2", "c3", "c2_b65536", "rf", "c4", "c5"):
     f = find("trace_%s/**/*kernel_stats.csv" % wl)
     if f:
-        shutil.copy(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)))
+        rows = [r for r in csv.reader(open(f))]
+        keep = [rows[0]] + [r for r in rows[1:] if not r[0].startswith("void at::") and "rocclr" not in r[0]][:8]
+        with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)), "w") as fo:
+            csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
         print("== kernel stats", wl)
-        print(open(f).read())
+        for r in keep:
+            print("   ", r[0][:70], r[1:4])
+for wl in ("c2", "c3", "c2g", "c3g", "c4", "c5", "c2_b65536", "c2_b512"):
     b = os.path.join(raw, "bench_%s.json" % wl)
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(out, "%s_bench_%s.json" % (tag, wl)))
         d = json.loads(open(b).read().strip().splitlines()[-1])
-        print("== bench", wl, d["value"], "evals/s", d["ms_per_step"], "ms/step", d["kernel_ms_per_step"])
+        print("== bench", wl, round(d["value"]), "evals/s", round(d["ms_per_step"], 3), "ms/step", d["kernel_ms_per_step"])
 
 
 def counters(pattern):
@@ -53,42 +60,75 @@ def counters(pattern):
     return res
 
 
-lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline --steps 4 --warmup 1"
-         " (c2, B=4096, L=10, K=30)",
-         "units: KB per dispatch; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM)", ""]
-traffic = {}
-for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-    for kern, cs in counters("pmc_%s/**/*counter_collection.csv" % cname).items():
-        if "swd_" in kern or "like_kernel" in kern or "rf_" in kern or "gauss" in kern:
-            v = cs[cname]
-            mean = sum(v) / len(v)
-            lines.append("%-11s %-70s dispatches %3d  mean %12.3f KB" % (cname, kern[:70], len(v), mean))
-            if "swd_group_kernel" in kern:
-                traffic[cname] = mean
-if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
-    hbm = (2.0 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024.0
-    lines.append("")
-    lines.append("swd_group_kernel HBM traffic per launch = 2 x FETCH + WRITE = %.0f bytes" % hbm)
-    json.dump({"workload": "c2", "batch": 4096, "kernel": "swd_group_kernel", "fetch_kb": traffic["FETCH_SIZE"],
-               "write_kb": traffic["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
-               "source": "profiles/%s_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
-                         "FETCH x2 gfx950 correction)" % tag},
-              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-open(os.path.join(out, "%s_pmc_hbm.txt" % tag), "w").write("\n".join(lines) + "\n")
-print("\n".join(lines))
+def steady(v):
+    """mean over the dispatches of full steps (drops the small set-up launches: < half of the largest)"""
+    big = [x for x in v if x >= 0.5 * max(v)]
+    return sum(big) / len(big)
 
-sq = counters("pmc_SQ/**/*counter_collection.csv")
-lines = ["rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -- python bench.py "
-         "--no-cpu-baseline --steps 4 --warmup 1 (c2); per dispatch, summed over XCDs", ""]
+
+summary = {}
+DOM = {"c2": ("swd_group_kernel", 4096), "c3": ("swd_group_kernel", 4096), "rf": ("rf_synth_kernel", 4096)}
+for wl, (dom, batch) in DOM.items():
+    lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of the %s command of tools/profile_round.sh" % wl,
+             "units: KB per dispatch (mean over the full-step dispatches); gfx950 correction: FETCH_SIZE x2 for wide coalesced reads "
+             "(MI355X_MICROARCH.md, HBM)", ""]
+    traffic = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        for kern, cs in counters("pmc_%s_%s/**/*counter_collection.csv" % (wl, cname)).items():
+            if any(k in kern for k in ("swd_", "like_kernel", "rf_", "gauss", "order_", "chain_")):
+                v = cs[cname]
+                lines.append("%-11s %-64s dispatches %3d  mean %12.3f KB" % (cname, kern[:64], len(v), steady(v)))
+                if dom in kern:
+                    traffic[cname] = steady(v)
+    entry = {"batch": batch, "kernel": dom}
+    if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+        hbm = (2.0 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024.0
+        lines += ["", "%s HBM traffic per launch = 2 x FETCH + WRITE = %.0f bytes" % (dom, hbm)]
+        entry.update(fetch_kb=traffic["FETCH_SIZE"], write_kb=traffic["WRITE_SIZE"], hbm_bytes_per_launch=hbm,
+                     source="profiles/%s_pmc_hbm_%s.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, FETCH x2 "
+                            "gfx950 correction)" % (tag, wl))
+    open(os.path.join(out, "%s_pmc_hbm_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    sq = counters("pmc_%s_SQ/**/*counter_collection.csv" % wl)
+    lines = ["rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU of the %s "
+             "command; per full-step dispatch, summed over XCDs; cycle counters in quad-cycles" % wl, ""]
+    for kern, cs in sq.items():
+        if dom in kern:
+            m = {k: steady(v) for k, v in cs.items()}
+            for k in sorted(m):
+                lines.append("%-22s %16.0f" % (k, m[k]))
+            bj = os.path.join(raw, "bench_%s.json" % wl)
+            kms = None
+            if os.path.exists(bj):
+                kms = json.loads(open(bj).read().strip().splitlines()[-1])["kernel_ms_per_step"]["swd"]
+            if m.get("SQ_WAVE_CYCLES") and m.get("SQ_ACTIVE_INST_VALU"):
+                lines.append("VALU-active share of resident-wave cycles = %.3f" % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]))
+            if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
+                alf = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])
+                lines.append("active-lane fraction of VALU cycles (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = %.3f" % alf)
+                entry["active_lane_frac"] = alf
+            if kms and m.get("SQ_ACTIVE_INST_VALU"):
+                busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (kms * 1e-3 * NSIMD * CLOCK_HZ)
+                lines.append("VALU busy over the kernel = SQ_ACTIVE_INST_VALU x 4 / (%.3f ms x %d SIMDs x %.1f GHz) = %.3f" % (kms, NSIMD, CLOCK_HZ / 1e9, busy))
+                entry["valu_busy"] = busy
+            if m.get("SQ_INSTS_VALU"):
+                entry["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
+                entry["waves_per_launch"] = m.get("SQ_WAVES")
+    if len(lines) > 2:
+        open(os.path.join(out, "%s_pmc_sq_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+    summary[wl] = entry
+sq = counters("pmc_b65536_SQ/**/*counter_collection.csv")
+lines = ["SQ counters of the lane-per-model kernels at B = 65536 (the throughput regime), per dispatch", ""]
 for kern, cs in sq.items():
-    if "swd_group_kernel" in kern:
-        m = {k: sum(v) / len(v) for k, v in cs.items()}
+    if "swd_kernel" in kern:
+        m = {k: steady(v) for k, v in cs.items()}
+        lines.append(kern[:80])
         for k in sorted(m):
-            lines.append("%-22s %16.0f" % (k, m[k]))
-        if m.get("SQ_WAVE_CYCLES") and m.get("SQ_ACTIVE_INST_VALU"):
-            lines.append("VALU-active share of resident-wave cycles = %.3f" % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]))
-        if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
-            lines.append("active-lane fraction of VALU cycles (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = %.3f"
-                         % (m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])))
-open(os.path.join(out, "%s_pmc_sq.txt" % tag), "w").write("\n".join(lines) + "\n")
+            lines.append("   %-22s %16.0f" % (k, m[k]))
+        if m.get("SQ_WAVE_CYCLES"):
+            lines.append("   VALU-active share of resident-wave cycles = %.3f, active-lane fraction %.3f"
+                         % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"], m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])))
+open(os.path.join(out, "%s_pmc_sq_b65536.txt" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
