@@ -15,6 +15,7 @@
 #define BH_COUNTER_WORDS 16
 #define BH_TRACE_WAVES 16384
 #define BH_DEBUG_WORDS (BH_COUNTER_WORDS + 4 * BH_TRACE_WAVES)
+#define BH_BOARD_WORDS (2 * 32768) // progress board: 2 wave slots x (8 XCCs x 4096 SIMD keys)
 
 // ---- IEEE division with the denominator-only work factored out ----------------------------------
 // hipcc expands the f64 `a / b` to   d = div_scale(b), n = div_scale(a), r = rcp(d),
@@ -90,7 +91,10 @@ struct SwdMultiArgs {
     const int32_t *split;
     int Lcut;
     int rows[2], lanes[2]; // per class (0 = deep, 1 = the rest): LDS rows per model, lanes per model (G)
+    int wg_n0, wg_n1;      // set by the launcher: > 0 = one-dimensional grid of two targets, interleaved (wavefront counts)
     unsigned long long *neval;
+    unsigned *board;  // optional: progress board of the group kernel, 2 words per physical SIMD (BH_BOARD_WORDS), see the kernel
+    unsigned stamp;   // launch stamp (16 bits) that marks this launch's entries of the board
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);

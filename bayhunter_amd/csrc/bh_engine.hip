@@ -43,7 +43,8 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter, sph, perm;
+        misfits, err_t, probe_in, probe_out, counter, sph, perm, board;
+    unsigned swd_stamp = 0;                // launch counter of the group kernel (marks its progress-board entries)
     // targets
     int nt = 0;
     int ldy = 0;
@@ -327,6 +328,13 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         return BH_OK;
     }
     SwdMultiArgs a{};
+    if (!e->board.p) { // progress board of the group kernel (scheduling aid; zeroed once, entries carry a launch stamp)
+        if ((rc = ensure(e, e->board, (size_t)BH_BOARD_WORDS * sizeof(unsigned)))) return rc;
+        HIPCHK(e, hipMemsetAsync(e->board.p, 0, (size_t)BH_BOARD_WORDS * sizeof(unsigned), st));
+    }
+    a.board = (unsigned *)e->board.p;
+    a.stamp = (++e->swd_stamp) & 0xffffu;
+    if (a.stamp == 0) a.stamp = (++e->swd_stamp) & 0xffffu;
     a.B = B; a.Lmax = Lmax; a.ntargets = 0; a.nlay = m.nlay; a.neval = counter; a.perm = perm;
     a.split = split; a.Lcut = Lcut;
     for (int j = 0; j < njobs; ++j) {
@@ -481,7 +489,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board})
         release(*b);
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);

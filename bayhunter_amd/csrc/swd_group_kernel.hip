@@ -150,6 +150,7 @@ __device__ __forceinline__ void park_ca25(double *dst, const Ca19 &c)
 // Wavefronts per workgroup: they are independent (no barrier after start-up) and only share one LDS
 // copy of the libm tables, which is what lets 8 wavefronts fit a CU's 160 KB of LDS.
 constexpr int GROUP_WPB = 2;
+constexpr unsigned PRIO_BLOCK = 8; // rounds between priority decisions (power of two)
 constexpr int LIBM_TAB_PAD = (LIBM_TAB_BYTES + 15) & ~15;
 
 // LDS ordering inside ONE wavefront: its LDS instructions execute in order, so a write by one lane is
@@ -164,8 +165,23 @@ __device__ __forceinline__ void wave_sync()
 __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     const int cls = (A.split != nullptr) ? (int)blockIdx.z : 1; // 0 = the deep models of a ragged batch, 1 = the rest
+    // Wavefront -> (target, index).  Two targets in a one-dimensional grid are INTERLEAVED wavefront by wavefront in
+    // proportion to their wavefront counts, so that every CU gets its share of both: dispatched target after
+    // target, the Rayleigh wavefronts fill whole CUs before the first Love wavefront starts, and a CU of eight
+    // Rayleigh wavefronts runs them up to 30 % slower than a mixed one (LDS traffic: 150 LDS instructions per
+    // Rayleigh round, 61 per Love round).  A workgroup's wavefronts only share the libm tables.
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / BH_WAVE));
+    int wid = (int)blockIdx.x * GROUP_WPB + wave, ty = (int)blockIdx.y;
+    bool beyond = false; // (interleaved grid: a last, odd wavefront may have nothing to do)
+    if (A.wg_n1 > 0) {
+        const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
+        beyond = wid >= (int)N;
+        const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
+        ty = (l1 > l0) ? 1 : 0;
+        wid = (l1 > l0) ? l0 : wid - l0;
+    }
     const int G = A.lanes[cls];
-    const SwdTarget T = A.t[blockIdx.y];
+    const SwdTarget T = A.t[ty];
     int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
     while (J > 1 && G * J > BH_WAVE) --J;
     // Love only: further trials INSIDE a lane group.  Its recursion is scalar (every lane of the group
@@ -175,8 +191,6 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     const int MPW = BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
     extern __shared__ __align__(16) unsigned char smem_all[];
     const int lane = threadIdx.x & (BH_WAVE - 1);
-    const int wave = threadIdx.x / BH_WAVE;
-    const int wid = blockIdx.x * GROUP_WPB + wave; // wavefront index inside this target's row of the grid
     // the workgroup's shared copy of the libm tables, then one private region per wavefront
     // this launch's range of the processing order (see SwdMultiArgs::split)
     int lo = 0, hi = A.B;
@@ -185,10 +199,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
         if (cls == 0) hi = ndeep;
         else lo = ndeep;
     }
-    if (lo + (int)blockIdx.x * GROUP_WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
+    if (A.wg_n1 == 0 && lo + (int)blockIdx.x * GROUP_WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
     const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * GROUP_WPB);
     __syncthreads();
-    if (lo + wid * MPW >= hi) return;
+    if (beyond || lo + wid * MPW >= hi) return;
     unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
     const bool spare = lane >= MPW * LPM;
     const int g = spare ? 0 : lane / LPM;        // model slot inside the wave
@@ -262,7 +276,38 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
     const unsigned long long w_start = prof ? wall_clock64() : 0ull, c_start = prof ? clock64() : 0ull;
     unsigned int nrounds = 0;
+    // Two wavefronts share a SIMD; at equal priority the hardware serves the OLDER one first (MI355X_MICROARCH.md,
+    // "two waves per SIMD"): the older runs its rounds in ~13 k cycles, the younger in ~17 k, finishes 30 % later and
+    // sets the kernel's time.  The two therefore (a) alternate between a high and a low issue priority every
+    // PRIO_BLOCK rounds, the two hardware wave slots of a SIMD in opposite phase -- each is the favoured one half of
+    // the time -- and (b) tell each other how far they are: every PRIO_BLOCK rounds a wavefront publishes the
+    // fraction of its period list its slowest model has behind it in a small board in global memory, indexed by
+    // the physical SIMD, and reads its neighbour's; whoever is behind takes the high priority until they are level,
+    // so that both reach the end of their lists together.  (Scheduling only: results do not depend on it.)
+    unsigned hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const unsigned hw_slot = hw_id & 1u;
+    const unsigned simd_key = ((xcc_id & 7u) << 12) | ((hw_id >> 4) & 0xfffu);
+    unsigned *board = A.board ? A.board + 2u * simd_key : nullptr;
+    const bool fair = (Gflags & 0x800) == 0;
+    const unsigned total_p = (unsigned)(K * (T.mode > 0 ? T.mode : 1));
     while (__ballot(S.active) != 0ull) {
+        if (fair && (nrounds & (PRIO_BLOCK - 1)) == 0) {
+            bool high = (((nrounds / PRIO_BLOCK) ^ hw_slot) & 1u) != 0u;
+            if (board != nullptr && !(Gflags & 0x400)) {
+                // periods behind the slowest model of this wavefront, as a fraction (16 bits) of its list
+                unsigned done = valid ? (S.active ? (unsigned)((S.iq - 1) * K + S.k) : total_p) : total_p;
+                for (int off = 32; off > 0; off >>= 1) done = min(done, (unsigned)__shfl_xor((int)done, off));
+                const unsigned frac = __builtin_amdgcn_readfirstlane(total_p ? (done << 12) / total_p : 4096u);
+                const unsigned mine = (A.stamp << 16) | frac;
+                __hip_atomic_store(board + hw_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned other = __hip_atomic_load(board + (hw_slot ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((other >> 16) == A.stamp && (other & 0xffffu) != frac) high = frac < (other & 0xffffu);
+            }
+            if (high) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         ++nrounds;
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (prof) t0 = clock64();
@@ -477,6 +522,7 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
             tS += t3 - t2c;
         }
     }
+    if (board != nullptr) __hip_atomic_store(board + hw_slot, (A.stamp << 16) | 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
     if (prof) {
         unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
@@ -540,7 +586,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
         kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
         maxmode = a0.t[t].mode > maxmode ? a0.t[t].mode : maxmode;
     }
-    static const int redundant = std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0; // experiment switch
+    static const int redundant = (std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0) | (std::getenv("BH_SWD_NO_BOARD") ? 0x400 : 0) | (std::getenv("BH_SWD_NO_FAIR") ? 0x800 : 0); // experiment switches
     SwdMultiArgs a = a0;
     const bool two = a0.split != nullptr && a0.Lcut < a0.Lmax;
     if (!two) a.split = nullptr;
@@ -608,7 +654,21 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
         a.rows[0] = a.rows[1];
         a.lanes[0] = a.lanes[1];
     }
-    const dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
+    dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
+    a.wg_n0 = a.wg_n1 = 0;
+    static const bool no_mix = std::getenv("BH_SWD_NO_MIX") != nullptr; // experiment switch
+    if (a.ntargets == 2 && !two && !no_mix) { // two targets, one depth class: interleave their wavefronts (see the kernel)
+        int n[2];
+        for (int t = 0; t < 2; ++t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && a.lanes[1] * J > BH_WAVE) --J;
+            const int mpw = BH_WAVE / (a.lanes[1] * J);
+            n[t] = (a.B + mpw - 1) / mpw; // wavefronts of this target
+        }
+        a.wg_n0 = n[0];
+        a.wg_n1 = n[1];
+        grid = dim3((n[0] + n[1] + GROUP_WPB - 1) / GROUP_WPB, 1, 1);
+    }
     const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
     hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
     return 0;

@@ -33,8 +33,9 @@ def test_two_ranks_write_what_one_rank_writes(tmp_path):
     from sharded_rank import job
     dc = job(24, 0, 24, None, one)
     assert dc.sweep == 40 and dc.nswaps > 10
-    names = sorted(os.listdir(os.path.join(one, "data")))
-    assert names == sorted(os.listdir(os.path.join(two, "data")))
+    assert sorted(os.listdir(os.path.join(one, "data"))) == sorted(os.listdir(os.path.join(two, "data")))
+    assert "test_config.pkl" in os.listdir(os.path.join(two, "data"))           # what the reference's PlotFromStorage opens
+    names = sorted(n for n in os.listdir(os.path.join(one, "data")) if n.endswith(".npy"))
     assert len(names) == 2 * 5 * 6 and names[0] == "c000_p1likes.npy"          # 6 ladders, both phases
     for n in names:
         a, b = np.load(os.path.join(one, "data", n)), np.load(os.path.join(two, "data", n))

@@ -68,6 +68,27 @@ for s_ in sorted(set(share)):
     m = (share == s_) & (ifn == 2)
     if m.any():
         print("  Rayleigh waves on SIMDs with %d wave(s): n %d, kcycles/round med %.2f, dur med %.0f us" % (s_, m.sum(), np.median(cyc[m] / rounds[m]) / 1e3, np.median(dur[m])))
+# partner type: for every Rayleigh wave, is there a Love wave on its SIMD?
+love_simds = set(key[ifn == 1].tolist())
+for nm, sel in (("with a Love wave", np.array([k in love_simds for k in key]) & (ifn == 2)), ("without", np.array([k not in love_simds for k in key]) & (ifn == 2))):
+    if sel.any():
+        print("  Rayleigh waves sharing a SIMD %s: n %d, dur us med/max %.0f/%.0f, kcycles/round med %.2f" % (nm, sel.sum(), np.median(dur[sel]), dur[sel].max(), np.median(cyc[sel] / rounds[sel]) / 1e3))
 for name, o in (("R", 1), ("L", 4)):
     nw = max(1, (ifn == (2 if name == "R" else 1)).sum())
     print("  %s per-wave Mcycles: A %.2f  B %.2f  S %.2f" % (name, c[o] / nw / 1e6, c[o + 1] / nw / 1e6, c[o + 2] / nw / 1e6))
+
+# the slowest wavefronts: what do they share a SIMD / a CU with?
+cukey = key // 4
+order = np.argsort(-dur)[:12]
+print("slowest wavefronts: type rounds kcyc/round dur_us | partner on the SIMD (type rounds dur) | CU: n Rayleigh, n Love | xcc")
+for i in order:
+    mates = [j for j in np.flatnonzero(key == key[i]) if j != i]
+    cu = np.flatnonzero(cukey == cukey[i])
+    ms = " ".join("%s %d %.0f" % ("RL"[ifn[j] == 1], rounds[j], dur[j]) for j in mates) or "-"
+    print("   %s %4d %6.2f %5.0f | %-14s | %d %d | %d" % ("RL"[ifn[i] == 1], rounds[i], cyc[i] / rounds[i] / 1e3, dur[i], ms,
+          int((ifn[cu] == 2).sum()), int((ifn[cu] == 1).sum()), int((hw[i] >> 16) & 15)))
+# per-CU composition vs speed of the Rayleigh waves
+nr = np.array([int((ifn[cukey == c] == 2).sum()) for c in cukey])
+for k in sorted(set(nr[ifn == 2])):
+    m = (ifn == 2) & (nr == k)
+    print("  Rayleigh waves on CUs with %d Rayleigh wave(s): n %4d, kcycles/round med %.2f max %.2f" % (k, m.sum(), np.median(cyc[m] / rounds[m]) / 1e3, (cyc[m] / rounds[m]).max() / 1e3))
