@@ -217,8 +217,9 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
 
     // LDS carve-up of the wavefront's region (all offsets multiples of 16 B)
-    double *ca = reinterpret_cast<double *>(smem);                 // [MPW*J][Lmax][CA_STRIDE]
-    double *xs = ca + (size_t)MPW * J * Lmax * CA_STRIDE;          // [11][MPW]
+    const int prow = Lmax > 1 ? Lmax - 1 : 1;                      // parked rows per group: the finite layers
+    double *ca = reinterpret_cast<double *>(smem);                 // [MPW*J][prow][CA_STRIDE]
+    double *xs = ca + (size_t)MPW * J * prow * CA_STRIDE;          // [11][MPW]
     double *ys = xs + NEV_MAX * MPW;
     double *per = ys + NEV_MAX * MPW;                              // [K]
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     md.b = mdl + 2 * Lmax * MPW + g;
     md.rho = mdl + 3 * Lmax * MPW + g;
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
-    double *cam = ca + (size_t)slot * Lmax * CA_STRIDE; // this group's parked layers
+    double *cam = ca + (size_t)slot * prow * CA_STRIDE; // this group's parked layers
     const bool par5 = (G >= 5) && !(Gflags & 0x100);
     const int gbase = slot * G; // first lane of this group
     // one layer count for the whole wavefront and no water layer: the recursion needs no masking
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / (G * J);
-    return ((size_t)MPW * J * Lmax * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
+    return ((size_t)MPW * J * (Lmax > 1 ? Lmax - 1 : 1) * CA_STRIDE + (size_t)2 * NEV_MAX * MPW +
             (size_t)((Kmax + 1) & ~1)) * sizeof(double) +
            (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) +
            (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
