@@ -11,7 +11,8 @@
 //
 // Work split: workgroup (bx, by) = 64 models x one slab of columns; 4 waves, wave w owns models
 // [16w, 16w+16) and all four 16-column blocks of the current 64-column tile (one A fragment feeds
-// four MFMAs).  K is streamed through LDS in tiles of 32.  Column slabs are summed later in a
+// four MFMAs).  K is streamed through LDS in tiles of 32, the global loads of the next tile in flight while
+// the MFMAs of the current one run (register double buffer).  Column slabs are summed later in a
 // fixed order by like_kernel, so the result does not depend on scheduling (no atomics).
 #include "bh_device.h"
 
@@ -34,35 +35,38 @@ __global__ __launch_bounds__(256, 2) void gauss_quad_kernel(int B, int n, int ld
     const int fi = l & 15, fk = l >> 4; // fragment coordinates
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 
+    // staging coordinates: D tile: thread -> model tid/4, 8 consecutive k; R^-1 tile: thread -> row tid/8, 8 consecutive columns
+    const int d_mdl = tid >> 2, d_kq = (tid & 3) * 8, d_gb = m0 + d_mdl;
+    const int r_kr = tid >> 3, r_cq = (tid & 7) * 8;
     for (int jt = c_begin; jt < c_end; jt += 64) {
         double4_t c[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) c[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // software pipeline: the global loads of K tile t+1 are in flight while the MFMAs of tile t run
+        double dreg[8], rreg[8];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + d_kq + i;
+                dreg[i] = (d_gb < B && k < n) ? ymod[(size_t)d_gb * ldy + k] - yobs[k] : 0.0;
+            }
+            const int k = k0 + r_kr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int col = jt + r_cq + i;
+                rreg[i] = (k < n && col < c_end) ? rinv[(size_t)k * n + col] : 0.0;
+            }
+        };
+        fetch(0);
         for (int k0 = 0; k0 < n; k0 += KT) {
             __syncthreads();
-            { // D tile: thread -> model tid/4, 8 consecutive k
-                const int mdl = tid >> 2, kq = (tid & 3) * 8;
-                const int gb = m0 + mdl;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = k0 + kq + i;
-                    double v = 0.0;
-                    if (gb < B && k < n) v = ymod[(size_t)gb * ldy + k] - yobs[k];
-                    Dt[kq + i][mdl] = v;
-                }
-            }
-            { // R^-1 tile: thread -> row tid/8, 8 consecutive columns
-                const int kr = tid >> 3, cq = (tid & 7) * 8;
-                const int k = k0 + kr;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int col = jt + cq + i;
-                    double v = 0.0;
-                    if (k < n && col < c_end) v = rinv[(size_t)k * n + col];
-                    Rt[kr][cq + i] = v;
-                }
+            for (int i = 0; i < 8; ++i) {
+                Dt[d_kq + i][d_mdl] = dreg[i];
+                Rt[r_kr][r_cq + i] = rreg[i];
             }
             __syncthreads();
+            if (k0 + KT < n) fetch(k0 + KT);
 #pragma unroll
             for (int kk = 0; kk < KT; kk += 4) {
                 const double a = Dt[kk + fk][w * 16 + fi];

@@ -110,3 +110,28 @@ def test_model_params_mode_and_flsph():
                 assert np.array_equal(y, g["y_mode2"][jj, ir])
             else:
                 assert np.isnan(x) and np.isnan(y)
+
+
+def test_synthobs_call_pattern_is_served():
+    """The reference's SynthObs (src/SynthObs.py:25-99; named in the north_star, out of scope as a class) drives the
+    plugins like this: Target(x=x, y=None) -> moddata.plugin.set_modelparams(mode= | gauss=, water=, p=, nsv=) ->
+    run_model(h=, vp=, vs=, rho=) with keyword arguments -> (xmod, ymod).  The same calls on this package's classes
+    reproduce the reference's observed-data files for the tutorial model to the files' 4-decimal rounding
+    (RF: the files predate the float64 rfmini and pin it to 1e-4 absolute)."""
+    h, vs, vpvs = np.array([5., 23., 8., 0.]), np.array([2.7, 3.6, 3.8, 4.4]), 1.73      # tutorial/create_testdata.py:13-15
+    vp = vs * vpvs
+    rho = vp * 0.32 + 0.77
+    x = np.linspace(1, 41, 21)
+    for ref, cls in CLS.items():
+        target = cls(x=x, y=None)
+        target.moddata.plugin.set_modelparams(mode=1)
+        xmod, ymod = target.moddata.plugin.run_model(h=h, vp=vp, vs=vs, rho=rho)
+        assert target.ref == ref and np.array_equal(xmod, x)
+        assert np.max(np.abs(ymod - st3(ref)[1])) <= 6e-5
+    xr = np.linspace(-5, 35, 201)
+    for ref, cls in (("prf", bh.PReceiverFunction), ("srf", bh.SReceiverFunction)):
+        target = cls(x=xr, y=None)
+        target.moddata.plugin.set_modelparams(gauss=1.0, water=0.001, p=6.4, nsv=None)
+        xmod, ymod = target.moddata.plugin.run_model(h=h, vp=vp, vs=vs, rho=rho)
+        assert target.ref == ref and np.allclose(xmod, xr, atol=1e-9)
+        assert np.max(np.abs(ymod - st3(ref)[1])) <= 1.5e-4
