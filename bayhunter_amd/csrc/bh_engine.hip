@@ -38,6 +38,8 @@ struct bh_engine {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;             // receiver-function kernels run here, next to the dispersion kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux2 = nullptr;            // second dispersion target of a lane-per-model call runs here, beside the first
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     int look_r = 0, look_l = 0;            // BH_SWD_LOOK_R / BH_SWD_LOOK_L env (experiment switches): trials per round by wave type
     bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
     std::string err;
@@ -94,6 +96,7 @@ int ensure(bh_engine *e, DevBuf &b, size_t bytes)
     if (b.p) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->aux) HIPCHK(e, hipStreamSynchronize(e->aux));
+        if (e->aux2) HIPCHK(e, hipStreamSynchronize(e->aux2));
         HIPCHK(e, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -309,6 +312,17 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         split = (Lcut < Lmax) ? p : nullptr;
     }
     if (G <= 1) {
+        // One lane per model: a launch per target.  A wavefront of these kernels keeps its SIMD's vector issue ~60 %
+        // busy (profiles/), so the targets of a call run SIDE BY SIDE: every second one on a second stream.
+        int nlive2 = 0;
+        for (int j = 0; j < njobs; ++j) nlive2 += (jobs[j].K != 0);
+        const bool fork2 = nlive2 > 1 && e->aux2 != nullptr;
+        ev_begin(e, 0, st);
+        if (fork2) {
+            HIPCHK(e, hipEventRecord(e->ev_fork2, st));
+            HIPCHK(e, hipStreamWaitEvent(e->aux2, e->ev_fork2, 0));
+        }
+        int nth = 0;
         for (int j = 0; j < njobs; ++j) {
             const SwdJob &J = jobs[j];
             if (J.K == 0) continue;
@@ -320,10 +334,14 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                 a.sl = B; a.sb = 1;
             }
             a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
-            ev_begin(e, 0, st);
-            bh_launch_swd(a, J.iwave, st);
-            ev_end(e, 0, st);
+            bh_launch_swd(a, J.iwave, (fork2 && (nth & 1)) ? e->aux2 : st);
+            ++nth;
         }
+        if (fork2) {
+            HIPCHK(e, hipEventRecord(e->ev_join2, e->aux2));
+            HIPCHK(e, hipStreamWaitEvent(st, e->ev_join2, 0));
+        }
+        ev_end(e, 0, st);
         HIPCHK(e, hipGetLastError());
         return BH_OK;
     }
@@ -437,7 +455,10 @@ int bh_engine_create(int device, bh_engine **out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join2, hipEventDisableTiming) != hipSuccess) {
         delete e;
         return BH_EHIP;
     }
@@ -500,6 +521,9 @@ void bh_engine_destroy(bh_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
+    if (e->ev_join2) (void)hipEventDestroy(e->ev_join2);
+    if (e->aux2) (void)hipStreamDestroy(e->aux2);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }

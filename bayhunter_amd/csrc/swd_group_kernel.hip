@@ -302,7 +302,10 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
                 for (int off = 32; off > 0; off >>= 1) done = min(done, (unsigned)__shfl_xor((int)done, off));
                 const unsigned frac = __builtin_amdgcn_readfirstlane(total_p ? (done << 12) / total_p : 4096u);
                 const unsigned mine = (A.stamp << 16) | frac;
-                __hip_atomic_store(board + hw_slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (plain store: written through the CU's L1 and KEPT in the XCD's L2 -- an agent-scope atomic store drops
+                // the line, and every look at the board then went to memory: 25 MB per launch; the load bypasses L1.
+                // Both wavefronts sit on the same CU, hence behind the same L2.)
+                *reinterpret_cast<volatile unsigned *>(board + hw_slot) = mine;
                 const unsigned other = __hip_atomic_load(board + (hw_slot ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((other >> 16) == A.stamp && (other & 0xffffu) != frac) high = frac < (other & 0xffffu);
             }
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
             tS += t3 - t2c;
         }
     }
-    if (board != nullptr) __hip_atomic_store(board + hw_slot, (A.stamp << 16) | 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (board != nullptr) *reinterpret_cast<volatile unsigned *>(board + hw_slot) = (A.stamp << 16) | 0xffffu;
     if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
     if (prof) {
         unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;

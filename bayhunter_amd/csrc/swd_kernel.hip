@@ -293,7 +293,7 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 // ceil(wavefronts / 2048) rounds, each as long as its longest wavefront.  Relative wavefront durations:
 //   group kernel, Rayleigh: 1 / .64 / .52 / .45 / .36 for 1 / 2 / 3 / 4 / 7 trials per round,
 //   group kernel, Love:     .735 / .54 / .39 / .33 / .26 (with two in-group trials at the first two levels),
-//   one lane per model:     4.3 (64 models per wavefront, every layer term serial).
+//   one lane per model:     2.7 (64 models per wavefront, every layer term serial; the targets of a call side by side).
 // More trials shorten every model's chain of dependent secular evaluations (what a small batch is bound
 // by) but cost lanes, i.e. wavefronts.  The plan minimises rounds x longest wavefront.
 namespace {
@@ -301,7 +301,7 @@ constexpr int PLAN_LEVELS = 5;
 const int plan_trials[PLAN_LEVELS] = {1, 2, 3, 4, 7};
 const double plan_dur[2][PLAN_LEVELS] = {{0.735, 0.54, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
 constexpr int PLAN_SLOTS = 2048;
-constexpr double PLAN_LANE_PER_MODEL = 4.3;
+constexpr double PLAN_LANE_PER_MODEL = 2.7;
 
 int plan_fit(int G, int level) // largest trial count <= the level's that fits a wavefront
 {
