@@ -21,8 +21,12 @@
 //                       inverse FFT of length nsamp in LDS (32 KB at nsamp = 2048 + 16 KB twiddles);
 //                       only the first nkeep real samples are written (rfmini_modrf.py:142).
 #include "bh_device.h"
+#include <cmath>
+#include <cstdlib>
 
 namespace {
+// w / a beyond which the Gauss low-pass exp(-(w/a)^2 / 4) is below 1e-30: 2 sqrt(30 ln 10)
+constexpr double RF_CUT_WA = 16.6226;
 
 struct cd {
     double re, im;
@@ -38,7 +42,6 @@ __device__ __forceinline__ cd operator*(cd a, cd b)
 __device__ __forceinline__ cd operator*(double s, cd a) { return cd{s * a.re, s * a.im}; }
 __device__ __forceinline__ cd operator*(cd a, double s) { return cd{s * a.re, s * a.im}; }
 __device__ __forceinline__ cd operator+(double s, cd a) { return cd{s + a.re, a.im}; }
-__device__ __forceinline__ cd operator-(cd a, double s) { return cd{a.re - s, a.im}; }
 __device__ __forceinline__ cd conj(cd a) { return cd{a.re, -a.im}; }
 __device__ __forceinline__ cd crecip(cd b)
 {
@@ -57,11 +60,97 @@ __device__ __forceinline__ cd csqrt_d(cd z)
     const double t = sqrt(0.5 * (r - z.re));
     return cd{fabs(z.im) / (2.0 * t), copysign(t, z.im)};
 }
-__device__ __forceinline__ cd cexp_d(cd z)
+// ---- elementary functions of the per-frequency recursion ------------------------------------------
+// The receiver function is held to 1e-4 of its peak (north_star), the tests to 1e-9; the library's correctly
+// rounded division / sqrt / hypot and its sincos / exp with their special-case paths are two thirds of the
+// instructions of a layer step.  These are the same functions to ~2 ulp for the arguments that occur here
+// (finite, normal range): hardware seed + two Newton steps, Cody-Waite reduction + minimax polynomials
+// (coefficients: fdlibm's __kernel_sin / __kernel_cos).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+// 1/sqrt(x), x > 0
+__device__ __forceinline__ double rsq_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+// sin and cos of a moderate argument (|x| < 2^20: |k| * 2^-107 of reduction error)
+__device__ __forceinline__ void sincos_cw(double x, double *sn, double *cs)
+{
+    const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);
+    double r = fma(-k, 0x1.921fb54442d18p+0, x);
+    r = fma(-k, 0x1.1a62633145c07p-54, r);
+    const int q = (int)k;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    *sn = (q & 2) ? -so : so;
+    *cs = ((q + 1) & 2) ? -co : co;
+}
+// e^x, Taylor of degree 13 on |r| <= ln2/2 (remainder 4e-18), scaled by ldexp (under/overflow as ldexp's)
+__device__ __forceinline__ double exp_cw(double x)
+{
+    const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(-k, 0x1.62e42fefa39efp-1, x);
+    r = fma(-k, 0x1.abc9e3b39803fp-56, r);
+    double p = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+    p = fma(r, p, 1.0 / 39916800.0);
+    p = fma(r, p, 1.0 / 3628800.0);
+    p = fma(r, p, 1.0 / 362880.0);
+    p = fma(r, p, 1.0 / 40320.0);
+    p = fma(r, p, 1.0 / 5040.0);
+    p = fma(r, p, 1.0 / 720.0);
+    p = fma(r, p, 1.0 / 120.0);
+    p = fma(r, p, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    const double kk = fmin(fmax(k, -2000.0), 2000.0);
+    return ldexp(p, (int)kk);
+}
+__device__ __forceinline__ cd crecip_f(cd b)
+{
+    const double i = rcp_nr(b.re * b.re + b.im * b.im);
+    return cd{b.re * i, -b.im * i};
+}
+// principal square root, branch-free; 0 for z = 0
+__device__ __forceinline__ cd csqrt_f(cd z)
+{
+    const double n2 = z.re * z.re + z.im * z.im;
+    const double r = n2 * rsq_nr(n2);                 // |z|
+    const double y = 0.5 * (r + fabs(z.re));
+    const double it = rsq_nr(y), t = y * it;          // t = sqrt(y), it = 1/t
+    const double u = 0.5 * z.im * it;                 // im / (2t)
+    cd o = (z.re >= 0.0) ? cd{t, u} : cd{fabs(u), copysign(t, z.im)};
+    if (!(n2 > 0.0)) o = cd{n2, n2};                  // 0 -> 0, NaN -> NaN
+    return o;
+}
+// e^z
+__device__ __forceinline__ cd cexp_f(cd z)
 {
     double s, c;
-    sincos(z.im, &s, &c);
-    const double m = exp(z.re);
+    sincos_cw(z.im, &s, &c);
+    const double m = exp_cw(z.re);
     return cd{m * c, m * s};
 }
 
@@ -83,7 +172,7 @@ __device__ __forceinline__ cm2 operator+(const cm2 &x, const cm2 &y)
 //  (the last two doubles of the record: the model's Nyquist bin, re / im)
 //  [4..7] m11 m12 m21 m22 (rotation)   [8..15] 2*h matrix (4 complex)
 //  [16..23] free-surface ru (4 complex)
-//  [24 + 8*l ...]           layer l = 0..Lmax-1 : vp, vs, h (flattened), qp, qs, -, -, -
+//  [24 + 8*l ...]           layer l = 0..Lmax-1 : 1/vp^2, 1/vs^2, h (flattened), 1/(pi qp), 1/(2 qp), 1/(pi qs), 1/(2 qs), -
 //  [24 + 8*Lmax + 32*i ...] interface below layer i (i = 0..Lmax-2): rd, td, ru, tu (4 complex each)
 constexpr int REC_HEAD = 24;
 __host__ __device__ inline size_t rec_doubles(int Lmax) { return REC_HEAD + 8 * (size_t)Lmax + 32 * (size_t)Lmax + 2; }
@@ -164,15 +253,17 @@ __device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, i
     const double *ifc = rec + REC_HEAD + 8 * Lmax;
     for (int i = 1; i < nlay; ++i) {
         const double *L = lay + 8 * (i - 1);
-        const double vp = L[0], vs = L[1], d = L[2], qp = L[3], qs = L[4];
-        // complex velocities with causal Q (greens.cpp:539-543), vertical slownesses, phases
-        const cd vpc = vp * cd{1. + lgw / (M_PI * qp), 1. / (2. * qp)};
-        const cd vsc = vs * cd{1. + lgw / (M_PI * qs), 1. / (2. * qs)};
-        const cd plc = csqrt_d(crecip(vpc * vpc) - p2);
-        const cd slc = csqrt_d(crecip(vsc * vsc) - p2);
-        const cd miwd = cd{0., -w * d};
-        const cd e11 = cexp_d(miwd * plc);
-        const cd e22 = cexp_d(miwd * slc);
+        // complex velocities with causal Q, v (a + i b) with a = 1 + ln(w/wref)/(pi Q), b = 1/(2Q) (greens.cpp:539-543);
+        // 1/v^2 - p^2 with 1/(a + ib)^2 = (a - ib)^2 / (a^2 + b^2)^2; vertical slownesses; phases e^{-i w d q}
+        const double d = L[2];
+        const double ap = fma(lgw, L[3], 1.0), bp = L[4], as = fma(lgw, L[5], 1.0), bs = L[6];
+        const double np = ap * ap + bp * bp, ns = as * as + bs * bs;
+        const double ip = L[0] * rcp_nr(np * np), is = L[1] * rcp_nr(ns * ns);
+        const cd plc = csqrt_f(cd{ip * (ap * ap - bp * bp) - p2, -2.0 * ip * ap * bp});
+        const cd slc = csqrt_f(cd{is * (as * as - bs * bs) - p2, -2.0 * is * as * bs});
+        const double wd = w * d;
+        const cd e11 = cexp_f(cd{wd * plc.im, -wd * plc.re});
+        const cd e22 = cexp_f(cd{wd * slc.im, -wd * slc.re});
         // Mueller (1985) top-down recursion, greens.cpp:196-224
         cm2 nt;
         if (i == 1)
@@ -187,7 +278,7 @@ __device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, i
         const cm2 rdn = load_cm2(icn), tun = load_cm2(icn + 24);
         const cm2 rn = rdn * nb;
         const cm2 m = cm2{C(1.) - rn.c11, -rn.c12, -rn.c21, C(1.) - rn.c22};
-        const cd idet = crecip(m.c11 * m.c22 - m.c12 * m.c21);
+        const cd idet = crecip_f(m.c11 * m.c22 - m.c12 * m.c21);
         const cm2 minv = cm2{idet * m.c22, -(idet * m.c12), -(idet * m.c21), idet * m.c11};
         q = minv * tun;
         if (i == 1)
@@ -218,12 +309,12 @@ __device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, i
         cz = cr;
         cr = t;
     }
-    const double denom = cz.re * cz.re + cz.im * cz.im;
+    const double idenom = rcp_nr(cz.re * cz.re + cz.im * cz.im);
     const cd num = cr * conj(cz);
-    const cd v = cd{num.re / denom, num.im / denom};
+    const cd v = cd{num.re * idenom, num.im * idenom};
     double wa = w / gauss;
     wa = (wa > 50.0) ? 50.0 : wa;
-    const cd cq = qg * cexp_d(cd{-0.25 * (wa * wa), -w * tshift});
+    const cd cq = qg * cexp_f(cd{-0.25 * (wa * wa), -w * tshift});
     return v * cq;
 }
 
@@ -275,7 +366,8 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
             hh = R * log(q) - zf;
         }
         double *lay = rec + REC_HEAD + 8 * l;
-        lay[0] = vp; lay[1] = vs; lay[2] = hh; lay[3] = qp; lay[4] = qs;
+        lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
+        lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
         // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
         const double vv = (A.waveno == 0) ? vp : vs;
         t0 += hh * sqrt(1. / (vv * vv) - p2);
@@ -342,7 +434,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
 
 // Spectrum of one model into LDS (bit-reversed, Hermitian-extended), inverse FFT of length N = nsamp in LDS:
 // iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) sum_k X[k] e^{+2 pi i k n / N}.
-__global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn)
+__global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn, int jcut)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = A.nsamp, half = N / 2;
@@ -356,16 +448,18 @@ __global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn)
     const double *rec = A.coef + (size_t)ib * recsz;
     for (int k = tid; k < half; k += 256) {
         double s, c;
-        sincospi(2.0 * (double)k / (double)N, &s, &c);
+        sincos_cw((2.0 * M_PI / (double)N) * (double)k, &s, &c);
         tw[k] = make_double2(c, s);
     }
     const int shift = 32 - logn;
     for (int j = tid; j < half; j += 256) {
-        const cd s = rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
+        // bins from jcut on: the Gauss low-pass has them below 1e-30 of the pass band (see bh_launch_rf)
+        const cd s = (j < jcut) ? rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
         x[(int)(__brev((unsigned)j) >> shift)] = make_double2(s.re, s.im);
         if (j > 0) x[(int)(__brev((unsigned)(N - j)) >> shift)] = make_double2(s.re, -s.im); // cx[N-j] = conj(cx[j])
     }
-    if (tid == 0) x[(int)(__brev((unsigned)half) >> shift)] = make_double2(rec[recsz - 2], rec[recsz - 1]);
+    if (tid == 0)
+        x[(int)(__brev((unsigned)half) >> shift)] = (half < jcut) ? make_double2(rec[recsz - 2], rec[recsz - 1]) : make_double2(0.0, 0.0);
     __syncthreads();
     for (int s = 0; s < logn; ++s) {
         const int l = 1 << s;          // half-size of the butterflies of this stage
@@ -397,5 +491,13 @@ void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     while ((1 << logn) < a.nsamp) ++logn;
     hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
     const size_t lds = (size_t)a.nsamp * 16 + (size_t)half * 16;
-    hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logn);
+    // Spectral cut-off.  Every bin carries the Gauss low-pass exp(-w^2 / (4 a^2)) (greens.cpp:343-398); where that
+    // factor is below 1e-30 the bin is below 1e-30 of the pass band (|R/Z| is of order one) and cannot change a
+    // double-precision sum of the others: such bins are set to zero instead of being computed (the reference
+    // computes them and multiplies by ~0).  With a = 2.5, 20 Hz, nsamp 2048 that is every bin above 6.6 Hz, a third.
+    static const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch
+    const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
+    const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
+    const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
+    hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logn, jcut);
 }
