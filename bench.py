@@ -431,11 +431,11 @@ def main():
         swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
         achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
         pmc = pmc_summary(args.workload, B)
-        traffic = None
-        if "hbm_bytes_per_launch" in pmc:
-            traffic = {"hbm_bytes_per_launch": pmc["hbm_bytes_per_launch"], "source": pmc.get("source")}
+        # measured HBM bytes per launch (PMC pass of tools/profile_round.sh, committed summary); null without one
+        traffic = pmc.get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
+                "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
                 "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
                         "(SURVEY.md 8(d)): see binding"}
