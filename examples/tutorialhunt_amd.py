@@ -51,5 +51,7 @@ else:
     opt = bh.MCMC_Optimizer(targets, initparams=initparams, priors=priors, random_seed=None)
     path = opt.mp_inversion()
     like = np.array([c.currentlikelihood for c in opt.batch.chains])
-print("result files in", path)
+# what the reference's tutorial does next with PlotFromStorage: outlier chains + merged posterior files c_*.npy
+outliers = bh.save_final_distribution(path, maxmodels=100000, dev=0.05)   # `path` = <savepath>/data
+print("result files in", path, "- outlier chains:", [int(o) for o in outliers])
 print("final log-likelihood of the chains: median %.1f, best %.1f" % (np.median(like), like.max()))
