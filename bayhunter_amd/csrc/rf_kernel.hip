@@ -18,7 +18,8 @@
 //                       wave-uniform (scalar loads).  Deconvolution + Gauss filter + time shift
 //                       (:343-398) are fused and the sample goes, with its Hermitian mirror, straight
 //                       to its bit-reversed place in LDS: the spectrum never exists in HBM.  Then the
-//                       inverse FFT of length nsamp in LDS (32 KB at nsamp = 2048 + 16 KB twiddles);
+//                       inverse FFT of length nsamp in LDS (32 KB at nsamp = 2048 + 8 KB twiddles:
+//                       four workgroups per CU);
 //                       only the first nkeep real samples are written (rfmini_modrf.py:142).
 #include "bh_device.h"
 #include <cmath>
@@ -434,19 +435,20 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
 
 // Spectrum of one model into LDS (bit-reversed, Hermitian-extended), inverse FFT of length N = nsamp in LDS:
 // iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) sum_k X[k] e^{+2 pi i k n / N}.
-__global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn, int jcut)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void rf_synth_kernel(RfKernelArgs A, int logn, int jcut)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = A.nsamp, half = N / 2;
     double2 *x = reinterpret_cast<double2 *>(smem);       // [N]
-    double2 *tw = x + N;                                   // [N/2]  e^{+2 pi i k / N}
+    double2 *tw = x + N;                                   // [N/4]  e^{+2 pi i k / N}, k < N/4; e^{i(t + pi/2)} = i e^{it} gives the rest
     const int ib = blockIdx.x;
     const int tid = threadIdx.x;
     const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
     const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
     const size_t recsz = rec_doubles(A.Lmax);
     const double *rec = A.coef + (size_t)ib * recsz;
-    for (int k = tid; k < half; k += 256) {
+    const int quarter = N / 4;
+    for (int k = tid; k < quarter; k += 256) {
         double s, c;
         sincos_cw((2.0 * M_PI / (double)N) * (double)k, &s, &c);
         tw[k] = make_double2(c, s);
@@ -467,7 +469,9 @@ __global__ __launch_bounds__(256) void rf_synth_kernel(RfKernelArgs A, int logn,
         for (int bfly = tid; bfly < half; bfly += 256) {
             const int m = bfly & (l - 1);
             const int i = ((bfly >> s) << (s + 1)) + m;
-            const double2 w = tw[m * tstride];
+            const int ti = m * tstride;
+            const double2 w0 = tw[ti & (quarter - 1)];
+            const double2 w = (ti < quarter) ? w0 : make_double2(-w0.y, w0.x);
             const double2 u = x[i], v = x[i + l];
             const double2 t = make_double2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
             x[i + l] = make_double2(u.x - t.x, u.y - t.y);
@@ -490,7 +494,7 @@ void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     int logn = 0;
     while ((1 << logn) < a.nsamp) ++logn;
     hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
-    const size_t lds = (size_t)a.nsamp * 16 + (size_t)half * 16;
+    const size_t lds = (size_t)a.nsamp * 16 + (size_t)(half / 2 > 0 ? half / 2 : 1) * 16; // spectrum + quarter twiddle table
     // Spectral cut-off.  Every bin carries the Gauss low-pass exp(-w^2 / (4 a^2)) (greens.cpp:343-398); where that
     // factor is below 1e-30 the bin is below 1e-30 of the pass band (|R/Z| is of order one) and cannot change a
     // double-precision sum of the others: such bins are set to zero instead of being computed (the reference
