@@ -59,6 +59,7 @@ struct SwdKernelArgs {
     int ldv;          // row stride of vel in elements
     int32_t *err;     // [B]
     unsigned long long *neval; // optional global counter of secular evaluations (may be null)
+    int look;         // trial velocities per round and model = lanes per model (1, 2, 4, 8 or 16), see SearchT::candidate
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);

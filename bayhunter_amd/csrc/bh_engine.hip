@@ -291,8 +291,8 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         int Lplan = m.typ_layers > 0 ? m.typ_layers : (e->hint_layers > 0 ? e->hint_layers : Lmax);
         if (Lplan > Lmax) Lplan = Lmax;
         bh_swd_plan(B, Lplan, n, iw, e->force_group, &G, look);
-        if (e->force_look > 0 && G > 1)
-            for (int t = 0; t < n; ++t) look[t] = e->force_look;
+        if (e->force_look > 0)
+            for (int t = 0; t < n; ++t) look[t] = e->force_look; // (one lane per model: rounded down to a power of two)
     }
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
@@ -334,6 +334,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                 a.sl = B; a.sb = 1;
             }
             a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
+            a.look = look[nth] > 1 ? look[nth] : 1;
             bh_launch_swd(a, J.iwave, (fork2 && (nth & 1)) ? e->aux2 : st);
             ++nth;
         }
@@ -488,8 +489,8 @@ int bh_engine_set_typical_layers(bh_engine *e, int nlay)
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round)
 {
     if (!e) return BH_EINVAL;
-    if (trials_per_round < 0 || trials_per_round > 12)
-        return fail(e, BH_EINVAL, "look-ahead must be 0 (auto) or 1..12 trial velocities per round");
+    if (trials_per_round < 0 || trials_per_round > 16)
+        return fail(e, BH_EINVAL, "look-ahead must be 0 (auto) or 1..16 trial velocities per round");
     e->force_look = trials_per_round;
     return BH_OK;
 }

@@ -43,15 +43,25 @@ namespace {
 #include "swd_common.h"
 
 // =================================================================================================
-// Kernel 1: one lane = one model (G = 1).  Best when the batch alone fills the chip
-// (B*targets/64 >> 1024 waves); everything per-layer stays in registers.
+// Kernel 1: one lane = one secular evaluation of one model, all layers serial in the lane; everything
+// per-layer stays in registers.
+//   J = 1   one lane = one model.  Best when the batch alone fills the chip (B*targets/64 >= 2048 waves).
+//   J > 1   J neighbouring lanes = one model, lane r evaluating the velocity the search will most probably
+//           ask for r requests from now (SearchT::candidate; the look-ahead of the group kernel without its
+//           layer-parallel phases): for the batches in between, which give the group kernel several rounds of
+//           wavefronts but this kernel, one lane per model, less than one wavefront per SIMD.  Every lane of a
+//           model holds the same search state and steps it with the same values: no broadcast.
+// Same operations, same bits for every J.
 // =================================================================================================
-template <int IFUNC>
+template <int IFUNC, bool LOOK>
 __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    const int sidx = blockIdx.x * BH_WAVE + lane; // position in the processing order
+    const int J = LOOK ? A.look : 1;      // power of two, 1..16
+    const int r = lane & (J - 1);         // this lane's trial
+    const int lbase = lane - r;           // first lane of the model
+    const int sidx = (blockIdx.x * BH_WAVE + lane) / J; // position in the processing order
     const bool valid = sidx < A.B;
     const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
     const int Lmax = A.Lmax;
@@ -97,32 +107,48 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
 
     SearchT<BH_WAVE> S;
-    S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, true, A.mode,
+    S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
            cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
 
     while (__ballot(S.active) != 0ull) {
-        if (!S.active) continue;
-        const double wvno = S.omega / S.ceval;
+        if (!S.active) continue; // (the lanes of a model share its state: they leave together)
+        const double omg = S.omega;
+        const double cev = LOOK ? S.candidate(r) : S.ceval;
+        const double wvno = omg / cev;
         double del;
         DivRange dr;
         dr.reset();
         if (IFUNC == 1)
-            del = love_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
+            del = love_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT);
         else
-            del = rayleigh_secular<false>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
+            del = rayleigh_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT);
         if (!dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
             if (IFUNC == 1)
-                del = love_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
+                del = love_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT);
             else
-                del = rayleigh_secular<true>(wvno, S.omega, md, mmax, llw, mtop, dr, LT);
+                del = rayleigh_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT);
         }
-        S.advance(del);
+        if (!LOOK) {
+            S.advance(del);
+        } else {
+            // every lane of the model reads all J (velocity, value) pairs; the search consumes them for as long as
+            // its next request is the very velocity (at the same omega) the next lane evaluated
+            bool live = true;
+            for (int j = 0; j < J; ++j) {
+                const double cj = __shfl(cev, lbase + j);
+                const double dj = __shfl(del, lbase + j);
+                // trial 0 IS the pending request (consumed unconditionally); a later one only if asked for now
+                if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
+                if (__ballot(live) == 0ull) break;
+                if (live) S.advance(dj);
+            }
+        }
     }
-    if (valid) A.err[ib] = S.errflag;
+    if (valid && r == 0) A.err[ib] = S.errflag;
     if (A.neval != nullptr) {
         // [0] secular evaluations; per wave type ([8] Rayleigh / [9] Love) evaluations and ([10] / [11]) layer-
         // propagator steps = evaluations x finite layers of the model (the flop model of SURVEY.md 8(d))
-        unsigned long long tot = S.evals, lps = (unsigned long long)S.evals * (unsigned long long)(valid ? mmax - 1 : 0);
+        unsigned long long tot = (r == 0) ? S.evals : 0u, lps = tot * (unsigned long long)(valid ? mmax - 1 : 0);
         for (int off = 32; off > 0; off >>= 1) {
             tot += __shfl_xor(tot, off);
             lps += __shfl_xor(lps, off);
@@ -278,12 +304,20 @@ size_t bh_swd_lds_bytes(int Lmax, int K, int mode)
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 {
-    const int grid = (a.B + BH_WAVE - 1) / BH_WAVE;
+    SwdKernelArgs b = a;
+    int J = 1;
+    while (2 * J <= a.look && 2 * J <= 16) J *= 2; // largest power of two <= look
+    b.look = J;
+    const int mpw = BH_WAVE / J;
+    const int grid = (a.B + mpw - 1) / mpw;
     const size_t lds = bh_swd_lds_bytes(a.Lmax, a.K, a.mode);
-    if (iwave == 1)
-        hipLaunchKernelGGL(swd_kernel<1>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
-    else
-        hipLaunchKernelGGL(swd_kernel<2>, dim3(grid), dim3(BH_WAVE), lds, stream, a);
+    if (iwave == 1) {
+        if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+        else hipLaunchKernelGGL((swd_kernel<1, false>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+    } else {
+        if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+        else hipLaunchKernelGGL((swd_kernel<2, false>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+    }
 }
 
 // ---- launch plan ------------------------------------------------------------------------------------
@@ -293,7 +327,8 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 // ceil(wavefronts / 2048) rounds, each as long as its longest wavefront.  Relative wavefront durations:
 //   group kernel, Rayleigh: 1 / .64 / .52 / .45 / .36 for 1 / 2 / 3 / 4 / 7 trials per round,
 //   group kernel, Love:     .735 / .54 / .39 / .33 / .26 (with two in-group trials at the first two levels),
-//   one lane per model:     2.7 (64 models per wavefront, every layer term serial; the targets of a call side by side).
+//   one lane per model:     3.44 (64 models per wavefront, every layer term serial; the targets of a call side by side);
+//                           x 1 / .60 / .40 / .30 / .26 with 1 / 2 / 4 / 8 / 16 trial lanes per model.
 // More trials shorten every model's chain of dependent secular evaluations (what a small batch is bound
 // by) but cost lanes, i.e. wavefronts.  The plan minimises rounds x longest wavefront.
 namespace {
@@ -301,7 +336,9 @@ constexpr int PLAN_LEVELS = 5;
 const int plan_trials[PLAN_LEVELS] = {1, 2, 3, 4, 7};
 const double plan_dur[2][PLAN_LEVELS] = {{0.735, 0.54, 0.39, 0.33, 0.26}, {1.0, 0.64, 0.52, 0.45, 0.36}};
 constexpr int PLAN_SLOTS = 2048;
-constexpr double PLAN_LANE_PER_MODEL = 2.7;
+constexpr double PLAN_LANE_PER_MODEL = 3.44; // in units of a 1-trial Rayleigh wavefront of the group kernel sharing its SIMD
+constexpr int PLAN_LANE_LEVELS = 5; // 1, 2, 4, 8, 16 trial lanes per model
+const double plan_lane_dur[PLAN_LANE_LEVELS] = {1.0, 0.60, 0.40, 0.30, 0.26};
 
 int plan_fit(int G, int level) // largest trial count <= the level's that fits a wavefront
 {
@@ -365,12 +402,27 @@ double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, 
             }
         }
     }
-    // the lane-per-model kernel: one launch per target, 64 models per wavefront
-    const long w1 = (long)ntargets * ((B + BH_WAVE - 1) / BH_WAVE);
-    const double c1 = (double)((w1 + PLAN_SLOTS - 1) / PLAN_SLOTS) * PLAN_LANE_PER_MODEL;
+    // the lane-per-evaluation kernel: one launch per target, 64 / J models per wavefront, J = trial lanes per model.
+    // Measured (B = 4096 ... 32 768, Rayleigh + Love side by side): one wavefront per SIMD or less -> 14.9 / 8.9 / 5.9 /
+    // 4.4 / 3.9 ms for J = 1 / 2 / 4 / 8 / 16; as soon as SIMDs are shared x 1.7, beyond 2048 wavefronts in proportion.
+    double c1 = 1e300;
+    int J1 = 1;
+    bool any_rayleigh = false;
+    for (int t = 0; t < ntargets; ++t) any_rayleigh = any_rayleigh || iwave[t] == 2;
+    for (int l = 0; l < PLAN_LANE_LEVELS; ++l) {
+        const int J = 1 << l;
+        const int mpw = BH_WAVE / J;
+        const long w = (long)ntargets * ((B + mpw - 1) / mpw);
+        double c = PLAN_LANE_PER_MODEL * plan_lane_dur[l] * (any_rayleigh ? 1.0 : 0.85);
+        if (w > PLAN_SLOTS / 2) c *= 1.7 * (w > PLAN_SLOTS ? (double)w / PLAN_SLOTS : 1.0);
+        if (c < c1) {
+            c1 = c;
+            J1 = J;
+        }
+    }
     if (Gforce == 1 || (Gforce <= 0 && c1 < best)) {
         *G = 1;
-        for (int t = 0; t < ntargets; ++t) look[t] = 1;
+        for (int t = 0; t < ntargets; ++t) look[t] = J1;
         return c1;
     }
     *G = Gg;

@@ -78,7 +78,8 @@ const char *bh_engine_last_error(const bh_engine *e);
  * (1..32; 0 = choose from the batch size and layer count, the default).  Results do not depend on it. */
 int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
 /* Tuning knob: trial phase velocities evaluated per round of the root search in the dispersion
- * kernel (1..12; 0 = choose from the batch size, the default).  The search (surfdisp96.f:390-686) asks
+ * kernel (1..16; 0 = choose from the batch size, the default; with one lane per model -- group 1 -- the
+ * largest power of two not above it is used).  The search (surfdisp96.f:390-686) asks
  * for one secular-function value at a time; with look-ahead the kernel also evaluates, on further
  * lanes, the velocities the search will most probably ask for next and hands them over if and only
  * if it does.  Results do not depend on it. */

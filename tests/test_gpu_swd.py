@@ -241,9 +241,9 @@ def test_lane_mappings_return_identical_bits(engine, G):
         engine.set_swd_group(0)
 
 
-@pytest.mark.parametrize("G,J", [(5, 2), (9, 3), (9, 7), (13, 4), (16, 2), (21, 3)])
+@pytest.mark.parametrize("G,J", [(5, 2), (9, 3), (9, 7), (13, 4), (16, 2), (21, 3), (1, 2), (1, 4), (1, 8), (1, 16)])
 def test_lookahead_does_not_change_results(engine, G, J):
-    """Look-ahead (extra lane groups evaluating the trial velocities the root search will probably
+    """Look-ahead (extra lane groups -- with G = 1: extra lanes -- evaluating the trial velocities the root search will probably
     ask for next, bh_engine_set_swd_lookahead) only changes WHEN a secular value is computed, never
     which values the search consumes: velocities (all wave/velocity types, higher modes, failing
     models, ragged layer counts, water layers) and the number of consumed evaluations are unchanged."""
@@ -298,7 +298,7 @@ def test_broken_models_are_failed_in_band(engine, oracle):
     per = np.linspace(2, 40, 12)
     good = np.arange(8, 24)
     try:
-        for G, J in ((0, 0), (1, 1), (9, 1), (9, 2), (9, 7), (16, 4)):
+        for G, J in ((0, 0), (1, 1), (1, 4), (9, 1), (9, 2), (9, 7), (16, 4)):
             engine.set_swd_group(G)
             engine.set_swd_lookahead(J)
             for iwave, igr in REFS.values():
