@@ -60,6 +60,8 @@ struct SwdKernelArgs {
     int32_t *err;     // [B]
     unsigned long long *neval; // optional global counter of secular evaluations (may be null)
     int look;         // trial velocities per round and model = lanes per model (1, 2, 4, 8 or 16), see SearchT::candidate
+    int fair;         // alternate the issue priority of the two wavefronts of a SIMD (scheduling only)
+    double *nev_high; // work array [bh_swd_nev_high_doubles(B, look)]: Neville orders the kernel does not keep in LDS
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
@@ -67,6 +69,7 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
 // one depth -- no masked layers, and the long-running deep models start first.  Results do not depend on it.
 void bh_launch_order(int B, const int32_t *nlay, int32_t *perm, int Lcut, int32_t *split, hipStream_t stream);
 size_t bh_swd_lds_bytes(int Lmax, int K, int mode);
+size_t bh_swd_nev_high_doubles(int B, int look);
 
 // group kernel: G lanes per model, all dispersion targets of a call in one launch
 struct SwdTarget {

@@ -45,7 +45,7 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter, sph, perm, board;
+        misfits, err_t, probe_in, probe_out, counter, sph, perm, board, nevhi;
     unsigned swd_stamp = 0;                // launch counter of the group kernel (marks its progress-board entries)
     // targets
     int nt = 0;
@@ -317,6 +317,13 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         int nlive2 = 0;
         for (int j = 0; j < njobs; ++j) nlive2 += (jobs[j].K != 0);
         const bool fork2 = nlive2 > 1 && e->aux2 != nullptr;
+        // work array of the launches (the Neville orders the kernel does not keep in LDS): one region per target,
+        // the targets run concurrently
+        size_t nev_off[BH_MAX_TARGETS + 1] = {0};
+        for (int t = 0; t < nlive2; ++t) nev_off[t + 1] = nev_off[t] + bh_swd_nev_high_doubles(B, look[t] > 1 ? look[t] : 1);
+        if ((rc = ensure(e, e->nevhi, nev_off[nlive2] * sizeof(double)))) return rc;
+        long lane_waves = 0; // wavefronts of the call
+        for (int t = 0; t < nlive2; ++t) lane_waves += (long)((B + 63) / 64) * (look[t] > 1 ? look[t] : 1);
         ev_begin(e, 0, st);
         if (fork2) {
             HIPCHK(e, hipEventRecord(e->ev_fork2, st));
@@ -335,6 +342,10 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             }
             a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
             a.look = look[nth] > 1 ? look[nth] : 1;
+            // priority time slice (log2 cycles) of wavefronts that share a SIMD, see swd_kernel; wavefronts with a SIMD of
+            // their own are left alone (a low-priority phase costs them 8 %: the CU's front end is shared)
+            a.fair = lane_waves <= 1024 ? -1 : (lane_waves <= 2048 ? 18 : 12);
+            a.nev_high = (double *)e->nevhi.p + nev_off[nth];
             bh_launch_swd(a, J.iwave, (fork2 && (nth & 1)) ? e->aux2 : st);
             ++nth;
         }
@@ -511,7 +522,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi})
         release(*b);
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);

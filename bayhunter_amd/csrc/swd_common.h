@@ -447,7 +447,10 @@ enum : int {
 // (:557-686) keep between two secular-function evaluations, for the fundamental mode.
 // `advance(del)` consumes the value of the secular function at `ceval` and either finishes the
 // model or leaves the next phase velocity to evaluate in `ceval` (with `omega` current).
-template <int XSC> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+// NLO: Neville entries kept in LDS; the orders from NLO on (rarely reached: the order only grows through
+// consecutive interpolation steps) live in a second array (`set_high`, global memory in the lane-per-evaluation
+// kernel, whose residency is bounded by LDS).  NLO = NEV_MAX: everything in LDS, no second array.
+template <int XSC, int NLO = NEV_MAX> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
     int XS = XSC;
     // constants of the reference's driver (compile-time: they cost no registers)
@@ -462,7 +465,38 @@ struct SearchT {
     int mode;            // highest mode wanted (1 = fundamental)
     double *cper, *cbper; // LDS, only for mode > 1: c(k) / cb(k) of surfdisp96.f:85, element k at [k*XS]
     const double *per; // LDS
-    double *xl, *yl;   // LDS Neville tables, element j at [j*XS]
+    double *xl, *yl;   // LDS Neville tables, element j at [j*XS] (j < NLO)
+    // entries j >= NLO at [(j - NLO) * XH] (only if NLO < NEV_MAX); explicitly GLOBAL pointers: a generic pointer
+    // would let the compiler fold the two cases into one flat access
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble *xh = nullptr, *yh = nullptr;
+    size_t XH = 0;
+    __device__ __forceinline__ void set_high(double *xh_, double *yh_, size_t stride)
+    {
+        xh = (gdouble *)xh_;
+        yh = (gdouble *)yh_;
+        XH = stride;
+    }
+    __device__ __forceinline__ double nev_x(int j) const
+    {
+        if (NLO >= NEV_MAX || j < NLO) return xl[j * XS];
+        return xh[(size_t)(j - NLO) * XH];
+    }
+    __device__ __forceinline__ double nev_y(int j) const
+    {
+        if (NLO >= NEV_MAX || j < NLO) return yl[j * XS];
+        return yh[(size_t)(j - NLO) * XH];
+    }
+    __device__ __forceinline__ void nev_set_x(int j, double v)
+    {
+        if (NLO >= NEV_MAX || j < NLO) xl[j * XS] = v;
+        else xh[(size_t)(j - NLO) * XH] = v;
+    }
+    __device__ __forceinline__ void nev_set_y(int j, double v)
+    {
+        if (NLO >= NEV_MAX || j < NLO) yl[j * XS] = v;
+        else yh[(size_t)(j - NLO) * XH] = v;
+    }
     double *vel;       // this model's output row (global)
     bool writer;       // this lane stores results (one lane per model)
     // state
@@ -709,8 +743,8 @@ struct SearchT {
                 bool halve = (s1 > ss2 || s2 > ss1 || nev == 0);
                 if (!halve) {
                     if (nev == 2) {
-                        xl[mnev * XS] = c3;
-                        yl[mnev * XS] = del3;
+                        nev_set_x(mnev, c3);
+                        nev_set_y(mnev, del3);
                     } else {
                         xl[0] = c1;
                         yl[0] = del1;
@@ -718,16 +752,16 @@ struct SearchT {
                         yl[XS] = del2;
                         mnev = 1;
                     }
-                    const double ym = yl[mnev * XS];
+                    const double ym = nev_y(mnev);
                     for (int kk = 1; kk <= mnev; ++kk) {
                         const int j = mnev - kk;
-                        const double yj = yl[j * XS];
+                        const double yj = nev_y(j);
                         const double denom = ym - yj;
                         if (fabs(denom) < 1.0e-10 * fabs(ym)) {
                             halve = true;
                             break;
                         }
-                        xl[j * XS] = (-yj * xl[(j + 1) * XS] + ym * xl[j * XS]) / denom;
+                        nev_set_x(j, (-yj * nev_x(j + 1) + ym * nev_x(j)) / denom);
                     }
                     if (!halve) {
                         c3 = xl[0];

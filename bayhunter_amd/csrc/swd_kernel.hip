@@ -42,6 +42,15 @@
 namespace {
 #include "swd_common.h"
 
+constexpr int LANE_TAB_PAD = (LIBM_TAB_BYTES + 15) & ~15;
+// LDS of one wavefront of kernel 1 (without the shared libm tables)
+__host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
+{
+    const size_t b = (size_t)4 * Lmax * 64 * sizeof(float) + (size_t)2 * 5 /* NEV_LO */ * 64 * sizeof(double) +
+                     (size_t)((K + 1) & ~1) * sizeof(double) + (mode > 1 ? (size_t)2 * K * 64 * sizeof(double) : 0);
+    return (b + 15) & ~(size_t)15;
+}
+
 // =================================================================================================
 // Kernel 1: one lane = one secular evaluation of one model, all layers serial in the lane; everything
 // per-layer stays in registers.
@@ -53,27 +62,35 @@ namespace {
 //           model holds the same search state and steps it with the same values: no broadcast.
 // Same operations, same bits for every J.
 // =================================================================================================
-template <int IFUNC, bool LOOK>
-__global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
+// Residency is bounded by LDS here (a wavefront's model alone is 10 KB at 10 layers), so only the first NEV_LO Neville
+// orders are kept in LDS (the higher ones, reached only through runs of consecutive interpolation steps, in a global
+// work array) and a workgroup is WPB wavefronts sharing ONE copy of the libm tables: WPB = 1 gives 7 wavefronts per
+// CU at 10 layers (10.2 + 5.1 + 0.25 + 5.5 KB; it was 5 with all 11 orders in LDS), WPB = 2 gives 8 -- 5-9 % faster
+// from 100 000 models on, 2.5 % slower below (the launcher picks).
+constexpr int NEV_LO = 5;
+template <int IFUNC, bool LOOK, int LANE_WPB>
+__global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    const int lane = threadIdx.x & (BH_WAVE - 1);
+    const int wave = threadIdx.x / BH_WAVE;
+    const int wid = blockIdx.x * LANE_WPB + wave; // this wavefront among all of the launch
     const int J = LOOK ? A.look : 1;      // power of two, 1..16
     const int r = lane & (J - 1);         // this lane's trial
     const int lbase = lane - r;           // first lane of the model
-    const int sidx = (blockIdx.x * BH_WAVE + lane) / J; // position in the processing order
+    const int sidx = (wid * BH_WAVE + lane) / J; // position in the processing order
     const bool valid = sidx < A.B;
     const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
     const int Lmax = A.Lmax;
     const int K = A.K;
 
+    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * LANE_WPB);
+    unsigned char *smem = smem_all + LANE_TAB_PAD + (size_t)wave * lane_wave_bytes(Lmax, K, A.mode);
     float *mdl = reinterpret_cast<float *>(smem);                       // [4][Lmax][64]
     double *xs = reinterpret_cast<double *>(smem + (size_t)4 * Lmax * BH_WAVE * sizeof(float));
-    double *ys = xs + NEV_MAX * BH_WAVE;                                 // [11][64] each
-    double *per = ys + NEV_MAX * BH_WAVE;                                // [K]
-    unsigned char *after = reinterpret_cast<unsigned char *>(per + ((K + 1) & ~1));
-    const LibmTabs LT = stage_libm_tables(after, lane);
-    double *cpl = reinterpret_cast<double *>(after + LIBM_TAB_BYTES); // [2][K][64], only if mode > 1
+    double *ys = xs + NEV_LO * BH_WAVE;                                  // [NEV_LO][64] each
+    double *per = ys + NEV_LO * BH_WAVE;                                 // [K]
+    double *cpl = per + ((K + 1) & ~1);                                  // [2][K][64], only if mode > 1
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = A.periods[k];
 
@@ -106,11 +123,31 @@ __global__ __launch_bounds__(BH_WAVE) void swd_kernel(SwdKernelArgs A)
     md.rho = mdl + 3 * Lmax * BH_WAVE + lane;
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
 
-    SearchT<BH_WAVE> S;
+    SearchT<BH_WAVE, NEV_LO> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
            cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
+    {
+        const size_t nl = (size_t)gridDim.x * LANE_WPB * BH_WAVE; // lanes of the launch
+        double *hx = A.nev_high + (size_t)wid * BH_WAVE + lane;
+        S.set_high(hx, hx + (size_t)(NEV_MAX - NEV_LO) * nl, nl);
+    }
 
+    // Two wavefronts share a SIMD (one of each target when the targets of a call run side by side); at equal
+    // priority the hardware serves the OLDER one first and a Rayleigh / Love pair takes as long as the two in
+    // sequence (B = 65 536: 25.8 ms ~ 13.4 + 11.5).  Alternating priorities in time slices, the two hardware wave
+    // slots in opposite phase, make them overlap: 20.9 ms with slices of 2^18 cycles for such mixed pairs; pairs of
+    // the same kind (more than 2048 wavefronts in the call) do best with short slices (2^12).  (Scheduling only.)
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const unsigned nrounds = hw_id & 1u; // hardware wave slot parity
+    const bool fair = A.fair != 0;
     while (__ballot(S.active) != 0ull) {
+        if (fair) {
+            // time slices of 2^A.fair cycles, the two hardware wave slots in opposite phase (the clock is shared)
+            const unsigned slice = (unsigned)(__builtin_readcyclecounter() >> A.fair);
+            if (((slice ^ nrounds) & 1u) != 0u) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         if (!S.active) continue; // (the lanes of a model share its state: they leave together)
         const double omg = S.omega;
         const double cev = LOOK ? S.candidate(r) : S.ceval;
@@ -295,11 +332,16 @@ void bh_launch_interp(int B, int K0, const double *x0, const double *y0, int ld0
     hipLaunchKernelGGL(interp_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, B, K0, x0, y0, ld0, K1, x1, y1, ld1);
 }
 
-size_t bh_swd_lds_bytes(int Lmax, int K, int mode)
+size_t bh_swd_lds_bytes(int Lmax, int K, int mode) { return LANE_TAB_PAD + lane_wave_bytes(Lmax, K, mode); } // one wavefront per workgroup
+
+// doubles of the global work array of a launch (Neville orders from NEV_LO on, one column per lane)
+size_t bh_swd_nev_high_doubles(int B, int look)
 {
-    return (size_t)4 * Lmax * BH_WAVE * sizeof(float) + (size_t)2 * NEV_MAX * BH_WAVE * sizeof(double) +
-           (size_t)((K + 1) & ~1) * sizeof(double) + LIBM_TAB_BYTES +
-           (mode > 1 ? (size_t)2 * K * BH_WAVE * sizeof(double) : 0);
+    int J = 1;
+    while (2 * J <= look && 2 * J <= 16) J *= 2;
+    const int mpw = BH_WAVE / J;
+    const size_t waves = (size_t)(((B + mpw - 1) / mpw + 1) / 2) * 2; // (rounded up to a whole workgroup of two)
+    return (size_t)2 * (NEV_MAX - NEV_LO) * waves * BH_WAVE;
 }
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
@@ -308,15 +350,35 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     int J = 1;
     while (2 * J <= a.look && 2 * J <= 16) J *= 2; // largest power of two <= look
     b.look = J;
+    static const int no_fair = std::getenv("BH_SWD_NO_FAIR") ? 1 : 0; // experiment switches
+    static const int slice = std::getenv("BH_SWD_SLICE") ? std::atoi(std::getenv("BH_SWD_SLICE")) : 0;
+    b.fair = (no_fair || a.fair < 0) ? 0 : (slice > 0 ? slice : (a.fair > 0 ? a.fair : 16));
     const int mpw = BH_WAVE / J;
-    const int grid = (a.B + mpw - 1) / mpw;
-    const size_t lds = bh_swd_lds_bytes(a.Lmax, a.K, a.mode);
-    if (iwave == 1) {
-        if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
-        else hipLaunchKernelGGL((swd_kernel<1, false>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+    const int waves = (a.B + mpw - 1) / mpw;
+    // two wavefronts per workgroup once the call has more wavefronts than fit with one (a.fair carries the engine's
+    // count class: 12 = more than 2048 wavefronts in the call)
+    const bool two = a.fair == 12 && LANE_TAB_PAD + 2 * lane_wave_bytes(a.Lmax, a.K, a.mode) <= 64 * 1024;
+    const size_t wb = lane_wave_bytes(a.Lmax, a.K, a.mode);
+    if (two) {
+        const dim3 grid((waves + 1) / 2), block(2 * BH_WAVE);
+        const size_t lds = LANE_TAB_PAD + 2 * wb;
+        if (iwave == 1) {
+            if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true, 2>), grid, block, lds, stream, b);
+            else hipLaunchKernelGGL((swd_kernel<1, false, 2>), grid, block, lds, stream, b);
+        } else {
+            if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true, 2>), grid, block, lds, stream, b);
+            else hipLaunchKernelGGL((swd_kernel<2, false, 2>), grid, block, lds, stream, b);
+        }
     } else {
-        if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
-        else hipLaunchKernelGGL((swd_kernel<2, false>), dim3(grid), dim3(BH_WAVE), lds, stream, b);
+        const dim3 grid(waves), block(BH_WAVE);
+        const size_t lds = LANE_TAB_PAD + wb;
+        if (iwave == 1) {
+            if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true, 1>), grid, block, lds, stream, b);
+            else hipLaunchKernelGGL((swd_kernel<1, false, 1>), grid, block, lds, stream, b);
+        } else {
+            if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true, 1>), grid, block, lds, stream, b);
+            else hipLaunchKernelGGL((swd_kernel<2, false, 1>), grid, block, lds, stream, b);
+        }
     }
 }
 
