@@ -30,6 +30,7 @@
 //     restatements of the host libm the reference links (bh_libm.h): results are bit-identical.
 #include "../../include/bh_engine.h"
 #include "bh_device.h"
+#include <cmath>
 #include <cstdlib>
 
 // glibc-exact exp / sincos (see bh_libm.h): with these the device's secular function is the
@@ -466,7 +467,7 @@ double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, 
     }
     // the lane-per-evaluation kernel: one launch per target, 64 / J models per wavefront, J = trial lanes per model.
     // Measured (B = 4096 ... 32 768, Rayleigh + Love side by side): one wavefront per SIMD or less -> 14.9 / 8.9 / 5.9 /
-    // 4.4 / 3.9 ms for J = 1 / 2 / 4 / 8 / 16; as soon as SIMDs are shared x 1.7, beyond 2048 wavefronts in proportion.
+    // 4.4 / 3.9 ms for J = 1 / 2 / 4 / 8 / 16; the factor for shared SIMDs below.
     double c1 = 1e300;
     int J1 = 1;
     bool any_rayleigh = false;
@@ -476,7 +477,10 @@ double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, 
         const int mpw = BH_WAVE / J;
         const long w = (long)ntargets * ((B + mpw - 1) / mpw);
         double c = PLAN_LANE_PER_MODEL * plan_lane_dur[l] * (any_rayleigh ? 1.0 : 0.85);
-        if (w > PLAN_SLOTS / 2) c *= 1.7 * (w > PLAN_SLOTS ? (double)w / PLAN_SLOTS : 1.0);
+        // wavefronts sharing a SIMD (time-sliced priorities): x 1.25 as soon as some do, x 1.4 when all do, then
+        // (wavefronts / 2048)^0.85
+        if (w > PLAN_SLOTS) c *= 1.4 * std::pow((double)w / PLAN_SLOTS, 0.85);
+        else if (w > PLAN_SLOTS / 2) c *= 1.25 + 0.15 * (double)(w - PLAN_SLOTS / 2) / (PLAN_SLOTS / 2);
         if (c < c1) {
             c1 = c;
             J1 = J;
