@@ -26,8 +26,8 @@ for C in (8, 64, 512):
     b = ChainBatch(targets(), list(range(C)), init, priors)
     t0 = time.perf_counter(); b.run(); dt = time.perf_counter() - t0
     print("host-driven ChainBatch  C=%5d: %7.2f ms/iteration  %9.0f chain-iterations/s" % (C, dt / 300 * 1e3, C * 300 / dt), flush=True)
-for C in (8, 64, 512, 4096, 16384):
-    d = DeviceChains(targets(), C, init, priors, seed=1)
+for C in (8, 64, 512, 4096, 16384, 32768, 65536):
+    d = DeviceChains(targets(), C, dict(init, maxmodels=5), priors, seed=1)   # a snapshot every 20 iterations
     d.engine.synchronize()
     t0 = time.perf_counter(); d.run(); dt = time.perf_counter() - t0
     st = d.state_host()
