@@ -136,3 +136,25 @@ def test_the_bench_path_against_the_oracle(workload):
     assert chk["max_rel_logL"] <= 1e-8 and chk["max_rel_misfit"] <= 1e-8, chk
     assert int((d_err != 0).sum().item()) < B // 20 and bool(torch.isfinite(d_logL).all().item())
     eng.close()
+
+
+def test_large_call_of_the_lane_kernel_two_wavefronts_per_workgroup(engine, oracle):
+    """More than 2048 wavefronts in one call: the lane-per-evaluation kernel runs with two wavefronts per workgroup
+    (shared libm tables) and time-sliced priorities, the Neville orders from five on in its global work array.
+    40 000 models x 4 trial lanes: identical to the planner's own choice for the batch, bit-identical to the oracle on
+    a sample (incl. the models with the longest runs of interpolation steps: low-velocity zones)."""
+    rs = np.random.RandomState(424242)
+    Bb = 40000
+    nlay, h, vp, vs, rho = synth_models(rs, Bb, 10, lvz_frac=0.3, ragged=True)
+    try:
+        for iwave, igr in ((2, 0), (1, 1)):
+            engine.set_swd_group(0); engine.set_swd_lookahead(0)
+            v0, e0 = engine.swd_batch(nlay, h, vp, vs, rho, SWD_PERIODS, iwave, igr)
+            engine.set_swd_group(1); engine.set_swd_lookahead(4)          # 2500 wavefronts
+            v1, e1 = engine.swd_batch(nlay, h, vp, vs, rho, SWD_PERIODS, iwave, igr)
+            assert np.array_equal(v0, v1) and np.array_equal(e0, e1)
+            idx = np.arange(0, Bb, 97)
+            ov, oe, _ = oracle.swd_batch(nlay[idx], h[:, idx].T, vp[:, idx].T, vs[:, idx].T, rho[:, idx].T, SWD_PERIODS, iwave, igr)
+            assert np.array_equal(e1[idx], oe) and np.array_equal(v1[idx], ov)
+    finally:
+        engine.set_swd_group(0); engine.set_swd_lookahead(0)
