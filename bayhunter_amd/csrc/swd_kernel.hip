@@ -44,10 +44,14 @@ namespace {
 #include "swd_common.h"
 
 constexpr int LANE_TAB_PAD = (LIBM_TAB_BYTES + 15) & ~15;
+#ifndef BH_NEV_LO
+#define BH_NEV_LO 5 // (a build with 2 sends every interpolation of order >= 2 through the global array: used once to test that path)
+#endif
+constexpr int NEV_LO = BH_NEV_LO; // Neville orders kept in LDS by kernel 1, see there
 // LDS of one wavefront of kernel 1 (without the shared libm tables)
 __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 {
-    const size_t b = (size_t)4 * Lmax * 64 * sizeof(float) + (size_t)2 * 5 /* NEV_LO */ * 64 * sizeof(double) +
+    const size_t b = (size_t)4 * Lmax * 64 * sizeof(float) + (size_t)2 * NEV_LO * 64 * sizeof(double) +
                      (size_t)((K + 1) & ~1) * sizeof(double) + (mode > 1 ? (size_t)2 * K * 64 * sizeof(double) : 0);
     return (b + 15) & ~(size_t)15;
 }
@@ -68,7 +72,6 @@ __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 // work array) and a workgroup is WPB wavefronts sharing ONE copy of the libm tables: WPB = 1 gives 7 wavefronts per
 // CU at 10 layers (10.2 + 5.1 + 0.25 + 5.5 KB; it was 5 with all 11 orders in LDS), WPB = 2 gives 8 -- 5-9 % faster
 // from 100 000 models on, 2.5 % slower below (the launcher picks).
-constexpr int NEV_LO = 5;
 template <int IFUNC, bool LOOK, int LANE_WPB>
 __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
