@@ -50,3 +50,25 @@ class Model(object):
             n = nlay[b]
             vp[:n, b], vs[:n, b], h[:n, b] = rvp, rvs, rh
         return nlay, h, vp, vs
+
+
+class ModelMatrix(object):
+    """The one helper of the reference's `ModelMatrix` the result store needs (src/Models.py:227-274; the
+    depth-interpolation / histogram helpers of that class serve plotting only and stay with the reference)."""
+
+    @staticmethod
+    def get_weightedvalues(weights, models=None, likes=None, misfits=None, noiseparams=None, vpvs=None):
+        """Rows repeated by `weights` (the number of iterations a model stayed current): returns
+        (wmodels, wlikes, wmisfits, wnoise, wvpvs), None for what was not given -- same outputs as the
+        reference's loops, as one `np.repeat` each."""
+        weights = np.array(weights, dtype=int)
+
+        def rep(a, as_rows):
+            if a is None:
+                return None
+            a = np.asarray(a, dtype=float)
+            if as_rows and a.ndim == 1:      # the reference treats scalars per model as a vector ...
+                return np.repeat(a, weights)
+            return np.repeat(a, weights, axis=0)
+
+        return (rep(models, False), rep(likes, True), rep(misfits, True), rep(noiseparams, False), rep(vpvs, True))

@@ -97,3 +97,21 @@ def test_philox_known_answers():
     p = philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], dtype=np.uint32),
                       (0xa4093822, 0x299f31d0))[0]
     assert [hex(int(v)) for v in p] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_weighted_values_repeat_rows_like_the_reference():
+    """ModelMatrix.get_weightedvalues (src/Models.py:227-274): rows repeated by their weights; expected values
+    written out by hand (the build container also compared with the reference's own loops)."""
+    from bayhunter_amd import ModelMatrix
+    w = [2, 0, 3]
+    models = np.arange(12.).reshape(3, 4)
+    likes = np.array([1., 2., 3.])
+    misfits = np.arange(6.).reshape(3, 2)
+    noise = misfits + 10
+    vpvs = np.array([1.7, 1.8, 1.9])
+    wm, wl, wmis, wn, wv = ModelMatrix.get_weightedvalues(w, models, likes, misfits, noise, vpvs)
+    rows = [0, 0, 2, 2, 2]
+    assert np.array_equal(wm, models[rows]) and np.array_equal(wl, likes[rows]) and np.array_equal(wmis, misfits[rows])
+    assert np.array_equal(wn, noise[rows]) and np.array_equal(wv, vpvs[rows])
+    assert ModelMatrix.get_weightedvalues(w, likes=likes)[0] is None
+    assert np.array_equal(ModelMatrix.get_weightedvalues(w, misfits=[1., 2., 3.])[2], np.array([1., 1., 3., 3., 3.]))
