@@ -76,7 +76,8 @@ class DeviceChains(object):
         self.iterations = self.iter_phase1 + self.iter_phase2
         self.iiter = -self.iter_phase1
         self.thinning = max(1, int(np.ceil(float(self.iter_phase2) / float(ip["maxmodels"]))))
-        self.swap_every, self.dist, self.nswaps, self.sweep, self.seed = int(swap_every), dist, 0, 0, int(seed)
+        self.swap_every, self.dist, self._nswaps_host, self.sweep, self.seed = int(swap_every), dist, 0, 0, int(seed)
+        self._dev_exchange = None
         from .parallel import chain_layout, chain_seeds
         off, tot = chain_layout(self.C, dist)
         if chain_offset is not None:
@@ -160,6 +161,17 @@ class DeviceChains(object):
             setattr(st, k[0], None if v is None else v.data_ptr())
         self.state = st
         torch.cuda.synchronize(dev)
+        # replica exchange on the device (one rank, or RCCL): the ladder of every chain of the job is static
+        if betas is not None and self.swap_every > 0:
+            on_gpu = dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or dist.get_backend() == "nccl"
+            if on_gpu and os.environ.get("BH_PT_HOST_EXCHANGE", "0") != "1":
+                from .parallel import DeviceExchange, gather_chain_axis
+                ladder_all = gather_chain_axis(self.ladder, 0, dist)
+                from .parallel import chain_layout
+                start = chain_layout(Cn, dist)[0]                      # position of this rank's block in gather order
+                mine = slice(start, start + Cn)
+                self._ext_stream = torch.cuda.ExternalStream(int(self.engine.stream), device=dev)
+                self._dev_exchange = DeviceExchange(ladder_all, self.seed, mine, dev)
         self.snap = {"p1": [], "p2": []}
 
     # ---- one lock-step iteration of all chains: three enqueues, no synchronisation -----------------
@@ -175,14 +187,26 @@ class DeviceChains(object):
             self.exchange()
 
     def exchange(self):
-        """One replica-exchange sweep (the only step of a sharded job with a collective)."""
+        """One replica-exchange sweep (the only step of a sharded job with a collective).  On the GPU (one rank, or
+        RCCL) it is enqueued on the engine's stream like an iteration (`parallel.DeviceExchange`); with a CPU
+        process group (gloo) the gathered values go through the host (`parallel.tempering_exchange`)."""
+        if self._dev_exchange is not None:
+            with self.torch.cuda.stream(self._ext_stream):
+                self._dev_exchange.sweep(self.t["like"], self.t["beta"], self.sweep, self.dist)
+            self.sweep += 1
+            return
         from .parallel import tempering_exchange
         self.engine.synchronize()
         newb, nacc = tempering_exchange(self.t["like"], self.t["beta"], self.ladder, self.sweep, self.seed, self.dist)
         self.t["beta"].copy_(newb)
         self.torch.cuda.synchronize(self.dev)
         self.sweep += 1
-        self.nswaps += nacc
+        self._nswaps_host += nacc
+
+    @property
+    def nswaps(self):
+        """accepted swaps so far (all ranks)"""
+        return self._nswaps_host + (int(self._dev_exchange.nacc.item()) if self._dev_exchange is not None else 0)
 
     def _snapshot(self):
         self.engine.synchronize()

@@ -47,6 +47,9 @@ def all_gather_rows(local, dist=None):
     return torch.cat([b[:int(c.item())] for b, c in zip(bufs, counts)], dim=0)
 
 
+_RS = np.random.RandomState(0)   # scratch generator of the swap decisions, re-seeded for every (ladder, sweep)
+
+
 def swap_decisions(logL, beta, sweep, seed):
     """Replica-exchange decisions for one sweep.  `logL[r]`, `beta[r]` for all replicas ordered by
     temperature rung; neighbours (r, r+1) with r of parity `sweep % 2` are proposed; accept with
@@ -57,8 +60,8 @@ def swap_decisions(logL, beta, sweep, seed):
     beta = np.asarray(beta, dtype=float)
     n = logL.size
     perm = np.arange(n)
-    rs = np.random.RandomState((int(seed) * 1000003 + int(sweep)) % (2 ** 32))
-    u = rs.uniform(size=n)
+    _RS.seed((int(seed) * 1000003 + int(sweep)) % (2 ** 32))      # (re-seeding is 30x cheaper than a new RandomState)
+    u = _RS.uniform(size=n)
     for r in range(sweep % 2, n - 1, 2):
         log_alpha = (beta[r] - beta[r + 1]) * (logL[r + 1] - logL[r])
         if np.log(u[r]) < log_alpha:
@@ -123,6 +126,67 @@ def tempering_exchange(local_logL, local_beta, local_ladder, sweep, seed, dist=N
     else:
         mine = slice(0, local.shape[0])
     return torch.as_tensor(newb[mine], dtype=lb.dtype, device=lb.device), nacc
+
+
+class DeviceExchange(object):
+    """`tempering_exchange` without leaving the GPU: the decisions of `ladder_swap_betas` as torch operations on the
+    stream the chains run on, so that a swap sweep is enqueued like an iteration -- no host synchronisation, no copy
+    of (logL, beta) to the host and back.  What the decisions need besides the gathered (logL, beta) is static or
+    host-computable: the ladder of every chain of the job, and the uniforms of a sweep (they depend on (seed, ladder,
+    sweep) only; their logarithms are uploaded from pinned memory).  Sharded jobs all-gather (logL, beta) with RCCL
+    (device tensors).  Same decisions as the NumPy form, bit for bit (tests/test_gpu_sharded.py)."""
+
+    def __init__(self, ladder_all, seed, mine, device):
+        import torch
+        self.torch, self.dev, self.seed, self.mine = torch, device, int(seed), mine
+        lad = np.asarray(ladder_all, dtype=np.int64)
+        self.N = lad.size
+        self.lids, self.counts = np.unique(lad, return_counts=True)          # sorted ladder ids, chains per ladder
+        # layout after sorting by (ladder, -beta, index): position p = rung r(p) of ladder lid(p), static
+        starts = np.concatenate(([0], np.cumsum(self.counts)[:-1]))
+        rung = np.arange(self.N) - np.repeat(starts, self.counts)
+        last = rung == np.repeat(self.counts, self.counts) - 1
+        self.left = [torch.as_tensor(((rung % 2 == par) & ~last)[:-1] if self.N > 1 else np.zeros(0, bool), device=device)
+                     for par in (0, 1)]
+        self.ladder = torch.as_tensor(lad, device=device)
+        self.nacc = torch.zeros((), dtype=torch.int64, device=device)
+
+    def _log_uniforms(self, sweep):
+        """log(u) in the sorted layout: ladder by ladder the numbers `swap_decisions` draws."""
+        out = np.empty(self.N)
+        p = 0
+        for lid, n in zip(self.lids, self.counts):
+            s2 = (self.seed * 7919 + int(lid)) % (2 ** 31)
+            _RS.seed((s2 * 1000003 + int(sweep)) % (2 ** 32))
+            out[p:p + n] = _RS.uniform(size=n)
+            p += n
+        with np.errstate(divide="ignore"):
+            return np.log(out)
+
+    def sweep(self, like, beta, sweep, dist=None):
+        """Enqueue one sweep on the CURRENT torch stream: `like`, `beta` = this rank's chains (device tensors);
+        `beta` is updated in place."""
+        torch = self.torch
+        # a fresh pinned buffer per sweep: the host runs ahead of the stream, and torch's host allocator reuses a
+        # pinned block only after the copy that reads it has completed
+        logu = torch.from_numpy(self._log_uniforms(sweep)).pin_memory().to(self.dev, non_blocking=True)
+        local = torch.stack((like.to(torch.float64), beta.to(torch.float64)), dim=1)
+        allv = all_gather_rows(local, dist)
+        L, Bt = allv[:, 0], allv[:, 1]
+        o1 = torch.sort(-Bt, stable=True).indices                      # beta descending, ties by chain index
+        order = o1[torch.sort(self.ladder[o1], stable=True).indices]   # grouped by ladder, coldest first
+        bs, ls = Bt[order], L[order]
+        if self.N > 1:
+            acc = self.left[int(sweep) % 2] & (logu[:-1] < (bs[:-1] - bs[1:]) * (ls[1:] - ls[:-1]))
+            nb = bs.clone()
+            nb[:-1] = torch.where(acc, bs[1:], nb[:-1])
+            nb[1:] = torch.where(acc, bs[:-1], nb[1:])
+            self.nacc += acc.sum()
+        else:
+            nb = bs
+        out = torch.empty_like(Bt)
+        out[order] = nb
+        beta.copy_(out[self.mine].to(beta.dtype))
 
 
 # ---- sharded chains: global numbering, result gather, cold-chain assembly -------------------------

@@ -176,6 +176,43 @@ def test_parallel_tempering_on_device_chains():
     assert np.mean(rate[mean_beta < 0.2]) > np.mean(rate[mean_beta > 0.6])
 
 
+def test_exchange_on_the_device_equals_the_host_exchange(monkeypatch):
+    """The swap sweep as torch operations on the engine's stream (parallel.DeviceExchange: no host synchronisation)
+    takes the decisions of the NumPy form (parallel.ladder_swap_betas) bit for bit: same betas after every sweep,
+    same chain states at the end, same number of accepted swaps -- with unequal ladders and tied temperatures."""
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=300, iter_main=100, maxmodels=20)
+    rs = np.random.RandomState(5)
+    sizes = [1, 2, 3, 5, 8, 4, 7, 6, 8, 8]
+    ladder = rs.permutation(np.repeat(np.arange(len(sizes)), sizes))           # ladders scattered over the chains
+    C = ladder.size
+    betas = np.ones(C)
+    for lid, n in enumerate(sizes):
+        b = 1.0 / np.geomspace(1.0, 20.0, n)
+        if n >= 5:
+            b[2] = b[1]                                                           # a tie
+        betas[ladder == lid] = b
+
+    def run(host):
+        monkeypatch.setenv("BH_PT_HOST_EXCHANGE", "1" if host else "0")
+        dc = DeviceChains(make_targets(g), C, init, su["priors"], seed=77, betas=betas, ladder=ladder, swap_every=5)
+        assert (dc._dev_exchange is None) == host
+        trace = []
+        while dc.iiter < dc.iter_phase2:
+            dc.iterate()
+            if dc.iiter % 5 == 0 and dc.iiter < 0:    # (burn-in: look after every sweep; main phase: the host runs ahead)
+                trace.append(dc.t["beta"].cpu().numpy().copy())
+        return dc, np.array(trace), dc.state_host()
+
+    d1, t1, s1 = run(True)
+    d2, t2, s2 = run(False)
+    assert t1.shape == t2.shape and np.array_equal(t1, t2)
+    assert d1.sweep == d2.sweep == 80 and d1.nswaps == d2.nswaps and d1.nswaps > 20
+    for k in ("n", "vs", "z", "like", "noise", "vpvs", "beta"):
+        assert np.array_equal(s1[k], s2[k]), k
+
+
 def test_posterior_statistics_match_reference_order_chains():
     """Statistical parity (the accept decisions are chaotic, parity of the sampler with its own
     random stream can only be statistical): the same problem sampled by 64 reference-order chains
