@@ -169,7 +169,9 @@ class DeviceExchange(object):
         torch = self.torch
         # a fresh pinned buffer per sweep: the host runs ahead of the stream, and torch's host allocator reuses a
         # pinned block only after the copy that reads it has completed
-        logu = torch.from_numpy(self._log_uniforms(sweep)).pin_memory().to(self.dev, non_blocking=True)
+        logu = torch.from_numpy(self._log_uniforms(sweep))
+        if torch.device(self.dev).type == "cuda":
+            logu = logu.pin_memory().to(self.dev, non_blocking=True)
         local = torch.stack((like.to(torch.float64), beta.to(torch.float64)), dim=1)
         allv = all_gather_rows(local, dist)
         L, Bt = allv[:, 0], allv[:, 1]

@@ -244,3 +244,35 @@ def test_sharded_chains_write_what_the_single_rank_job_writes(tmp_path, rungs):
     else:
         ids = [int(np.load(os.path.join(two, "c%03d_p2models.npy" % c))[0, 1]) for c in range(12)]
         assert ids == list(range(12))                                   # 12 distinct chains, numbered globally
+
+
+def test_device_exchange_takes_the_decisions_of_the_numpy_form():
+    """parallel.DeviceExchange (the swap sweep as torch operations; on a GPU it runs on the engine's stream) against
+    parallel.ladder_swap_betas, here on CPU tensors: unequal ladders scattered over the chains, tied temperatures,
+    many sweeps of both parities, -1e15 sentinels among the likelihoods."""
+    import torch
+    from bayhunter_amd import parallel as P
+    rs = np.random.RandomState(9)
+    sizes = [1, 2, 3, 8, 5, 8, 7, 4]
+    ladder = rs.permutation(np.repeat(np.arange(len(sizes)) * 3 + 1, sizes))       # ids need not be 0..n-1
+    N = ladder.size
+    beta = np.ones(N)
+    for lid, n in zip(np.arange(len(sizes)) * 3 + 1, sizes):
+        b = 1.0 / np.geomspace(1.0, 25.0, n)
+        if n >= 5:
+            b[3] = b[2]
+        beta[ladder == lid] = rs.permutation(b)
+    ex = P.DeviceExchange(ladder, seed=4711, mine=slice(0, N), device="cpu")
+    bt = torch.from_numpy(beta.copy())
+    bn = beta.copy()
+    nacc = 0
+    for sweep in range(60):
+        logL = rs.normal(300.0, 8.0, N)
+        logL[rs.rand(N) < 0.05] = -1e15
+        bn, k = P.ladder_swap_betas(logL, bn, ladder, sweep, 4711)
+        nacc += k
+        ex.sweep(torch.from_numpy(logL), bt, sweep)
+        assert np.array_equal(bt.numpy(), bn), sweep
+    assert int(ex.nacc) == nacc and nacc > 50
+    for lid in np.unique(ladder):                                                    # temperatures stay in their ladder
+        assert np.array_equal(np.sort(bn[ladder == lid]), np.sort(beta[ladder == lid]))
