@@ -107,7 +107,13 @@ def _worker(rank, world, port, out):
         L, Bt, lad = _pt_job()
         my = slice(0, 6) if rank == 0 else slice(6, 12)
         newb, nacc = parallel.tempering_exchange(torch.tensor(L[my]), torch.tensor(Bt[my]), lad[my], sweep=0, seed=9, dist=dist)
-        out.put((rank, float(t.item()), rows.squeeze(1).tolist(), perm.tolist(), (mine.start, mine.stop), newb.tolist(), nacc))
+        # the same exchange as device work (here CPU tensors over gloo; RCCL when the tensors are on GPUs), three sweeps
+        ex = parallel.DeviceExchange(lad, seed=9, mine=my, device="cpu")
+        bt = torch.tensor(Bt[my])
+        for sw in range(3):
+            ex.sweep(torch.tensor(L[my]), bt, sw, dist)
+        out.put((rank, float(t.item()), rows.squeeze(1).tolist(), perm.tolist(), (mine.start, mine.stop), newb.tolist(), nacc,
+                 bt.tolist(), int(ex.nacc)))
     finally:
         dist.destroy_process_group()
 
@@ -124,9 +130,14 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, t0, rows0, perm0, mine0, nb0, na0), (r1, t1, rows1, perm1, mine1, nb1, na1) = res
+    (r0, t0, rows0, perm0, mine0, nb0, na0, db0, dn0), (r1, t1, rows1, perm1, mine1, nb1, na1, db1, dn1) = res
     L, Bt, lad = _pt_job()
     expect_b, expect_n = parallel.ladder_swap_betas(L, Bt, lad, 0, 9)
+    b3, n3 = Bt, 0
+    for sw in range(3):
+        b3, k = parallel.ladder_swap_betas(L, b3, lad, sw, 9)
+        n3 += k
+    assert db0 == b3[:6].tolist() and db1 == b3[6:].tolist() and dn0 == dn1 == n3
     assert na0 == na1 == expect_n and expect_n > 0
     assert nb0 == expect_b[:6].tolist() and nb1 == expect_b[6:].tolist()
     assert t0 == t1 == 2.0
