@@ -170,7 +170,7 @@ __device__ __forceinline__ cm2 operator+(const cm2 &x, const cm2 &y)
 
 // ---- per-model coefficient record (doubles) ---------------------------------------------------
 //  [0] nlay  [1] p (s/km)  [2] do_decomp  [3] bad (NaN propagation of t0 / decomp)
-//  (the last two doubles of the record: the model's Nyquist bin, re / im)
+//  (the last two doubles of the record are spare)
 //  [4..7] m11 m12 m21 m22 (rotation)   [8..15] 2*h matrix (4 complex)
 //  [16..23] free-surface ru (4 complex)
 //  [24 + 8*l ...]           layer l = 0..Lmax-1 : 1/vp^2, 1/vs^2, h (flattened), 1/(pi qp), 1/(2 qp), 1/(pi qs), 1/(2 qs), -
@@ -425,12 +425,127 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
     }
     rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
     rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
-    // the Nyquist bin of this model (this lane wrote the record it reads)
-    const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
-    const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
-    const cd ny = rf_one_frequency(rec, Lmax, A.nsamp / 2, dw, qg, A.gauss, A.tshift, A.waveno);
-    rec[rec_doubles(Lmax) - 2] = ny.re;
-    rec[rec_doubles(Lmax) - 1] = ny.im;
+}
+
+// The same record with LP lanes per model, lane l = layer l (LP = 16 or 32 >= Lmax): the serial kernel above is a
+// chain of ~10 interface computations per lane with 64 wavefronts on the whole chip (0.10 ms at B = 4096, a sixth of
+// the receiver function's time); here every layer's flattening and the interface above it are one lane's work.
+// Same operations per layer: the depth of a layer's top is the reference's running sum, formed in its order; the
+// direct-wave delay is summed by the model's first lane in layer order.  (The Nyquist bin is the synthesis kernel's.)
+template <int LP>
+__global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ibr = t / LP, l = t % LP, lane = threadIdx.x & 63, lbase = lane - l;
+    const bool vm = ibr < A.B;
+    const int ib = vm ? ibr : 0;
+    const int Lmax = A.Lmax;
+    double *rec = A.coef + (size_t)ib * rec_doubles(Lmax);
+    const int nlay = A.nlay[ib];
+    const ptrdiff_t base = (ptrdiff_t)ib * A.sb;
+    const double R = 6371.0;
+    const double p = A.p_s_per_deg * 0.00899; // wrap.cpp:55
+    const double p2 = p * p;
+    const bool on = vm && l < nlay;
+    const int lc = (l < nlay) ? l : (nlay > 0 ? nlay - 1 : 0);
+
+    // this layer, flattened (model.cpp:221-252); ztop = the running sum of the thicknesses above, in the loop's order
+    double ztop = 0.0;
+    for (int i = 0; i < lc; ++i) ztop = ztop + A.h[base + (ptrdiff_t)i * A.sl];
+    const ptrdiff_t o = base + (ptrdiff_t)lc * A.sl;
+    const double znext = ztop + A.h[o];
+    const bool half = (lc == nlay - 1);
+    double hh = half ? -1.0 : (znext - ztop);
+    double vp = A.vp[o], vs = A.vs[o], rh = A.rho[o];
+    const double qp = A.qp ? A.qp[o] : 500.0, qs = A.qs ? A.qs[o] : 225.0;
+    {
+        const double zb = ztop + hh;
+        double r = R - ztop;
+        double q = R / r;
+        const double zf = R * log(q);
+        vp *= q;
+        vs *= q;
+        rh /= q;
+        const bool lower_halfspace = !(hh > 0.0) && !(vp < 1.0 && rh < 0.1);
+        if (!lower_halfspace) {
+            r = R - zb;
+            q = R / r;
+            hh = R * log(q) - zf;
+        }
+    }
+    if (on) {
+        double *lay = rec + REC_HEAD + 8 * l;
+        lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
+        lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
+    }
+    // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
+    const double vv = (A.waveno == 0) ? vp : vs;
+    const double term = hh * sqrt(1. / (vv * vv) - p2);
+    // the layer above, from the neighbouring lane
+    const double pvp = __shfl(vp, lane - 1), pvs = __shfl(vs, lane - 1), prh = __shfl(rh, lane - 1);
+    if (on && l > 0) {
+        cm2 rd, td, ru, tu;
+        interface_coeffs(p, pvp, pvs, prh, vp, vs, rh, rd, td, ru, tu);
+        double *ic = rec + REC_HEAD + 8 * Lmax + 32 * (l - 1);
+        store_cm2(ic, rd);
+        store_cm2(ic + 8, td);
+        store_cm2(ic + 16, ru);
+        store_cm2(ic + 24, tu);
+    }
+    double t0 = 0.0;
+    for (int i = 0; i < LP; ++i) {
+        const double ti = __shfl(term, lbase + i);
+        if (i < nlay) t0 += ti;
+    }
+    if (vm && l == 0) {
+        // free surface, greens.cpp:87-112 (plain sqrt) and displacement matrix :307-322
+        const cd a = csqrt_d(C(1. / (vp * vp) - p2));
+        const cd b = csqrt_d(C(1. / (vs * vs) - p2));
+        const double t1 = 2. * vs * vs;
+        const double t2 = t1 * p2 - 1.;
+        const cd d1 = C(t2 * t2);
+        const cd d2 = (t1 * t1 * p2) * a * b;
+        const cd d = d1 + d2;
+        const cd t3 = C(2. * t1 * p * t2) / d;
+        cm2 ru;
+        ru.c11 = (d2 - d1) / d;
+        ru.c12 = -(b * t3);
+        ru.c21 = a * t3;
+        ru.c22 = ru.c11;
+        store_cm2(rec + 16, ru);
+        const double vs2 = vs * vs, x = 1. - 2. * vs2 * p2;
+        const cd a1 = conj(a), b1 = conj(b);
+        const cd qq = crecip(C(x * x) + (4. * vs2 * vs2 * p2) * a1 * b1);
+        cm2 hm;
+        hm.c11 = qq * a1 * b1 * (2. * vs2 * p);
+        hm.c12 = qq * b1 * (1. - 2. * vs2 * p2);
+        hm.c21 = qq * a1 * (1. - 2. * vs2 * p2);
+        hm.c22 = -(qq * a1 * b1 * (2. * vs2 * p));
+        hm.c11 = 2.0 * hm.c11; hm.c12 = 2.0 * hm.c12; hm.c21 = 2.0 * hm.c21; hm.c22 = 2.0 * hm.c22;
+        store_cm2(rec + 8, hm);
+        // top-layer quantities before flattening (q = 1 for the top layer anyway): rfmini_modrf.py:125-130, wrap.cpp:13,73-74
+        const double vp0 = A.vp[base], vs0 = A.vs[base];
+        const double kap = vp0 / vs0;
+        const double poisson = (2 - kap * kap) / (2 - 2 * (kap * kap));
+        const double nsv = (A.nsv > 0.0) ? A.nsv : vs0;
+        const double vptop = nsv * sqrt((1. - poisson) / (.5 - poisson));
+        const double vstop = nsv;
+        double bad = 0.0;
+        if (t0 != t0) bad = 1.0;
+        if (nlay < 2) bad = 1.0; // the reference reads an uninitialised matrix here
+        // rotation Z/R -> P/SV with REAL vertical slownesses (greens.cpp:324-341)
+        double do_decomp = 0.0, m11 = 0, m12 = 0, m21 = 0, m22 = 0;
+        if (vstop > 0.01 && fabs(p) > 0.0001) {
+            do_decomp = 1.0;
+            const double aa = sqrt(1. / (vptop * vptop) - p * p), bb = sqrt(1. / (vstop * vstop) - p * p);
+            m11 = -(2 * vstop * vstop * p * p - 1.) / (vptop * aa);
+            m12 = 2. * p * vstop * vstop / vptop;
+            m21 = -2. * p * vstop;
+            m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
+        }
+        rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
+        rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
+    }
 }
 
 // Spectrum of one model into LDS (bit-reversed, Hermitian-extended), inverse FFT of length N = nsamp in LDS:
@@ -460,8 +575,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         x[(int)(__brev((unsigned)j) >> shift)] = make_double2(s.re, s.im);
         if (j > 0) x[(int)(__brev((unsigned)(N - j)) >> shift)] = make_double2(s.re, -s.im); // cx[N-j] = conj(cx[j])
     }
-    if (tid == 0)
-        x[(int)(__brev((unsigned)half) >> shift)] = (half < jcut) ? make_double2(rec[recsz - 2], rec[recsz - 1]) : make_double2(0.0, 0.0);
+    if (tid == 0) { // the Nyquist bin: one more frequency for one thread, and only when the filter keeps it
+        const cd s = (half < jcut) ? rf_one_frequency(rec, A.Lmax, half, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
+        x[(int)(__brev((unsigned)half) >> shift)] = make_double2(s.re, s.im);
+    }
     __syncthreads();
     for (int s = 0; s < logn; ++s) {
         const int l = 1 << s;          // half-size of the butterflies of this stage
@@ -493,7 +610,12 @@ void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     const int half = a.nsamp / 2;
     int logn = 0;
     while ((1 << logn) < a.nsamp) ++logn;
-    hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
+    if (a.Lmax <= 16)
+        hipLaunchKernelGGL((rf_coef_layers_kernel<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    else if (a.Lmax <= 32)
+        hipLaunchKernelGGL((rf_coef_layers_kernel<32>), dim3((a.B + 7) / 8), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
     const size_t lds = (size_t)a.nsamp * 16 + (size_t)(half / 2 > 0 ? half / 2 : 1) * 16; // spectrum + quarter twiddle table
     // Spectral cut-off.  Every bin carries the Gauss low-pass exp(-w^2 / (4 a^2)) (greens.cpp:343-398); where that
     // factor is below 1e-30 the bin is below 1e-30 of the pass band (|R/Z| is of order one) and cannot change a
