@@ -10,6 +10,18 @@
 //                          keep, move counters, proposal-width adaptation every 1000 iterations
 //                          (:425-450, :584-587).
 // The forward models + likelihood between the two are bh_evaluate_batch on device pointers.
+//
+// Speculative windows (bh_chain_propose_window / bh_chain_accept_window): a chain's iterations are sequential, but
+// every draw is a pure function of (chain, iteration, purpose), so the proposals of the NEXT `depth` iterations can be
+// written down for both outcomes of every accept/reject decision before any of them is evaluated: a binary tree with
+// 2^depth - 1 nodes per chain (heap order: node 0 = this iteration's proposal, node 2j+1 / 2j+2 = the next
+// iteration's proposal after node j was rejected / accepted).  ONE bh_evaluate_batch over all nodes of all chains
+// then costs what a batch of that size costs (for a few chains: the same ~1.5 ms latency floor as one proposal per
+// chain), and the accept kernel walks the realised path through the tree: `depth` iterations per evaluation launch,
+// bit for bit the sequential walk (same arithmetic on the same operands in the same order; the evaluation of a
+// model does not depend on the batch it is in).  Windows end at the iterations where something outside the
+// chain's own state changes: the proposal-width adaptation (every 1000th iteration must be the LAST of its window)
+// and, on the host side, snapshots and temperature exchanges.
 // Random numbers: Philox4x32-10, counter = (global chain index, iteration, purpose), key = seed -- every draw is
 // a pure function of its coordinates, so results do not depend on scheduling.  (The reference uses
 // one Mersenne-Twister stream per chain; trajectories therefore agree statistically, not draw by
@@ -52,13 +64,15 @@ struct Draws {
     double u_move, u_index, u_z, u_accept, u_noise, normal;
 };
 
-__device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, int c, int C, int iiter)
+// k = position of the iteration inside a speculative window (injected draws: [depth][6][C])
+__device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, int c, int C, int iiter, int k)
 {
     Draws d;
-    if (S.inject != nullptr) { // test mode: [6][C]
-        d.u_move = S.inject[0 * (size_t)C + c]; d.u_index = S.inject[1 * (size_t)C + c];
-        d.u_z = S.inject[2 * (size_t)C + c]; d.u_accept = S.inject[3 * (size_t)C + c];
-        d.u_noise = S.inject[4 * (size_t)C + c]; d.normal = S.inject[5 * (size_t)C + c];
+    if (S.inject != nullptr) { // test mode
+        const double *in = S.inject + (size_t)k * 6 * C;
+        d.u_move = in[0 * (size_t)C + c]; d.u_index = in[1 * (size_t)C + c];
+        d.u_z = in[2 * (size_t)C + c]; d.u_accept = in[3 * (size_t)C + c];
+        d.u_noise = in[4 * (size_t)C + c]; d.normal = in[5 * (size_t)C + c];
         return d;
     }
     Philox ph;
@@ -84,12 +98,56 @@ __device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, 
 enum { MV_VS = 0, MV_Z = 1, MV_BIRTH = 2, MV_DEATH = 3, MV_NOISE = 4, MV_VPVS = 5 };
 __device__ __forceinline__ int par_index(int mv) { return mv <= 1 ? mv : (mv <= 3 ? 2 : mv - 1); } // PAR_MAP
 
-__global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int C, int iiter)
+// A chain's model parameters in registers / scratch
+struct Params {
+    int n;
+    double vs[BH_CHAIN_MAXLAYERS + 1], z[BH_CHAIN_MAXLAYERS + 1];
+    double vpvs;
+    double noise[2 * BH_MAX_TARGETS];
+};
+
+// The state a tree node's proposal starts from: the proposal of the nearest ancestor that is entered through
+// its "accepted" edge (and was valid), else the chain's current state.  node < 0: the chain's current state.
+__device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, int c, int from_node, Params &P)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if (from_node < 0) {
+        P.n = S.n[c];
+        for (int i = 0; i < P.n; ++i) {
+            P.vs[i] = S.vs[(size_t)i * C + c];
+            P.z[i] = S.z[(size_t)i * C + c];
+        }
+        P.vpvs = S.vpvs[c];
+        for (int i = 0; i < 2 * nt; ++i) P.noise[i] = S.noise[(size_t)i * C + c];
+    } else {
+        const size_t col = (size_t)from_node * C + c;
+        P.n = S.pn[col];
+        for (int i = 0; i < P.n; ++i) {
+            P.vs[i] = S.pvs[(size_t)i * ldp + col];
+            P.z[i] = S.pz[(size_t)i * ldp + col];
+        }
+        P.vpvs = S.pvpvs[col];
+        for (int i = 0; i < 2 * nt; ++i) P.noise[i] = S.pnoise[col * 2 * nt + i];
+    }
+}
+
+__device__ void layer_thicknesses(const Params &P, double *h)
+{
+    double prev = 0.0;
+    for (int i = 0; i + 1 < P.n; ++i) {
+        const double zd = (P.z[i] + P.z[i + 1]) / 2.;
+        h[i] = zd - prev;
+        prev = zd;
+    }
+    if (P.n >= 1) h[P.n - 1] = 0.0;
+}
+
+// One proposal (SingleChain.py:246-420, :511-556; Models.py:26-52): from the state of `from_node`, with the draws of
+// iteration `iiter`, into column node*C + c of the proposal arrays (leading dimension ldp).
+__device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S, int C, size_t ldp, int c, int iiter, int k,
+                             int from_node, int node)
+{
     const int ML = cfg.maxlayers, nt = cfg.nt;
-    const Draws d = get_draws(cfg, S, c, C, iiter);
+    const Draws d = get_draws(cfg, S, c, C, iiter, k);
     // ---- which modification (SingleChain.py:512-517, :596-599) ---------------------------------
     int nnoise = 0;
     for (int i = 0; i < 2 * nt; ++i) nnoise += (cfg.noise_lo[i] != cfg.noise_hi[i]);
@@ -109,15 +167,11 @@ __global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int 
     const int mv = moves[mi];
 
     // ---- proposal -----------------------------------------------------------------------------------
-    double vs[BH_CHAIN_MAXLAYERS + 1], z[BH_CHAIN_MAXLAYERS + 1];
-    int n = S.n[c];
-    for (int i = 0; i < n; ++i) {
-        vs[i] = S.vs[(size_t)i * C + c];
-        z[i] = S.z[(size_t)i * C + c];
-    }
-    double vpvs = S.vpvs[c];
-    double noise[2 * BH_MAX_TARGETS];
-    for (int i = 0; i < 2 * nt; ++i) noise[i] = S.noise[(size_t)i * C + c];
+    Params P;
+    load_base(S, C, ldp, nt, c, from_node, P);
+    double *vs = P.vs, *z = P.z, *noise = P.noise;
+    int n = P.n;
+    double vpvs = P.vpvs;
     double dvs2 = 0.0;
     bool valid = true;
     if (mv == MV_VS) {
@@ -193,15 +247,11 @@ __global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int 
         z[j + 1] = zi;
         vs[j + 1] = vi;
     }
+    P.n = n;
+    P.vpvs = vpvs;
     // ---- nuclei -> layers (Models.py:39-52), validity with the CURRENT vp/vs (:330-392) ------------
     double h[BH_CHAIN_MAXLAYERS + 1];
-    double prev = 0.0;
-    for (int i = 0; i + 1 < n; ++i) {
-        const double zd = (z[i] + z[i + 1]) / 2.;
-        h[i] = zd - prev;
-        prev = zd;
-    }
-    if (n >= 1) h[n - 1] = 0.0;
+    layer_thicknesses(P, h);
     if (valid && (mv <= MV_DEATH)) {
         const int layermodel = n - 1;
         if (!(layermodel >= cfg.layermin && layermodel <= cfg.layermax)) valid = false;
@@ -217,99 +267,147 @@ __global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int 
             }
         }
     }
-    // ---- write the proposal and the layered model (invalid: re-evaluate the current model) ---------
-    S.move[c] = mv;
-    S.valid[c] = valid ? 1 : 0;
-    S.dvs2[c] = dvs2;
-    if (!valid) { // keep the evaluate batch well-formed: it sees the current model, result ignored
-        n = S.n[c];
-        for (int i = 0; i < n; ++i) {
-            vs[i] = S.vs[(size_t)i * C + c];
-            z[i] = S.z[(size_t)i * C + c];
-        }
-        vpvs = S.vpvs[c];
-        for (int i = 0; i < 2 * nt; ++i) noise[i] = S.noise[(size_t)i * C + c];
-        prev = 0.0;
-        for (int i = 0; i + 1 < n; ++i) {
-            const double zd = (z[i] + z[i + 1]) / 2.;
-            h[i] = zd - prev;
-            prev = zd;
-        }
-        h[n - 1] = 0.0;
+    // ---- write the proposal and the layered model (invalid: re-evaluate the model it started from) ---------
+    const size_t col = (size_t)node * C + c;
+    S.move[col] = mv;
+    S.valid[col] = valid ? 1 : 0;
+    S.dvs2[col] = dvs2;
+    if (!valid) { // keep the evaluate batch well-formed: it sees the unchanged model, result ignored
+        load_base(S, C, ldp, nt, c, from_node, P);
+        layer_thicknesses(P, h);
+        n = P.n;
+        vpvs = P.vpvs;
     }
-    S.pn[c] = n;
-    S.pvpvs[c] = vpvs;
+    S.pn[col] = n;
+    S.pvpvs[col] = vpvs;
     for (int i = 0; i < n; ++i) {
-        S.pvs[(size_t)i * C + c] = vs[i];
-        S.pz[(size_t)i * C + c] = z[i];
+        S.pvs[(size_t)i * ldp + col] = vs[i];
+        S.pz[(size_t)i * ldp + col] = z[i];
     }
-    for (int i = 0; i < 2 * nt; ++i) S.pnoise[(size_t)c * 2 * nt + i] = noise[i]; // [C][2nt]: evaluate's layout
+    for (int i = 0; i < 2 * nt; ++i) S.pnoise[col * 2 * nt + i] = noise[i]; // [columns][2nt]: evaluate's layout
     // vp: crustal vp/vs down to the first layer with vs >= mantle[0], mantle[1] below (Models.py:26-37)
     bool deep = false;
     for (int i = 0; i < n; ++i) {
         if (cfg.mantle_vs > 0.0 && vs[i] >= cfg.mantle_vs) deep = true;
-        S.lay_h[(size_t)i * C + c] = h[i];
-        S.lay_vs[(size_t)i * C + c] = vs[i];
-        S.lay_vp[(size_t)i * C + c] = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
+        S.lay_h[(size_t)i * ldp + col] = h[i];
+        S.lay_vs[(size_t)i * ldp + col] = vs[i];
+        S.lay_vp[(size_t)i * ldp + col] = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
     }
-    S.lay_n[c] = n;
+    S.lay_n[col] = n;
 }
 
-__global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C, int iiter, const double *logL,
-                                    const double *misfits)
+// lane = chain, one proposal per chain (depth 1; ldp = C)
+__global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int C, int iiter)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    propose_node(cfg, S, C, (size_t)C, c, iiter, 0, -1, 0);
+}
+
+// Speculative window: T = 2^(depth-1) lanes per chain (64 / T chains per single-wavefront workgroup); level k of the
+// tree is proposed by the first 2^k lanes of a chain, the levels one after the other (a node reads the proposal of
+// an ancestor written in an earlier level: __syncthreads orders them).
+__global__ void __launch_bounds__(64) chain_propose_window_kernel(bh_chain_config cfg, bh_chain_state S, int C, size_t ldp,
+                                                                   int iiter, int depth)
+{
+    const int T = 1 << (depth - 1);
+    const int per_wg = 64 / T;
+    const int c = blockIdx.x * per_wg + (int)threadIdx.x / T;
+    const int p = (int)threadIdx.x % T;
+    for (int k = 0; k < depth; ++k) {
+        if (c < C && p < (1 << k)) {
+            const int node = (1 << k) - 1 + p;
+            // nearest ancestor entered through its "accepted" edge whose proposal was valid
+            int from = -1;
+            for (int j = node; j > 0; j = (j - 1) >> 1) {
+                const int parent = (j - 1) >> 1;
+                if ((j & 1) == 0 && S.valid[(size_t)parent * C + c]) {
+                    from = parent;
+                    break;
+                }
+            }
+            propose_node(cfg, S, C, ldp, c, iiter + k, k, from, node);
+        }
+        __syncthreads();
+    }
+}
+
+// lane = chain: walk the realised path through the window's tree (depth 1: the plain accept step)
+__global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C, size_t ldp, int iiter, int depth,
+                                    const double *logL, const double *misfits)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int nt = cfg.nt;
-    if (S.valid[c]) {
-        const Draws d = get_draws(cfg, S, c, C, iiter);
-        const int mv = S.move[c];
-        const int pi = par_index(mv);
-        S.proposed[pi * (size_t)C + c] += 1.0;
-        const double like = logL[c], cur = S.like[c];
-        const double beta = S.beta ? S.beta[c] : 1.0;
-        const double dl = (S.beta ? beta * (like - cur) : like - cur);
-        double alpha;
-        if (mv == MV_BIRTH || mv == MV_DEATH) { // Bodin et al. (2012), SingleChain.py:468-485
-            const double theta = S.propdist[2 * (size_t)C + c];
-            const double dv = cfg.vsmax - cfg.vsmin;
-            const double Bt = S.dvs2[c] / (2. * (theta * theta));
-            if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + dl;
-            else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + dl;
-        } else {
-            alpha = dl;
-        }
-        if (log(d.u_accept) < alpha) {
-            const int n = S.pn[c];
-            S.n[c] = n;
-            for (int i = 0; i < n; ++i) {
-                S.vs[(size_t)i * C + c] = S.pvs[(size_t)i * C + c];
-                S.z[(size_t)i * C + c] = S.pz[(size_t)i * C + c];
+    int node = 0, last = -1;
+    double cur = S.like[c];
+    const double beta = S.beta ? S.beta[c] : 1.0;
+    for (int k = 0; k < depth; ++k) {
+        const size_t col = (size_t)node * C + c;
+        bool accepted = false;
+        if (S.valid[col]) {
+            const Draws d = get_draws(cfg, S, c, C, iiter + k, k);
+            const int mv = S.move[col];
+            const int pi = par_index(mv);
+            S.proposed[pi * (size_t)C + c] += 1.0;
+            const double like = logL[col];
+            const double dl = (S.beta ? beta * (like - cur) : like - cur);
+            double alpha;
+            if (mv == MV_BIRTH || mv == MV_DEATH) { // Bodin et al. (2012), SingleChain.py:468-485
+                const double theta = S.propdist[2 * (size_t)C + c];
+                const double dv = cfg.vsmax - cfg.vsmin;
+                const double Bt = S.dvs2[col] / (2. * (theta * theta));
+                if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + dl;
+                else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + dl;
+            } else {
+                alpha = dl;
             }
-            S.vpvs[c] = S.pvpvs[c];
-            for (int i = 0; i < 2 * nt; ++i) S.noise[(size_t)i * C + c] = S.pnoise[(size_t)c * 2 * nt + i];
-            S.like[c] = like;
-            for (int i = 0; i <= nt; ++i) S.misfits[(size_t)i * C + c] = misfits[(size_t)c * (nt + 1) + i];
-            S.accepted[pi * (size_t)C + c] += 1.0;
-            S.naccepted[c] += 1;
-        }
-        // proposal-width adaptation (SingleChain.py:425-450): only reached with a valid proposal (:584)
-        if (iiter % 1000 == 0) {
-            bool all = true;
-            for (int i = 0; i < 5; ++i) all = all && (S.proposed[i * (size_t)C + c] != 0.0);
-            if (all)
-                for (int i = 0; i < 5; ++i) {
-                    const double rate = S.accepted[i * (size_t)C + c] / S.proposed[i * (size_t)C + c] * 100;
-                    double pd = S.propdist[i * (size_t)C + c];
-                    if (rate < cfg.acc_lo) {
-                        pd = pd * 0.95;
-                        if (pd < 0.001) pd = 0.001;
-                    } else if (rate > cfg.acc_hi) {
-                        pd = pd * 1.05;
+            if (log(d.u_accept) < alpha) {
+                accepted = true;
+                last = node;
+                cur = like;
+                S.accepted[pi * (size_t)C + c] += 1.0;
+                S.naccepted[c] += 1;
+            }
+            // proposal-width adaptation (SingleChain.py:425-450): only reached with a valid proposal (:584).
+            // The host ends a window at such an iteration (the widths enter the next proposals).
+            if ((iiter + k) % 1000 == 0) {
+                bool all = true;
+                for (int i = 0; i < 5; ++i) all = all && (S.proposed[i * (size_t)C + c] != 0.0);
+                if (all)
+                    for (int i = 0; i < 5; ++i) {
+                        const double rate = S.accepted[i * (size_t)C + c] / S.proposed[i * (size_t)C + c] * 100;
+                        double pd = S.propdist[i * (size_t)C + c];
+                        if (rate < cfg.acc_lo) {
+                            pd = pd * 0.95;
+                            if (pd < 0.001) pd = 0.001;
+                        } else if (rate > cfg.acc_hi) {
+                            pd = pd * 1.05;
+                        }
+                        S.propdist[i * (size_t)C + c] = pd;
                     }
-                    S.propdist[i * (size_t)C + c] = pd;
-                }
+            }
         }
+        node = 2 * node + (accepted ? 2 : 1);
+    }
+    if (last >= 0) { // the last accepted proposal of the window becomes the chain's state
+        const size_t col = (size_t)last * C + c;
+        const int n = S.pn[col];
+        S.n[c] = n;
+        for (int i = 0; i < n; ++i) {
+            S.vs[(size_t)i * C + c] = S.pvs[(size_t)i * ldp + col];
+            S.z[(size_t)i * C + c] = S.pz[(size_t)i * ldp + col];
+        }
+        // rows beyond n are kept at zero: the state arrays are then a function of the trajectory alone, not of how
+        // it was cut into windows (only the last accepted proposal of a window is written)
+        for (int i = n; i < cfg.maxlayers; ++i) {
+            S.vs[(size_t)i * C + c] = 0.0;
+            S.z[(size_t)i * C + c] = 0.0;
+        }
+        S.vpvs[c] = S.pvpvs[col];
+        for (int i = 0; i < 2 * nt; ++i) S.noise[(size_t)i * C + c] = S.pnoise[col * 2 * nt + i];
+        S.like[c] = cur;
+        for (int i = 0; i <= nt; ++i) S.misfits[(size_t)i * C + c] = misfits[col * (nt + 1) + i];
     }
 }
 
@@ -317,22 +415,46 @@ __global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C
 
 extern "C" {
 
-int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter)
+int bh_chain_propose_window(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
+                            int depth, ptrdiff_t ld)
 {
     if (!cfg || !state || C < 0 || cfg->maxlayers > BH_CHAIN_MAXLAYERS || cfg->nt > BH_MAX_TARGETS) return BH_EINVAL;
+    if (depth < 1 || depth > BH_CHAIN_MAXDEPTH || ld < (ptrdiff_t)C * ((1 << depth) - 1)) return BH_EINVAL;
+    for (int k = 0; k + 1 < depth; ++k)
+        if ((iiter + k) % 1000 == 0) return BH_EINVAL; // an adaptation iteration must be the last of its window
     if (C == 0) return BH_OK;
-    hipLaunchKernelGGL(chain_propose_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter);
+    if (depth == 1 && ld == C) {
+        hipLaunchKernelGGL(chain_propose_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter);
+    } else {
+        const int per_wg = 64 >> (depth - 1);
+        hipLaunchKernelGGL(chain_propose_window_kernel, dim3((C + per_wg - 1) / per_wg), dim3(64), 0, (hipStream_t)stream, *cfg,
+                           *state, C, (size_t)ld, iiter, depth);
+    }
     return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
+}
+
+int bh_chain_accept_window(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter, int depth,
+                           ptrdiff_t ld, const double *logL, const double *misfits)
+{
+    if (!cfg || !state || C < 0 || !logL || !misfits) return BH_EINVAL;
+    if (depth < 1 || depth > BH_CHAIN_MAXDEPTH || ld < (ptrdiff_t)C * ((1 << depth) - 1)) return BH_EINVAL;
+    for (int k = 0; k + 1 < depth; ++k)
+        if ((iiter + k) % 1000 == 0) return BH_EINVAL;
+    if (C == 0) return BH_OK;
+    hipLaunchKernelGGL(chain_accept_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, (size_t)ld,
+                       iiter, depth, logL, misfits);
+    return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
+}
+
+int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter)
+{
+    return bh_chain_propose_window(stream, cfg, state, C, iiter, 1, C);
 }
 
 int bh_chain_accept(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
                     const double *logL, const double *misfits)
 {
-    if (!cfg || !state || C < 0 || !logL || !misfits) return BH_EINVAL;
-    if (C == 0) return BH_OK;
-    hipLaunchKernelGGL(chain_accept_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter,
-                       logL, misfits);
-    return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
+    return bh_chain_accept_window(stream, cfg, state, C, iiter, 1, C, logL, misfits);
 }
 
 } // extern "C"

@@ -110,6 +110,10 @@ __device__ __forceinline__ void sincos_cw(double x, double *sn, double *cs)
 // e^x, Taylor of degree 13 on |r| <= ln2/2 (remainder 4e-18), scaled by ldexp (under/overflow as ldexp's)
 __device__ __forceinline__ double exp_cw(double x)
 {
+    // |x| beyond the exponent range: the reduction below would lose all bits of r; clamped, the result is ldexp's
+    // 0 / inf as for the library's exp (x < -745 -> 0, x > 710 -> inf).  NaN passes through (both tests are false).
+    x = (x < -800.0) ? -800.0 : x;
+    x = (x > 800.0) ? 800.0 : x;
     const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
     double r = fma(-k, 0x1.62e42fefa39efp-1, x);
     r = fma(-k, 0x1.abc9e3b39803fp-56, r);
@@ -186,6 +190,12 @@ __device__ __forceinline__ void store_cm2(double *p, const cm2 &m)
 __device__ __forceinline__ cm2 load_cm2(const double *p)
 {
     return cm2{cd{p[0], p[1]}, cd{p[2], p[3]}, cd{p[4], p[5]}, cd{p[6], p[7]}};
+}
+// 0 for finite entries, NaN as soon as one is NaN or +-inf (x - x is 0 for finite x only)
+__device__ __forceinline__ double nonfinite(const cm2 &m)
+{
+    return (m.c11.re - m.c11.re) + (m.c11.im - m.c11.im) + (m.c12.re - m.c12.re) + (m.c12.im - m.c12.im) +
+           (m.c21.re - m.c21.re) + (m.c21.im - m.c21.im) + (m.c22.re - m.c22.re) + (m.c22.im - m.c22.im);
 }
 
 // greens.cpp:19-85 (P/SV part)
@@ -331,6 +341,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
     const double p = A.p_s_per_deg * 0.00899; // wrap.cpp:55
     const double p2 = p * p;
     double bad = 0.0;
+    double nf = 0.0; // stays 0 while every coefficient of the record is finite
 
     // top-layer quantities before flattening (q = 1 for the top layer anyway)
     const double vp0 = A.vp[base], vs0 = A.vs[base];
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
         double *lay = rec + REC_HEAD + 8 * l;
         lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
         lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
+        for (int k = 0; k < 7; ++k) nf += lay[k] - lay[k];
         // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
         const double vv = (A.waveno == 0) ? vp : vs;
         t0 += hh * sqrt(1. / (vv * vv) - p2);
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
             hm.c22 = -(qq * a1 * b1 * (2. * vs2 * p));
             hm.c11 = 2.0 * hm.c11; hm.c12 = 2.0 * hm.c12; hm.c21 = 2.0 * hm.c21; hm.c22 = 2.0 * hm.c22;
             store_cm2(rec + 8, hm);
+            nf += nonfinite(ru) + nonfinite(hm);
             (void)vp2;
         } else {
             cm2 rd, td, ru, tu;
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
             store_cm2(ic + 8, td);
             store_cm2(ic + 16, ru);
             store_cm2(ic + 24, tu);
+            nf += nonfinite(rd) + nonfinite(td) + nonfinite(ru) + nonfinite(tu);
         }
         pvp = vp; pvs = vs; prh = rh;
         ztop = znext;
@@ -422,7 +436,12 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
         m12 = 2. * p * vstop * vstop / vptop;
         m21 = -2. * p * vstop;
         m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
+        nf += (m11 - m11) + (m12 - m12) + (m21 - m21) + (m22 - m22);
     }
+    // A non-finite coefficient makes every bin of the reference's spectrum non-finite, hence the whole trace (the
+    // inverse FFT sums all bins); with the spectral cut-off the bins above it are not formed here, so the record
+    // carries the flag instead of relying on the propagation
+    if (nf != 0.0) bad = 1.0;
     rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
     rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
 }
@@ -473,10 +492,12 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
             hh = R * log(q) - zf;
         }
     }
+    double nf = 0.0; // stays 0 while every coefficient this lane writes is finite
     if (on) {
         double *lay = rec + REC_HEAD + 8 * l;
         lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
         lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
+        for (int k = 0; k < 7; ++k) nf += lay[k] - lay[k];
     }
     // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
     const double vv = (A.waveno == 0) ? vp : vs;
@@ -491,11 +512,15 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         store_cm2(ic + 8, td);
         store_cm2(ic + 16, ru);
         store_cm2(ic + 24, tu);
+        nf += nonfinite(rd) + nonfinite(td) + nonfinite(ru) + nonfinite(tu);
     }
-    double t0 = 0.0;
+    double t0 = 0.0, nfall = 0.0;
     for (int i = 0; i < LP; ++i) {
-        const double ti = __shfl(term, lbase + i);
-        if (i < nlay) t0 += ti;
+        const double ti = __shfl(term, lbase + i), ni = __shfl(nf, lbase + i);
+        if (i < nlay) {
+            t0 += ti;
+            nfall += ni;
+        }
     }
     if (vm && l == 0) {
         // free surface, greens.cpp:87-112 (plain sqrt) and displacement matrix :307-322
@@ -542,7 +567,11 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
             m12 = 2. * p * vstop * vstop / vptop;
             m21 = -2. * p * vstop;
             m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
+            nfall += (m11 - m11) + (m12 - m12) + (m21 - m21) + (m22 - m22);
         }
+        // non-finite coefficients anywhere in the record: the whole trace is non-finite in the reference (see rf_coef_kernel)
+        nfall += nonfinite(ru) + nonfinite(hm);
+        if (nfall != 0.0) bad = 1.0;
         rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
         rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
     }
@@ -621,7 +650,7 @@ void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     // factor is below 1e-30 the bin is below 1e-30 of the pass band (|R/Z| is of order one) and cannot change a
     // double-precision sum of the others: such bins are set to zero instead of being computed (the reference
     // computes them and multiplies by ~0).  With a = 2.5, 20 Hz, nsamp 2048 that is every bin above 6.6 Hz, a third.
-    static const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch
+    const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch, read per launch (tests toggle it)
     const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
     const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;

@@ -7,6 +7,15 @@ so the per-chain Python of the reference's sampler (src/SingleChain.py:511-589 `
 per-chain loops of `bayhunter_amd.chains.ChainBatch`) disappears from the loop; the host only
 counts iterations and takes thinned snapshots of the chain states.
 
+Few chains (BASELINE configs[3]: 8 per GPU) leave the GPU idle: one evaluation launch costs ~1.5 ms
+whether it holds 8 or 500 models (the length of ONE model's dispersion root search).  `spec_depth` = d
+advances every chain by d iterations per launch instead: the proposals of both outcomes of each of the
+next d accept/reject decisions are written down first (bh_chain_propose_window: a binary tree of
+2^d - 1 proposals per chain; the draws are a pure function of (chain, iteration)), all of them are
+evaluated in ONE bh_evaluate_batch, and bh_chain_accept_window walks the realised path -- the
+trajectory of the sequential walk, bit for bit.  Windows end where something outside a chain's own
+state changes: proposal-width adaptation (every 1000th iteration), snapshots, temperature exchanges.
+
 Random numbers are counter-based (Philox4x32-10) on the device, so a run is reproducible from
 `seed` but is NOT the reference's Mersenne-Twister trajectory: `ChainBatch` is the draw-for-draw
 replay of the reference, this class is the throughput mode.  The proposal / validity / acceptance
@@ -31,13 +40,27 @@ import os.path as op
 import numpy as np
 
 from .chains import ChainBatch, DEFAULT_INITPARAMS, DEFAULT_PRIORS, _is_fixed
-from .engine import BH_CHAIN_MAXLAYERS, ChainConfig, ChainState, EngineError
+from .engine import BH_CHAIN_MAXDEPTH, BH_CHAIN_MAXLAYERS, ChainConfig, ChainState, EngineError
 from .Targets import JointTarget
+
+
+def auto_spec_depth(nchains, budget=None):
+    """Speculation depth for `nchains` chains on one GPU: the deepest tree whose nodes (chains x (2^d - 1)
+    evaluations per launch) stay within `budget` evaluations -- below ~1000 models a launch of the dispersion kernel
+    costs about what 8 models cost (1.5 ms at B <= 512, 2.0 ms at 1024, 3.0 ms at 2048), so d
+    iterations per launch are nearly free; beyond it the launch time grows faster than the depth.
+    BH_SPEC_BUDGET overrides the budget (0 = no speculation)."""
+    if budget is None:
+        budget = int(os.environ.get("BH_SPEC_BUDGET", "1024"))
+    d = 1
+    while d < BH_CHAIN_MAXDEPTH and nchains * ((1 << (d + 1)) - 1) <= budget:
+        d += 1
+    return d
 
 
 class DeviceChains(object):
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None):
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
         torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
         (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
@@ -50,7 +73,10 @@ class DeviceChains(object):
         chains keep their states and swap betas, so nothing but (logL, beta, ladder) of each chain crosses GPUs).
         Posterior samples are the snapshots of the chains that hold beta = 1 at that time
         (`samples(cold_only=True)`, and what `save()` writes).
-        device: CUDA device index; default = the engine's (`JointTarget(..., engine=)`), else 0."""
+        device: CUDA device index; default = the engine's (`JointTarget(..., engine=)`), else 0.
+        spec_depth: iterations per evaluation launch (speculative window, 1..7; module docstring).  None = chosen
+        from the number of chains so that a launch stays in the latency regime (`auto_spec_depth`); 1 = one
+        iteration per launch.  Results do not depend on it."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
@@ -77,9 +103,16 @@ class DeviceChains(object):
         self.iiter = -self.iter_phase1
         self.thinning = max(1, int(np.ceil(float(self.iter_phase2) / float(ip["maxmodels"]))))
         self.swap_every, self.dist, self._nswaps_host, self.sweep, self.seed = int(swap_every), dist, 0, 0, int(seed)
+        self.depth = auto_spec_depth(self.C) if spec_depth is None else int(spec_depth)
+        if not 1 <= self.depth <= BH_CHAIN_MAXDEPTH:
+            raise EngineError("spec_depth must be 1..%d" % BH_CHAIN_MAXDEPTH)
+        self.ld = self.C * ((1 << self.depth) - 1)        # columns of the proposal arrays: all nodes of all chains
+        self.snap_in_run = False                          # run(): windows also end at snapshot iterations
+        self.launches = 0
         self._dev_exchange = None
-        from .parallel import chain_layout, chain_seeds
-        off, tot = chain_layout(self.C, dist)
+        from .parallel import chain_layout, chain_seeds, rank_chain_counts
+        self.rank_counts = rank_chain_counts(self.C, dist, int(device))       # collective buffers on THIS rank's GPU
+        off, tot = chain_layout(self.C, dist, int(device))
         if chain_offset is not None:
             off = int(chain_offset)
         self.chain_offset, self.C_global = off, max(tot, off + self.C)
@@ -143,18 +176,19 @@ class DeviceChains(object):
         t["naccepted"] = torch.zeros(Cn, dtype=torch.int64, device=dev)
         t["beta"] = None if betas is None else torch.as_tensor(np.asarray(betas, dtype=np.float64)).to(dev)
         self.ladder = None if betas is None else np.asarray(ladder if ladder is not None else np.zeros(Cn), dtype=np.int64)
+        ld = self.ld                                      # node j of chain c in column j*C + c
         for k in ("pn", "move", "valid", "lay_n"):
-            t[k] = torch.zeros(Cn, **i32)
+            t[k] = torch.zeros(ld, **i32)
         for k in ("pvs", "pz", "lay_h", "lay_vp", "lay_vs"):
-            t[k] = torch.zeros((ML, Cn), **f64)
-        t["pvpvs"], t["dvs2"] = torch.zeros(Cn, **f64), torch.zeros(Cn, **f64)
-        t["pnoise"] = torch.zeros((Cn, 2 * nt), **f64)
-        t["inject"] = torch.zeros((6, Cn), **f64) if inject else None
+            t[k] = torch.zeros((ML, ld), **f64)
+        t["pvpvs"], t["dvs2"] = torch.zeros(ld, **f64), torch.zeros(ld, **f64)
+        t["pnoise"] = torch.zeros((ld, 2 * nt), **f64)
+        t["inject"] = torch.zeros((self.depth, 6, Cn), **f64) if inject else None
         self.t = t
-        # outputs of the evaluate call of the current iteration
-        self.logL = torch.zeros(Cn, **f64)
-        self.mis = torch.zeros((Cn, nt + 1), **f64)
-        self.err = torch.zeros(Cn, **i32)
+        # outputs of the evaluate call of the current window
+        self.logL = torch.zeros(ld, **f64)
+        self.mis = torch.zeros((ld, nt + 1), **f64)
+        self.err = torch.zeros(ld, **i32)
         st = ChainState()
         for k in ChainState._fields_:
             v = t[k[0]]
@@ -166,25 +200,41 @@ class DeviceChains(object):
             on_gpu = dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or dist.get_backend() == "nccl"
             if on_gpu and os.environ.get("BH_PT_HOST_EXCHANGE", "0") != "1":
                 from .parallel import DeviceExchange, gather_chain_axis
-                ladder_all = gather_chain_axis(self.ladder, 0, dist)
-                from .parallel import chain_layout
-                start = chain_layout(Cn, dist)[0]                      # position of this rank's block in gather order
+                ladder_all = gather_chain_axis(self.ladder, 0, dist, int(device))
+                start = int(sum(self.rank_counts[:self.rank]))         # position of this rank's block in gather order
                 mine = slice(start, start + Cn)
                 self._ext_stream = torch.cuda.ExternalStream(int(self.engine.stream), device=dev)
-                self._dev_exchange = DeviceExchange(ladder_all, self.seed, mine, dev)
+                self._dev_exchange = DeviceExchange(ladder_all, self.seed, mine, dev, self.rank_counts)
         self.snap = {"p1": [], "p2": []}
 
-    # ---- one lock-step iteration of all chains: three enqueues, no synchronisation -----------------
+    def window(self):
+        """Iterations the next launch may cover: the speculation depth, cut where something outside a chain's own
+        state changes -- the proposal-width adaptation (an iteration with iiter % 1000 == 0 is the last of its
+        window), a temperature exchange, a snapshot of run(), the end of the run."""
+        i = self.iiter
+        w = min(self.depth, self.iter_phase2 - i, (-i) % 1000 + 1)
+        if self.swap_every > 0 and self.t["beta"] is not None:
+            w = min(w, self.swap_every - i % self.swap_every)
+        if self.snap_in_run:
+            w = min(w, self.thinning - i % self.thinning)
+        return max(1, w)
+
+    # ---- one lock-step window of all chains: three enqueues, no synchronisation ---------------------
     def iterate(self):
+        """Advance every chain by `window()` iterations (1 with spec_depth = 1); returns that number."""
         e, t, Cn = self.engine, self.t, self.C
-        e.chain_propose(self.cfg, self.state, Cn, self.iiter)
-        e.evaluate_batch_dev(Cn, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
-                             t["lay_vs"].data_ptr(), None, Cn, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
+        w = self.window()
+        B = Cn * ((1 << w) - 1)
+        e.chain_propose_window(self.cfg, self.state, Cn, self.iiter, w, self.ld)
+        e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
+                             t["lay_vs"].data_ptr(), None, self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
                              self.mis.data_ptr(), self.err.data_ptr())
-        e.chain_accept(self.cfg, self.state, Cn, self.iiter, self.logL.data_ptr(), self.mis.data_ptr())
-        self.iiter += 1
+        e.chain_accept_window(self.cfg, self.state, Cn, self.iiter, w, self.ld, self.logL.data_ptr(), self.mis.data_ptr())
+        self.iiter += w
+        self.launches += 1
         if self.swap_every > 0 and t["beta"] is not None and self.iiter % self.swap_every == 0:
             self.exchange()
+        return w
 
     def exchange(self):
         """One replica-exchange sweep (the only step of a sharded job with a collective).  On the GPU (one rank, or
@@ -221,12 +271,17 @@ class DeviceChains(object):
         self.engine.set_typical_layers(int(np.ceil(row["n"].mean())))
 
     def run(self, progress=None):
-        while self.iiter < self.iter_phase2:
-            if self.iiter % self.thinning == 0:
-                self._snapshot()
-            self.iterate()
-            if progress is not None and self.iiter % 1000 == 0:
-                progress(self)
+        self.snap_in_run = True
+        try:
+            while self.iiter < self.iter_phase2:
+                if self.iiter % self.thinning == 0:
+                    self._snapshot()
+                before = self.iiter
+                self.iterate()
+                if progress is not None and self.iiter // 1000 != before // 1000:
+                    progress(self)
+        finally:
+            self.snap_in_run = False
         self.engine.synchronize()
         self.engine.set_typical_layers(0)
         return self
@@ -264,9 +319,15 @@ class DeviceChains(object):
         if not (gather or cold_only):
             return out
         from .parallel import gather_chain_axis, cold_samples
-        out = {k: gather_chain_axis(v, 1, self.dist) for k, v in out.items()}
+        dv = self.dev.index
+        out = {k: gather_chain_axis(v, 1, self.dist, dv) for k, v in out.items()}
+        out["chain_id"] = gather_chain_axis(self.chain_offset + np.arange(Cn, dtype=np.int64), 0, self.dist, dv)
+        if len(np.unique(out["chain_id"])) != out["chain_id"].size:
+            raise EngineError("sharded job with overlapping chain numbers (chain_offset): two ranks would draw the same "
+                              "random streams and write the same files")
         if cold_only and "beta" in out:
-            ladder = gather_chain_axis(self.ladder, 0, self.dist)
+            ladder = gather_chain_axis(self.ladder, 0, self.dist, dv)
+            out.pop("chain_id")
             ids, out = cold_samples(out, ladder)
             out["ladder"] = ids
         return out
@@ -284,7 +345,9 @@ class DeviceChains(object):
                 continue
             s = self.samples(tag, cold_only=tempered, gather=True)      # collective: every rank takes part
             if self.rank == 0:
-                ids = s["ladder"] if tempered else np.arange(s["models"].shape[1])
+                # file numbers = GLOBAL chain indices (= the chain's Philox / initial-state index), also with an
+                # explicit chain_offset; tempered runs: ladder ids
+                ids = s["ladder"] if tempered else s["chain_id"]
                 write_chain_files(savepath, tag, s, ids)
         if self.rank == 0:
             from .results import save_config

@@ -47,6 +47,7 @@ class TargetDesc(C.Structure):
 
 BH_MAX_TARGETS = 8
 BH_CHAIN_MAXLAYERS = 32
+BH_CHAIN_MAXDEPTH = 7
 
 
 class ChainConfig(C.Structure):
@@ -121,11 +122,14 @@ def load_library():
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
     L.bh_chain_propose.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int]
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
+    L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
+    L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
                  "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept"):
+                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
+                 "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 2:
+    if L.bh_abi_version() != 3:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
@@ -134,7 +138,8 @@ def load_library():
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
                     "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept")
+                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
+                    "bh_chain_propose_window", "bh_chain_accept_window")
 
 
 def _f64(a):
@@ -394,6 +399,17 @@ class Engine(object):
         rc = self._L.bh_chain_accept(self.stream, C.byref(cfg), C.byref(state), int(C_), int(iiter), logL, misfits)
         if rc != BH_OK:
             raise EngineError("bh_chain_accept failed (%d)" % rc)
+
+    def chain_propose_window(self, cfg, state, C_, iiter, depth, ld):
+        rc = self._L.bh_chain_propose_window(self.stream, C.byref(cfg), C.byref(state), int(C_), int(iiter), int(depth), int(ld))
+        if rc != BH_OK:
+            raise EngineError("bh_chain_propose_window failed (%d)" % rc)
+
+    def chain_accept_window(self, cfg, state, C_, iiter, depth, ld, logL, misfits):
+        rc = self._L.bh_chain_accept_window(self.stream, C.byref(cfg), C.byref(state), int(C_), int(iiter), int(depth), int(ld),
+                                            logL, misfits)
+        if rc != BH_OK:
+            raise EngineError("bh_chain_accept_window failed (%d)" % rc)
 
 
 _default = {}

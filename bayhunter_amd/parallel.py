@@ -8,7 +8,17 @@ computes the same swap permutation from a shared seed.  Parallel tempering has n
 the reference: "parity unpinned"; it is checked through invariants (permutation validity, detailed
 balance of the acceptance rule, identical decisions on every rank).
 """
+import threading
+
 import numpy as np
+
+
+def _cuda_device(device=None):
+    """torch device for collective buffers under nccl: the GPU named by the caller (a chain driver passes its
+    engine's GPU), else the current one.  Never the implicit `'cuda'` of a process that has not selected a device:
+    with one rank per GPU that would put every rank's buffers on GPU 0."""
+    import torch
+    return torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
 
 
 def shard_slice(n_items, rank, world):
@@ -27,27 +37,47 @@ def chain_owner(chain, n_chains, world):
     raise IndexError(chain)
 
 
-def all_gather_rows(local, dist=None):
-    """Concatenate per-rank row blocks [n_r, m] (n_r may differ by rank) on every rank."""
+def all_gather_rows(local, dist=None, counts=None):
+    """Concatenate per-rank row blocks [n_r, m] (n_r may differ by rank) on every rank.
+    counts: the n_r of every rank when the caller knows them (static layouts): the call is then ONE fixed-size
+    collective with no host synchronisation; otherwise the counts are gathered first (an extra collective and a
+    device-to-host read)."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
     home = local.device
     if dist.get_backend() == "gloo" and local.is_cuda:   # CPU tests / dry runs: gloo moves host memory
-        return all_gather_rows(local.cpu(), dist).to(home)
-    n = torch.tensor([local.shape[0]], device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    nmax = int(max(c.item() for c in counts))
-    pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    bufs = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    return torch.cat([b[:int(c.item())] for b, c in zip(bufs, counts)], dim=0)
+        return all_gather_rows(local.cpu(), dist, counts).to(home)
+    if counts is None:
+        n = torch.tensor([local.shape[0]], device=local.device)
+        cts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(cts, n)
+        counts = [int(c.item()) for c in cts]
+    counts = [int(c) for c in counts]
+    if counts[dist.get_rank()] != local.shape[0]:
+        raise ValueError("all_gather_rows: rank %d holds %d rows, counts say %d" % (dist.get_rank(), local.shape[0], counts[dist.get_rank()]))
+    nmax = max(counts)
+    if local.shape[0] == nmax:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    if all(c == nmax for c in counts):
+        return out
+    return torch.cat([out[r * nmax:r * nmax + c] for r, c in enumerate(counts)], dim=0)
 
 
-_RS = np.random.RandomState(0)   # scratch generator of the swap decisions, re-seeded for every (ladder, sweep)
+_TLS = threading.local()   # scratch generator of the swap decisions, one per thread (two chain drivers may run in threads)
+
+
+def _scratch_rs():
+    rs = getattr(_TLS, "rs", None)
+    if rs is None:
+        rs = _TLS.rs = np.random.RandomState(0)
+    return rs
 
 
 def swap_decisions(logL, beta, sweep, seed):
@@ -60,8 +90,9 @@ def swap_decisions(logL, beta, sweep, seed):
     beta = np.asarray(beta, dtype=float)
     n = logL.size
     perm = np.arange(n)
-    _RS.seed((int(seed) * 1000003 + int(sweep)) % (2 ** 32))      # (re-seeding is 30x cheaper than a new RandomState)
-    u = _RS.uniform(size=n)
+    rs = _scratch_rs()
+    rs.seed((int(seed) * 1000003 + int(sweep)) % (2 ** 32))       # (re-seeding is 30x cheaper than a new RandomState)
+    u = rs.uniform(size=n)
     for r in range(sweep % 2, n - 1, 2):
         log_alpha = (beta[r] - beta[r + 1]) * (logL[r + 1] - logL[r])
         if np.log(u[r]) < log_alpha:
@@ -69,14 +100,15 @@ def swap_decisions(logL, beta, sweep, seed):
     return perm
 
 
-def tempering_swap(local_logL, local_beta, sweep, seed, dist=None):
+def tempering_swap(local_logL, local_beta, sweep, seed, dist=None, device=None):
     """All-gather (logL, beta) of the local replicas (rank-major rung order), decide the swaps.
-    Returns (perm over all replicas, slice of the global arrays owned by this rank)."""
+    Returns (perm over all replicas, slice of the global arrays owned by this rank).
+    device: this rank's GPU (nccl groups; default the current device)."""
     import torch
     local = torch.stack((torch.as_tensor(local_logL, dtype=torch.float64),
                          torch.as_tensor(local_beta, dtype=torch.float64)), dim=1)
     if dist is not None and dist.is_initialized() and dist.get_backend() == "nccl":
-        local = local.cuda()
+        local = local.to(_cuda_device(device))
     allv = all_gather_rows(local, dist).cpu().numpy()
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
@@ -136,9 +168,12 @@ class DeviceExchange(object):
     sweep) only; their logarithms are uploaded from pinned memory).  Sharded jobs all-gather (logL, beta) with RCCL
     (device tensors).  Same decisions as the NumPy form, bit for bit (tests/test_gpu_sharded.py)."""
 
-    def __init__(self, ladder_all, seed, mine, device):
+    def __init__(self, ladder_all, seed, mine, device, rank_counts=None):
+        """rank_counts: chains per rank of the job (static): the gather of a sweep is then one fixed-size
+        collective and the sweep is enqueue-only on every rank count, not just on one."""
         import torch
         self.torch, self.dev, self.seed, self.mine = torch, device, int(seed), mine
+        self.rank_counts = None if rank_counts is None else [int(c) for c in rank_counts]
         lad = np.asarray(ladder_all, dtype=np.int64)
         self.N = lad.size
         self.lids, self.counts = np.unique(lad, return_counts=True)          # sorted ladder ids, chains per ladder
@@ -157,8 +192,9 @@ class DeviceExchange(object):
         p = 0
         for lid, n in zip(self.lids, self.counts):
             s2 = (self.seed * 7919 + int(lid)) % (2 ** 31)
-            _RS.seed((s2 * 1000003 + int(sweep)) % (2 ** 32))
-            out[p:p + n] = _RS.uniform(size=n)
+            rs = _scratch_rs()
+            rs.seed((s2 * 1000003 + int(sweep)) % (2 ** 32))
+            out[p:p + n] = rs.uniform(size=n)
             p += n
         with np.errstate(divide="ignore"):
             return np.log(out)
@@ -173,7 +209,7 @@ class DeviceExchange(object):
         if torch.device(self.dev).type == "cuda":
             logu = logu.pin_memory().to(self.dev, non_blocking=True)
         local = torch.stack((like.to(torch.float64), beta.to(torch.float64)), dim=1)
-        allv = all_gather_rows(local, dist)
+        allv = all_gather_rows(local, dist, self.rank_counts)
         L, Bt = allv[:, 0], allv[:, 1]
         o1 = torch.sort(-Bt, stable=True).indices                      # beta descending, ties by chain index
         order = o1[torch.sort(self.ladder[o1], stable=True).indices]   # grouped by ladder, coldest first
@@ -192,15 +228,24 @@ class DeviceExchange(object):
 
 
 # ---- sharded chains: global numbering, result gather, cold-chain assembly -------------------------
-def chain_layout(n_local, dist=None):
-    """(offset of this rank's first chain, total chains of the job): ranks own contiguous blocks of the
-    global chain list in rank order (block sizes may differ)."""
+def rank_chain_counts(n_local, dist=None, device=None):
+    """Chains held by every rank of the job (one small all-gather; rank order)."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(n_local)]
+    dev = _cuda_device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    world = dist.get_world_size()
+    return all_gather_rows(torch.tensor([[int(n_local)]], dtype=torch.int64, device=dev), dist, [1] * world).cpu().numpy().ravel().tolist()
+
+
+def chain_layout(n_local, dist=None, device=None):
+    """(offset of this rank's first chain, total chains of the job): ranks own contiguous blocks of the
+    global chain list in rank order (block sizes may differ).  device: this rank's GPU (nccl groups: where the
+    collective's buffer lives; default the current device)."""
+    counts = rank_chain_counts(n_local, dist, device)
+    if len(counts) == 1:
         return 0, int(n_local)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    counts = all_gather_rows(torch.tensor([[int(n_local)]], dtype=torch.int64, device=dev), dist).cpu().numpy().ravel()
-    return int(counts[:dist.get_rank()].sum()), int(counts.sum())
+    return int(sum(counts[:dist.get_rank()])), int(sum(counts))
 
 
 def chain_seeds(seed, offset, n_local):
@@ -210,9 +255,9 @@ def chain_seeds(seed, offset, n_local):
     return rs.randint(0, 2 ** 31 - 1, size=int(offset) + int(n_local))[int(offset):]
 
 
-def gather_chain_axis(a, axis, dist=None):
+def gather_chain_axis(a, axis, dist=None, device=None):
     """numpy array with a chain axis (this rank's chains) -> the same array for ALL chains of the job, on every
-    rank (all-gather; RCCL when the process group is nccl, gloo otherwise)."""
+    rank (all-gather; RCCL when the process group is nccl, gloo otherwise).  device: this rank's GPU (nccl)."""
     import torch
     a = np.asarray(a)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -220,7 +265,7 @@ def gather_chain_axis(a, axis, dist=None):
     moved = np.ascontiguousarray(np.moveaxis(a, axis, 0))
     t = torch.from_numpy(moved.reshape(moved.shape[0], -1))
     if dist.get_backend() == "nccl":
-        t = t.cuda()
+        t = t.to(_cuda_device(device))
     out = all_gather_rows(t, dist).cpu().numpy()
     return np.moveaxis(out.reshape((out.shape[0],) + moved.shape[1:]), 0, axis)
 

@@ -13,7 +13,6 @@ import os
 import os.path as op
 import pickle
 import sys
-import types
 
 import numpy as np
 
@@ -49,44 +48,48 @@ def _shadow(obj, classes):
 
 
 def _reference_classes():
-    """name -> class object importable under the reference's module path while pickling.  Where the reference
-    package itself is importable its own classes are used; otherwise empty stand-in classes are registered under
-    the reference's module names for the duration of the dump (pickle stores classes BY NAME: the file then
-    loads into the real classes wherever the reference is installed)."""
-    classes, added = {}, []
+    """name -> class object standing for the reference's class of that name while pickling.  Where the reference
+    package itself is already imported its own classes are used; otherwise empty stand-in classes that carry the
+    reference's (module, name) -- `_RefPickler` writes that name into the file (pickle stores classes BY NAME: the
+    file then loads into the real classes wherever the reference is installed).  Nothing is registered in
+    sys.modules: a concurrent `import BayHunter` in another thread never sees a stand-in."""
+    classes = {}
     for name, mod in _REF_CLASS.items():
         m = sys.modules.get(mod)
-        if m is None:
-            try:
-                m = __import__(mod, fromlist=[name])
-            except Exception:
-                m = None
-        if m is None or not hasattr(m, name):
-            for part in (mod.split(".")[0], mod):
-                if part not in sys.modules:
-                    sys.modules[part] = types.ModuleType(part)
-                    added.append(part)
-            m = sys.modules[mod]
-            cls = type(name, (object,), {"__module__": mod})
-            setattr(m, name, cls)
-        classes[name] = getattr(m, name)
-    return classes, added
+        if m is not None and hasattr(m, name):
+            classes[name] = getattr(m, name)
+        else:
+            classes[name] = type(name, (object,), {"__module__": mod, "_bh_ref_path": (mod, name)})
+    return classes
+
+
+class _RefPickler(pickle._Pickler):
+    """The pure-Python pickler with one change: a stand-in class is written as the GLOBAL it stands for, without the
+    importability check of `save_global` (the class lives in the reference package, which need not be installed
+    where the file is written).  The dispatch table is this class's own copy with its own handler for classes:
+    libraries that extend the stock table process-wide (dill does, once imported) do not change what is written."""
+    dispatch = dict(pickle._Pickler.dispatch)
+
+    def _save_class(self, obj):
+        ref = obj.__dict__.get("_bh_ref_path")
+        if ref is None:
+            return pickle._Pickler.save_global(self, obj)
+        self.write(pickle.GLOBAL + ref[0].encode("ascii") + b"\n" + ref[1].encode("ascii") + b"\n")
+        self.memoize(obj)
+
+    dispatch[type] = _save_class
 
 
 def save_config(targets, configfile, priors=None, initparams=None):
     """Write the configuration pickle `PlotFromStorage.__init__` needs (src/Plotting.py:52-58): the targets (as
     instances of the reference's classes), their refs, priors and initparams (src/utils.py:127-153)."""
     tl = targets.targets if hasattr(targets, "targets") else list(targets)
-    classes, added = _reference_classes()
-    try:
-        data = {"targets": [_shadow(t, classes) for t in tl], "targetrefs": [t.ref for t in tl],
-                "priors": dict(priors or {}), "initparams": dict(initparams or {})}
-        os.makedirs(op.dirname(op.abspath(configfile)), exist_ok=True)
-        with open(configfile, "wb") as f:
-            pickle.dump(data, f, protocol=2)
-    finally:
-        for part in added:
-            sys.modules.pop(part, None)
+    classes = _reference_classes()
+    data = {"targets": [_shadow(t, classes) for t in tl], "targetrefs": [t.ref for t in tl],
+            "priors": dict(priors or {}), "initparams": dict(initparams or {})}
+    os.makedirs(op.dirname(op.abspath(configfile)), exist_ok=True)
+    with open(configfile, "wb") as f:
+        _RefPickler(f, protocol=2).dump(data)
     return configfile
 
 

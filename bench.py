@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- forward-model + logL evaluations per second on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5|c2g|c3g] [--batch B]
+
+The default (--workload all) prints the c2 line -- the configuration the metric is quoted on -- and, inside the same
+JSON line, the other BASELINE configs as blocks timed the same way right after it: "c3" (configs[2], with an
+`rf_roofline` block for the receiver-function kernels measured alone on that configuration), "c4" and "c5"
+(configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s).
 
 A "step" is ONE pass of the hot path over one batch of B synthetic candidate models that are
 already resident in HBM: `bh_evaluate_batch` (C ABI, memspace = device) = every registered
@@ -48,6 +53,9 @@ FP64_VALU_PEAK_TF = 78.6    # CDNA4 FP64 vector peak; this path
 # flop-equivalents per layer-propagator step: Rayleigh ~320, Love ~65
 FLOP_PER_LPS = {2: 320.0, 1: 65.0}
 NPOOL = 4                   # distinct batches rotated through the steps
+CLOCK_WARMUP_MS = 150.0     # untimed launches of the step before the --warmup steps (clock ramp of an idle GPU)
+RF_CUT_WA = 16.6226         # csrc/rf_kernel.hip: w/a beyond which the Gauss low-pass is below 1e-30
+RF_FLOP_PER_LAYER_STEP = 600.0   # flop-equivalents of one layer of the reflectivity recursion for one frequency
 
 
 def build_workload(name, B, L, seed):
@@ -207,12 +215,15 @@ def cpu_baseline(spec, batch, noise, workload):
                       % (n, workload, best, sorted(probe_rates), ncpu, 1.0 / per_model)}
 
 
-def run_chains(args, eng, rank, world, dist, dev):
-    """c4 / c5: device-resident chains (bayhunter_amd.device_chains) on the c3 targets."""
+def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
+    """c4 / c5: device-resident chains (bayhunter_amd.device_chains) on the c3 targets.  Returns the result block on
+    rank 0 (None elsewhere).  `steps` / `warmup` are ITERATIONS of every chain (main phase timed, burn-in untimed); one
+    evaluation launch advances every chain by `spec_depth` iterations (speculative windows, chain_kernel.hip)."""
+    import torch
     import bayhunter_amd as bh
     from bayhunter_amd.device_chains import DeviceChains
     from bayhunter_amd.synth import true_model, SWD_PERIODS, RF_TIME, SEED
-    C = args.chains or (8 if args.workload == "c4" else 64)
+    C = args.chains or (8 if workload == "c4" else 64)
     nlay, h, vp, vs, rho = true_model(args.layers)
     nrs = np.random.RandomState(SEED + 2)
     ys = {}
@@ -225,15 +236,16 @@ def run_chains(args, eng, rank, world, dist, dev):
     jt = bh.JointTarget([bh.RayleighDispersionPhase(SWD_PERIODS, ys["r"]), bh.LoveDispersionPhase(SWD_PERIODS, ys["l"]), t3], engine=eng)
     priors = dict(vpvs=(1.4, 2.1), layers=(1, 20), vs=(2, 5), z=(0, 60), rfnoise_corr=(0.35, 0.75), rfnoise_sigma=(1e-5, 0.05),
                   swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1))
-    init = dict(iter_burnin=args.warmup, iter_main=args.steps, acceptance=(40, 45), thickmin=0.1, lvz=None, hvz=None, rcond=None,
-                maxmodels=max(1, args.steps // 100))
+    init = dict(iter_burnin=warmup, iter_main=steps, acceptance=(40, 45), thickmin=0.1, lvz=None, hvz=None, rcond=None,
+                maxmodels=max(1, steps // 100))
     kw = {}
-    if args.workload == "c5":   # one temperature per rank (geometric ladder 1..30 over 8 rungs), ladders = chains
+    if workload == "c5":   # one temperature per rank (geometric ladder 1..30 over 8 rungs), ladders = chains
         ladder = 1.0 / np.geomspace(1.0, 30.0, 8)
         kw = dict(betas=np.full(C, ladder[rank % 8]), ladder=np.arange(C) + C * (rank // 8), swap_every=100)
     # ONE job seed on every rank: the chains' streams follow their global index, the exchange decisions the job seed
-    dc = DeviceChains(jt, C, init, priors, seed=20260927, device=dev.index, dist=dist if world > 1 else None, **kw)
-    import torch
+    dc = DeviceChains(jt, C, init, priors, seed=20260927, device=dev.index, dist=dist if world > 1 else None,
+                      spec_depth=args.spec_depth or None, **kw)
+
     def fence():
         eng.synchronize(); torch.cuda.synchronize()
         if world > 1:
@@ -244,30 +256,39 @@ def run_chains(args, eng, rank, world, dist, dev):
     eng.set_instrumentation(timing=True, counting=False)
     eng.timing_reset()
     fence()
+    launches0 = dc.launches
     t0 = time.perf_counter()
     while dc.iiter < dc.iter_phase2:
         dc.iterate()
     fence()
     elapsed = time.perf_counter() - t0
     ncalls, tot_ms, fam_ms = eng.timing_collect()
+    eng.set_instrumentation(timing=False, counting=False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    if rank == 0:
-        st = dc.state_host()
-        out = {"metric": "forward-model+logL evals/sec (one per chain and iteration of device-resident transdimensional chains)",
-               "value": world * C * args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": {"c4": "BASELINE configs[3]: independent chains sharded per GPU, joint Rayleigh+Love+P-RF, up to 20 layers",
-                                       "c5": "BASELINE configs[4]: parallel tempering, one temperature of an 8-rung ladder per rank, exchange "
-                                             "every 100 iterations, joint Rayleigh+Love+P-RF, up to 20 layers"}[args.workload],
-                          "chains_per_gpu": C, "mean_layers_at_end": float(st["n"].mean()), "accepted_swaps": int(dc.nswaps),
-                          "parallelism": "chains sharded per GPU; c5: one small all-gather per exchange"},
-               "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
-               "median_logL": float(np.median(st["like"]))}
-        print(json.dumps(out))
+    nswaps = int(dc.nswaps)        # (collective-free: the swap decisions are identical on every rank)
+    if rank != 0:
+        return None
+    st = dc.state_host()
+    launches = dc.launches - launches0
+    return {"metric": "forward-model+logL evals/sec consumed by the chains = chain-iterations/s (device-resident transdimensional chains)",
+            "value": world * C * steps / elapsed, "unit": "chain-iterations/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": {"c4": "BASELINE configs[3]: independent chains sharded per GPU, joint Rayleigh+Love+P-RF, up to 20 layers",
+                                    "c5": "BASELINE configs[4]: parallel tempering, one temperature of an 8-rung ladder per rank, exchange "
+                                          "every 100 iterations, joint Rayleigh+Love+P-RF, up to 20 layers"}[workload],
+                       "chains_per_gpu": C, "mean_layers_at_end": float(st["n"].mean()), "accepted_swaps": nswaps,
+                       "parallelism": "chains sharded per GPU; c5: one small all-gather per exchange"},
+            "speculation": {"depth": dc.depth, "evaluation_launches": launches, "iterations_per_launch": steps / max(1, launches),
+                            "models_evaluated_per_launch": C * ((1 << dc.depth) - 1), "ms_per_launch": elapsed / max(1, launches) * 1e3,
+                            "note": "the proposals of both outcomes of the next `depth` accept/reject decisions are evaluated in one "
+                                    "launch and the realised path replayed: bit-identical to depth 1 (tests/test_gpu_device_chains.py)"},
+            "reference_iterations_per_s_per_core": 357.0,
+            "kernel_ms_per_launch": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
+            "median_logL": float(np.median(st["like"]))}
 
 
 def parity_check(spec, batch, noise, d_logL, d_misf, d_err, n=64):
@@ -317,16 +338,229 @@ def pmc_summary(workload, B):
     return {}
 
 
+def rf_roofline(eng, spec, d_batch, B, L, dev, reps=20):
+    """The receiver-function kernels ALONE on the workload's own configuration: `reps` bh_rf_batch
+    calls on device pointers, HIP events around the kernel family (engine instrumentation, on the launch stream);
+    flop model = computed bins x (L-1) layer steps x 600 flop-equivalents + 5 N log2 N for the inverse FFT; HBM bytes =
+    the model arrays in, the per-model coefficient record written and read once, nkeep samples out."""
+    import torch
+    from bayhunter_amd import engine as E
+    s = [t for t in spec if t["kind"] == E.TARGET_RF][0]
+    nl, h, vp, vs, rho = d_batch
+    out = torch.zeros((B, s["n"]), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        eng.rf_batch_dev(B, L, nl.data_ptr(), h.data_ptr(), vp.data_ptr(), vs.data_ptr(), rho.data_ptr(), B, 1,
+                         s["p"], s["gauss"], s["nsamp"], s["fsamp"], s["tshift"], s["waveno"], s["n"], out.data_ptr(), stream=stream)
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    eng.set_instrumentation(timing=True, counting=False)
+    eng.timing_reset()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    ncalls, tot_ms, fam = eng.timing_collect()
+    eng.set_instrumentation(timing=False, counting=False)
+    ms = fam["rf"] / max(1, ncalls)
+    nsamp, half = s["nsamp"], s["nsamp"] // 2
+    dw = 2.0 * np.pi * s["fsamp"] / nsamp
+    jc = np.floor(RF_CUT_WA * s["gauss"] / dw) + 1.0                 # csrc/rf_kernel.hip: bh_launch_rf
+    bins = half + 1 if (os.environ.get("BH_RF_NO_CUT") or not jc < half) else int(jc)
+    flop = B * (bins * (L - 1) * RF_FLOP_PER_LAYER_STEP + 5.0 * nsamp * np.log2(nsamp))
+    rec = 24 + 40 * L + 2                                            # doubles per coefficient record (rf_kernel.hip: rec_doubles)
+    nbytes = B * (4 * L * 8 + 4 + 2 * rec * 8 + s["n"] * 8)
+    tf = flop / (ms * 1e-3) / 1e12
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    pmc = pmc_summary("rf_c3", B)
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": pmc.get("hbm_bytes_per_launch"), "traffic_unit": "bytes per call (coefficient + synthesis kernel)",
+            "traffic_source": pmc.get("source"),
+            "kernel": "rf_coef_layers_kernel + rf_synth_kernel, alone (no dispersion kernel beside them)", "kernel_ms_per_launch": ms,
+            "algorithmic_bytes_per_launch": nbytes,
+            "config": {"B": B, "layers": L, "nsamp": nsamp, "gauss": s["gauss"], "fsamp": s["fsamp"], "nkeep": s["n"],
+                       "bins_total": half + 1, "bins_computed": bins},
+            "binding": {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (flop-equivalents)",
+                        "frac": tf / FP64_VALU_PEAK_TF, "flop_equivalents_per_layer_step": RF_FLOP_PER_LAYER_STEP,
+                        "valu_busy": pmc.get("valu_busy"),
+                        "note": "computed bins only (the bins the Gauss low-pass puts below 1e-30 are not computed, rf_kernel.hip)"},
+            "rf_per_s": B / (ms * 1e-3)}
+
+
+def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True):
+    """One evaluate workload (c2 / c3 / c2g / c3g): untimed clock warm-up, `--warmup` steps, then EXACTLY `--steps`
+    steps between barrier + synchronize on both sides, max over ranks.  Returns the result block on rank 0."""
+    import torch
+    from bayhunter_amd import engine as E
+    B, L = args.batch, args.layers
+    spec, batches, noise, truth, nrs = build_workload(workload, B, L, seed=20260927 + 1000 * rank)
+    observed_data(eng, spec, truth, nrs)
+    eng.set_targets(spec)
+    eng._owner = None
+    nt = len(spec)
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_batches = [tuple(to_dev(a) for a in b) for b in batches]        # (nlay, h, vp, vs, rho) in HBM
+    d_noise = to_dev(noise)
+    d_logL = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_misf = torch.zeros((B, nt + 1), dtype=torch.float64, device=dev)
+    d_err = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        nl, h, vp, vs, rho = d_batches[i % NPOOL]
+        eng.evaluate_batch_dev(B, L, nl.data_ptr(), h.data_ptr(), vp.data_ptr(), vs.data_ptr(), rho.data_ptr(),
+                               B, 1, d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(),
+                               stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # Clock warm-up (VERDICT r02 #9): an idle GPU ramps its clock over the first launches (4.09 -> 3.60 ms over six
+    # steps in the round-2 trace), longer than --warmup: ~CLOCK_WARMUP_MS of the same step, untimed, before the
+    # warm-up steps.  Not part of K or W.
+    eng.set_instrumentation(timing=False, counting=False)
+    t0 = time.perf_counter()
+    n_clock = 0
+    while (time.perf_counter() - t0) * 1e3 < CLOCK_WARMUP_MS or n_clock < 4:
+        step(n_clock)
+        n_clock += 1
+        if n_clock % 4 == 0:
+            torch.cuda.synchronize()
+    fence()
+    eng.set_instrumentation(timing=False, counting=True)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    counters = eng.debug_counters() if args.warmup > 0 else None   # evaluations / layer steps of one step (last warm-up)
+    eng.set_instrumentation(timing=True, counting=False)
+    eng.timing_reset()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    fence()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        evs[i + 1].record()                # (the kernels are launched on torch's current stream: these events see them)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ncalls, tot_ms, fam_ms = eng.timing_collect()
+    eng.set_instrumentation(timing=False, counting=False)
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    n_failed = int((d_err != 0).sum().item())
+    finite = bool(torch.isfinite(d_logL).all().item())
+    rank_ms = [elapsed / args.steps * 1e3]
+    if world > 1:
+        tall = torch.zeros(world, dtype=torch.float64, device=dev)
+        tall[rank] = elapsed
+        dist.all_reduce(tall, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) / args.steps * 1e3 for v in tall.tolist()]
+        elapsed = float(tall.max().item())
+    if rank != 0:
+        return None
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    # dominant kernel: the dispersion kernel (all dispersion targets of a step in one launch);
+    # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model and target (SURVEY.md 8(d))
+    K = spec[0]["n"]
+    nswd = sum(1 for s in spec if s["kind"] == E.TARGET_SWD)
+    bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
+    swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
+    achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
+    pmc = pmc_summary(workload, B)
+    # measured HBM bytes per launch (PMC pass of tools/profile_round.sh, committed summary); null without one
+    traffic = pmc.get("hbm_bytes_per_launch")
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
+            "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
+            "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
+                    "(SURVEY.md 8(d)): see binding"}
+    if counters is not None:
+        # flop model of SURVEY.md 8(d): layer-propagator steps, counted in the kernel PER WAVE TYPE, x flop-equivalents
+        ev_r, ev_l, lps_r, lps_l = counters[8], counters[9], counters[10], counters[11]
+        flop = lps_r * FLOP_PER_LPS[2] + lps_l * FLOP_PER_LPS[1]
+        tf = flop / (swd_ms_per_launch * 1e-3) / 1e12
+        roof["binding"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (flop-equivalents)",
+                           "frac": tf / FP64_VALU_PEAK_TF,
+                           "secular_evals_per_step": {"rayleigh": ev_r, "love": ev_l},
+                           "layer_steps_per_step": {"rayleigh": lps_r, "love": lps_l},
+                           "flop_equivalents_per_layer_step": {"rayleigh": FLOP_PER_LPS[2], "love": FLOP_PER_LPS[1]},
+                           "valu_busy": pmc.get("valu_busy"), "active_lane_frac": pmc.get("active_lane_frac"),
+                           "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
+                           "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (kernel time x 1024 SIMDs x clock), active_lane_frac = "
+                                   "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): separate rocprofv3 --pmc pass "
+                                   "(profiles/pmc_summary.json); null without one"}
+    out = {
+        "metric": "forward-model+logL evals/sec (batched 10-layer models)",
+        "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic" if not dryrun else "synthetic (DRY RUN: all ranks on one GPU, gloo)",
+        "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
+                                "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF",
+                                "c2g": "joint Rayleigh+Love GROUP dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
+                                "c3g": "c3 with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF"}[workload],
+                   "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
+                   "parallelism": "models sharded one batch per GPU, no data-path collective"},
+        "ms_per_step_stats": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max()),
+                              "source": "HIP events on the launch stream around each of the K timed steps (rank 0)"},
+        "clock_warmup": {"ms": CLOCK_WARMUP_MS, "steps": n_clock, "note": "untimed launches of the same step before the --warmup steps"},
+        "roofline": roof,
+        "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
+        "gpu_ms_per_step": tot_ms / max(1, ncalls),
+        "failed_models_last_step": n_failed, "logL_finite": finite,
+    }
+    if world > 1:
+        out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+    if not args.no_parity:
+        try:
+            out["parity_check"] = parity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_logL, d_misf, d_err)
+        except Exception as ex:
+            out["parity_check"] = {"n": 0, "error": repr(ex)}
+    if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline:
+        try:
+            out["rf_roofline"] = rf_roofline(eng, spec, d_batches[0], B, L, dev)
+        except Exception as ex:
+            out["rf_roofline"] = {"error": repr(ex)}
+    if with_cpu and not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
+        try:
+            out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, workload)
+        except Exception as ex:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (ex,)}
+        try:   # the reference's own compiled code, where oracle/_ref was built (it travels with the repo)
+            from oracle import refshim
+            if refshim.available() and workload in ("c2", "c3", "c2g"):
+                # north_star: "next to the reference CPU Fortran path timed on the same box's host cores":
+                # the reference's own compiled code is the baseline, the port is kept beside it
+                ref = cpu_baseline_reference(spec, batches[0], noise, workload)
+                out["cpu_baseline_port"] = out["cpu_baseline"]
+                out["cpu_baseline"] = ref
+        except Exception as ex:
+            out["cpu_baseline_reference_error"] = repr(ex)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c2g", "c3g", "c4", "c5"])
+    ap.add_argument("--workload", default="all", choices=["all", "c2", "c3", "c2g", "c3g", "c4", "c5"],
+                    help="all (default): the c2 line (headline) carrying c3, c4 and c5 blocks; or one workload")
     ap.add_argument("--chains", type=int, default=0, help="c4/c5: chains per GPU (default 8 / 64)")
+    ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
+                    "--workload c4/c5, 600 inside --workload all)")
+    ap.add_argument("--spec-depth", type=int, default=0, help="c4/c5: iterations per evaluation launch (0 = automatic)")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rf-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last step (after the timed region)")
     args = ap.parse_args()
 
@@ -356,141 +590,46 @@ def main():
     if dryrun:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dryrun:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=dev)
+        # first contact with the collective library, before anything is timed: every rank contributes 1
+        one = torch.ones(1, dtype=torch.float64, device="cpu" if dryrun else dev)
+        dist.all_reduce(one)
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(one.item()),
+                "devices": torch.cuda.device_count()}
 
     from bayhunter_amd import engine as E
     eng = E.Engine(local_rank)
+    out = None
     if args.workload in ("c4", "c5"):
-        run_chains(args, eng, rank, world, dist, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    B, L = args.batch, args.layers
-    spec, batches, noise, truth, nrs = build_workload(args.workload, B, L, seed=20260927 + 1000 * rank)
-    observed_data(eng, spec, truth, nrs)
-    eng.set_targets(spec)
-    nt = len(spec)
-
-    def to_dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_batches = [tuple(to_dev(a) for a in b) for b in batches]        # (nlay, h, vp, vs, rho) in HBM
-    d_noise = to_dev(noise)
-    d_logL = torch.zeros(B, dtype=torch.float64, device=dev)
-    d_misf = torch.zeros((B, nt + 1), dtype=torch.float64, device=dev)
-    d_err = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(i):
-        nl, h, vp, vs, rho = d_batches[i % NPOOL]
-        eng.evaluate_batch_dev(B, L, nl.data_ptr(), h.data_ptr(), vp.data_ptr(), vs.data_ptr(), rho.data_ptr(),
-                               B, 1, d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(),
-                               stream=stream)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    eng.set_instrumentation(timing=False, counting=True)
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    counters = eng.debug_counters() if args.warmup > 0 else None   # evaluations / layer steps of one step (last warm-up)
-    eng.set_instrumentation(timing=True, counting=False)
-    eng.timing_reset()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    ncalls, tot_ms, fam_ms = eng.timing_collect()
-    n_failed = int((d_err != 0).sum().item())
-    finite = bool(torch.isfinite(d_logL).all().item())
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        # dominant kernel: the dispersion kernel (all dispersion targets of a step in one launch);
-        # algorithmic bytes per launch = (4*L*8 in + K*8 + 4 out) per model and target
-        K = spec[0]["n"]
-        nswd = sum(1 for s in spec if s["kind"] == E.TARGET_SWD)
-        bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
-        swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
-        achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
-        pmc = pmc_summary(args.workload, B)
-        # measured HBM bytes per launch (PMC pass of tools/profile_round.sh, committed summary); null without one
-        traffic = pmc.get("hbm_bytes_per_launch")
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
-                "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
-                "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
-                        "(SURVEY.md 8(d)): see binding"}
-        if counters is not None:
-            # flop model of SURVEY.md 8(d): layer-propagator steps, counted in the kernel PER WAVE TYPE, x flop-equivalents
-            ev_r, ev_l, lps_r, lps_l = counters[8], counters[9], counters[10], counters[11]
-            flop = lps_r * FLOP_PER_LPS[2] + lps_l * FLOP_PER_LPS[1]
-            tf = flop / (swd_ms_per_launch * 1e-3) / 1e12
-            roof["binding"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (flop-equivalents)",
-                               "frac": tf / FP64_VALU_PEAK_TF,
-                               "secular_evals_per_step": {"rayleigh": ev_r, "love": ev_l},
-                               "layer_steps_per_step": {"rayleigh": lps_r, "love": lps_l},
-                               "flop_equivalents_per_layer_step": {"rayleigh": FLOP_PER_LPS[2], "love": FLOP_PER_LPS[1]},
-                               "valu_busy": pmc.get("valu_busy"), "active_lane_frac": pmc.get("active_lane_frac"),
-                               "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
-                               "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 cycles / (kernel time x 1024 SIMDs x clock), active_lane_frac = "
-                                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): separate rocprofv3 --pmc pass "
-                                       "(profiles/pmc_summary.json); null without one"}
-        out = {
-            "metric": "forward-model+logL evals/sec (batched 10-layer models)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" if not dryrun else "synthetic (DRY RUN: all ranks on one GPU, gloo)",
-            "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
-                                    "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF",
-                                    "c2g": "joint Rayleigh+Love GROUP dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
-                                    "c3g": "c3 with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF"}[args.workload],
-                       "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
-                       "parallelism": "models sharded one batch per GPU, no data-path collective"},
-            "roofline": roof,
-            "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
-            "gpu_ms_per_step": tot_ms / max(1, ncalls),
-            "failed_models_last_step": n_failed, "logL_finite": finite,
-        }
-        if not args.no_parity:
+        out = run_chains(args, eng, rank, world, dist, dev, args.workload, args.chain_steps or args.steps, args.warmup)
+    elif args.workload != "all":
+        out = run_eval(args, eng, rank, world, dist, dev, args.workload, dryrun)
+    else:
+        # the headline line (c2, the configuration the metric is quoted on) carrying the other BASELINE configs as blocks:
+        # c3 = configs[2] (same --steps / --warmup, its own timed region), c4 / c5 = configs[3] / [4] per-GPU shares
+        out = run_eval(args, eng, rank, world, dist, dev, "c2", dryrun)
+        blocks = {}
+        blocks["c3"] = run_eval(args, eng, rank, world, dist, dev, "c3", dryrun)
+        csteps = args.chain_steps or 600
+        for w in ("c4", "c5"):
             try:
-                out["parity_check"] = parity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_logL, d_misf, d_err)
-            except Exception as ex:
-                out["parity_check"] = {"n": 0, "error": repr(ex)}
-        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N = 1 only
-            try:
-                out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, args.workload)
-            except Exception as ex:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (ex,)}
-            try:   # the reference's own compiled code, where oracle/_ref was built (it travels with the repo)
-                from oracle import refshim
-                if refshim.available() and args.workload in ("c2", "c3", "c2g"):
-                    # north_star: "next to the reference CPU Fortran path timed on the same box's host cores":
-                    # the reference's own compiled code is the baseline, the port is kept beside it
-                    ref = cpu_baseline_reference(spec, batches[0], noise, args.workload)
-                    out["cpu_baseline_port"] = out["cpu_baseline"]
-                    out["cpu_baseline"] = ref
-            except Exception as ex:
-                out["cpu_baseline_reference_error"] = repr(ex)
+                blocks[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
+            except Exception as ex:          # the chain blocks must never take the headline number down with them
+                blocks[w] = {"error": repr(ex)}
+        if rank == 0:
+            c3 = blocks["c3"]
+            c3["ratio_to_c2_ms_per_step"] = c3["ms_per_step"] / out["ms_per_step"]
+            out.update(blocks)
+    if rank == 0 and out is not None:
+        if comm is not None:
+            out["collective_check"] = comm
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 2
+#define BH_ABI_VERSION 3
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -200,6 +200,7 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
  * NULL the six draws of an iteration are read from it instead ([6][C]: u_move, u_index, u_z,
  * u_accept, u_noise in [0,1) and one standard normal) -- used by the tests. */
 #define BH_CHAIN_MAXLAYERS 32 /* upper bound of cfg.maxlayers (nuclei per chain) */
+#define BH_CHAIN_MAXDEPTH 7   /* iterations per speculative window (2^7 - 1 = 127 proposals per chain) */
 
 typedef struct bh_chain_config {
     int32_t nt;                   /* targets (noise has 2*nt entries: corr, sigma per target) */
@@ -247,6 +248,22 @@ int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_st
 /* logL [C], misfits [C][nt+1]: outputs of bh_evaluate_batch for this iteration (device). */
 int bh_chain_accept(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
                     const double *logL, const double *misfits);
+
+/* Speculative window: `depth` (1..BH_CHAIN_MAXDEPTH) iterations iiter .. iiter+depth-1 of every chain per evaluation
+ * launch, with exactly the results of `depth` propose/evaluate/accept rounds (SingleChain.py:511-589 is a sequential
+ * loop; its draws here are a pure function of (chain, iteration), so the proposals of both outcomes of every
+ * decision can be written down in advance).  The proposal members of `state` (pn, move, valid, pvs, pz, pvpvs,
+ * pnoise, dvs2, lay_*) then hold N = 2^depth - 1 proposals per chain in heap order -- node 0 = the proposal of
+ * iteration iiter, nodes 2j+1 / 2j+2 = the proposals of the next iteration after node j was rejected / accepted --
+ * node j of chain c in column j*C + c of arrays with `ld` >= N*C columns ("[k][ld]" instead of "[k][C]"; pnoise
+ * [ld][2nt]).  One window = bh_chain_propose_window -> bh_evaluate_batch(B = N*C, stride_l = ld, stride_b = 1,
+ * noise = pnoise) -> bh_chain_accept_window(logL [N*C], misfits [N*C][nt+1]), which walks the realised path.
+ * An iteration with iiter % 1000 == 0 (proposal-width adaptation) must be the last of its window (BH_EINVAL
+ * otherwise); state->inject, if used, holds [depth][6][C].  depth = 1, ld = C is bh_chain_propose / _accept. */
+int bh_chain_propose_window(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
+                            int depth, ptrdiff_t ld);
+int bh_chain_accept_window(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
+                           int depth, ptrdiff_t ld, const double *logL, const double *misfits);
 
 /* ---- diagnostics -------------------------------------------------------------------------
  * Evaluate one elementary function on the device for n float64 inputs (host pointers):

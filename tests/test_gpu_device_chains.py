@@ -55,29 +55,36 @@ def compare(dc, hb, exact):
         assert np.array_equal(st["proposed"][:, c], ch.proposed) and np.array_equal(st["accepted"][:, c], ch.accepted)
 
 
-@pytest.mark.parametrize("name", ["exp", "gauss"])
-def test_injected_draws_same_trajectory(name):
+@pytest.mark.parametrize("name,depth", [("exp", 1), ("gauss", 1), ("exp", 3), ("gauss", 4)])
+def test_injected_draws_same_trajectory(name, depth):
+    """depth > 1: speculative windows (the proposals of both outcomes of the next `depth` decisions, one evaluation
+    launch, the realised path replayed) against the host twin iterating one step at a time."""
     g = golden("chain_golden.npz")
     su = SETUPS[name]
     init = dict(su["init"], iter_burnin=1100, iter_main=150, lvz=0.1, hvz=0.4)
     priors = dict(su["priors"], mantle=(4.3, 1.8))
     C = 48
     targets = make_targets(g)
-    dc = DeviceChains(targets, C, init, priors, seed=7, inject=True)
+    dc = DeviceChains(targets, C, init, priors, seed=7, inject=True, spec_depth=depth)
     hb = host_twin(dc, targets, init, priors)
     rs = np.random.RandomState(99)
     it = 0
     while dc.iiter < dc.iter_phase2:
-        d = np.vstack((rs.uniform(size=(5, C)), rs.normal(size=(1, C))))
+        w = dc.window()
+        d = np.zeros((depth, 6, C))
+        for k in range(w):
+            d[k] = np.vstack((rs.uniform(size=(5, C)), rs.normal(size=(1, C))))
         dc.t["inject"].copy_(dc.torch.from_numpy(d))
         dc.torch.cuda.synchronize()
-        for c, ch in enumerate(hb.chains):
-            ch.rstate.set(d[:, c])
-        dc.iterate()
-        hb.iterate()
+        assert dc.iterate() == w
+        for k in range(w):
+            for c, ch in enumerate(hb.chains):
+                ch.rstate.set(d[k][:, c])
+            hb.iterate()
         it += 1
         if it % 50 == 0 or dc.iiter in (-999, 1):      # incl. right after the width adaptations
             compare(dc, hb, exact=True)
+    assert dc.launches == it and (depth == 1 or it < 1250 / depth + 8)
     compare(dc, hb, exact=True)
     st = dc.state_host()
     assert (st["accepted"].sum(axis=0) > 50).all() and (st["n"] != st["n"][0]).any()   # chains really moved / differ
@@ -94,12 +101,14 @@ def test_device_philox_same_trajectory_and_reproducible():
     dc = DeviceChains(targets, C, init, su["priors"], seed=seed)
     hb = host_twin(dc, targets, init, su["priors"])
     while dc.iiter < dc.iter_phase2:
-        d = draws(seed, C, dc.iiter)
-        for c, ch in enumerate(hb.chains):
-            ch.rstate.set(d[:, c])
+        before = dc.iiter
+        for k in range(dc.window()):                    # (the default depth for 40 chains is 4 iterations per launch)
+            d = draws(seed, C, dc.iiter + k)
+            for c, ch in enumerate(hb.chains):
+                ch.rstate.set(d[:, c])
+            hb.iterate()
         dc.iterate()
-        hb.iterate()
-        if dc.iiter % 60 == 0:
+        if dc.iiter // 60 != before // 60:
             compare(dc, hb, exact=False)
     compare(dc, hb, exact=False)
     a = dc.state_host()
@@ -110,6 +119,55 @@ def test_device_philox_same_trajectory_and_reproducible():
         assert np.array_equal(a[k], b[k]), k
     dc3 = DeviceChains(make_targets(g), C, init, su["priors"], seed=seed + 1).run()
     assert not np.array_equal(a["like"], dc3.state_host()["like"])
+
+
+@pytest.mark.parametrize("name", ["exp", "gauss"])
+def test_speculative_windows_walk_the_sequential_trajectory(name):
+    """d iterations per evaluation launch must be the d = 1 run with the same seed, bit for bit --
+    states, counters, adapted widths, snapshots -- for the exp and the Gauss set-up, across the adaptation
+    iterations (-1000, 0), with 8 chains (BASELINE configs[3] per-GPU share) at several depths incl. the default."""
+    g = golden("chain_golden.npz")
+    su = SETUPS[name]
+    init = dict(su["init"], iter_burnin=1150, iter_main=250, maxmodels=25)
+    C = 8
+    keys = ("n", "vs", "z", "like", "noise", "vpvs", "misfits", "propdist", "proposed", "accepted", "naccepted")
+
+    def run(depth):
+        dc = DeviceChains(make_targets(g), C, init, su["priors"], seed=20260928, spec_depth=depth).run()
+        return dc, dc.state_host(), dc.samples("p1"), dc.samples("p2")
+
+    d1, s1, p1a, p2a = run(1)
+    assert d1.launches == 1400
+    for depth in (2, 5, None):
+        dk, sk, p1b, p2b = run(depth)
+        assert dk.iiter == d1.iiter and dk.launches < 1400 / min(dk.depth, 4) * 1.05 + 10   # (+ windows cut at snapshots / adaptations)
+        for k in keys:
+            assert np.array_equal(s1[k], sk[k]), (depth, k)
+        for a, b in ((p1a, p1b), (p2a, p2b)):
+            for k in a:
+                assert np.array_equal(a[k], b[k], equal_nan=True), (depth, k)
+    assert dk.depth == 7 and (s1["accepted"].sum(axis=0) > 100).all()
+
+
+def test_speculative_windows_with_tempering_stop_at_the_exchanges():
+    """Windows end at temperature exchanges: a tempered run with 5 iterations per launch equals the
+    one-iteration-per-launch run (betas, states, accepted swaps)."""
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=280, iter_main=60, maxmodels=10)
+    nl, nr = 4, 4
+    C = nl * nr
+    ladder = np.repeat(np.arange(nl), nr)
+    betas = np.tile(1.0 / np.geomspace(1.0, 20.0, nr), nl)
+    out = []
+    for depth in (1, 5):
+        dc = DeviceChains(make_targets(g), C, init, su["priors"], seed=5, betas=betas, ladder=ladder, swap_every=7,
+                          spec_depth=depth).run()
+        out.append((dc.state_host(), dc.nswaps, dc.sweep, dc.launches))
+    (a, na, sa, la), (b, nb, sb, lb) = out
+    assert na == nb and sa == sb == 340 // 7 and na > 3 and lb < la / 2
+    for k in ("n", "vs", "z", "like", "noise", "vpvs", "beta", "propdist", "accepted"):
+        assert np.array_equal(a[k], b[k]), k
 
 
 def test_many_chains_converge_and_save(tmp_path):

@@ -57,6 +57,35 @@ def test_quality_factors_and_nsv(engine, oracle):
         assert np.max(np.abs(rf[b] - o)) <= TOL * np.abs(o).max()
 
 
+def test_spectral_cutoff_changes_nothing_and_nonfinite_models_stay_nonfinite(engine, oracle, monkeypatch):
+    """bins the Gauss low-pass puts below 1e-30 are not computed (rf_kernel.hip).  (1) With and without the
+    cut-off (BH_RF_NO_CUT) the traces agree to 1e-13 of the peak on random models, for the c3 filter (a third of the bins
+    cut) and the tutorial's (three quarters).  (2) The reference computes every bin, so a model whose coefficients are
+    not finite gives an all-NaN trace there; the cut-off must not turn it into a finite one: same NaN rows as the oracle."""
+    rs = np.random.RandomState(77)
+    nlay, h, vp, vs, rho = synth_models(rs, 64, 12, lvz_frac=0.3, ragged=True)
+    for gauss, nsamp, fsamp, nkeep in ((2.5, 2048, 20.0, 1024), (1.0, 512, 5.0, 201)):
+        monkeypatch.delenv("BH_RF_NO_CUT", raising=False)
+        cut = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, gauss, nsamp, fsamp, 5.0, 0, nkeep)
+        monkeypatch.setenv("BH_RF_NO_CUT", "1")
+        full = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, gauss, nsamp, fsamp, 5.0, 0, nkeep)
+        monkeypatch.delenv("BH_RF_NO_CUT")
+        assert np.isfinite(full).all()
+        assert np.max(np.abs(cut - full) / np.abs(full).max(axis=1, keepdims=True)) <= 1e-13
+    # broken models: an infinite velocity, a NaN density, a zero S velocity in the crust
+    nlay, h, vp, vs, rho = synth_models(rs, 8, 6)
+    vp[2, 1] = np.inf
+    rho[3, 3] = np.nan
+    vs[1, 5] = 0.0
+    rf = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, 2.5, 2048, 20.0, 5.0, 0, 1024)
+    orf = oracle.rf_batch(nlay, h.T, vp.T, vs.T, rho.T, 6.4, 2.5, 2048, 20.0, 5.0, 0, 1024)
+    bad_o = ~np.isfinite(orf).all(axis=1)
+    bad_e = ~np.isfinite(rf).all(axis=1)
+    assert bad_o[[1, 3]].all() and np.array_equal(bad_e, bad_o), (bad_e, bad_o)
+    ok = ~bad_o
+    assert np.max(np.abs(rf[ok] - orf[ok]) / np.abs(orf[ok]).max(axis=1, keepdims=True)) <= TOL
+
+
 def test_bad_arguments_fail_loudly(engine):
     from bayhunter_amd.engine import EngineError
     nlay, h, vp, vs, rho = synth_models(np.random.RandomState(1), 2, 3)
