@@ -99,12 +99,20 @@ struct SwdMultiArgs {
     unsigned long long *neval;
     unsigned *board;  // optional: progress board of the group kernel, 2 words per physical SIMD (BH_BOARD_WORDS), see the kernel
     unsigned stamp;   // launch stamp (16 bits) that marks this launch's entries of the board
+    unsigned *started; // optional: every workgroup adds 1 when it starts (cumulative over launches): a second stream waits
+                       // for "all workgroups of this launch are resident" before it dispatches work beside them
+    int prio_low;      // s_setprio level of a wavefront's unfavoured phase (0; 1 when receiver-function wavefronts at 0 run beside it)
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
 double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
-int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream);
+struct SwdLaunchInfo {
+    unsigned workgroups; // of the launch (what SwdMultiArgs::started is advanced by)
+    long waves;          // wavefronts that do work
+    size_t lds;          // bytes per workgroup
+};
+int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2);
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,
@@ -123,9 +131,14 @@ struct RfKernelArgs {
     double *coef;  // workspace [B][bh_rf_coef_doubles(Lmax)]
     double *rf;    // [B][ldr]
     int ldr;
+    int lds_min;   // lower bound of the synthesis kernel's LDS request in bytes (0 = what the trace needs), see bh_engine.hip
+    int beside;    // > 0: the 96-register build that runs beside two dispersion wavefronts per SIMD, at issue priority beside - 1
 };
 size_t bh_rf_coef_doubles(int Lmax);
-void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream);
+// LDS of one workgroup of the synthesis kernel for traces of nsamp samples; a CU has 160 KB, one workgroup may use all
+constexpr size_t BH_RF_MAX_LDS = 160 * 1024;
+size_t bh_rf_lds_bytes(int nsamp);
+int bh_launch_rf(const RfKernelArgs &a, hipStream_t stream); // 0, or -1 when the trace does not fit a workgroup's LDS
 
 struct LikeTargetDev {
     int law, n, off; // off: column offset of this target's samples inside a ymod row

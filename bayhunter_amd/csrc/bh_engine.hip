@@ -42,6 +42,17 @@ struct bh_engine {
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     int look_r = 0, look_l = 0;            // BH_SWD_LOOK_R / BH_SWD_LOOK_L env (experiment switches): trials per round by wave type
     bool overlap_rf = true;                // BH_NO_OVERLAP env turns it off (A/B testing)
+    int rf_lds_beside_swd = 40 * 1024;     // BH_RF_LDS_BESIDE env (bytes; experiment switch), see launch_rf
+    // co-resident receiver function (see bh_evaluate_batch): the dispersion kernel counts its started workgroups here
+    unsigned *started = nullptr;           // device word (signal memory where available), cumulative over launches
+    unsigned started_expected = 0;         // value after every launch enqueued so far has started
+    bool rf_beside = false;                // BH_RF_BESIDE env turns the co-resident mode on (measured slower, see bh_evaluate_batch)
+    int rf_beside_prio = 0;                // BH_RF_BESIDE_PRIO env: issue priority (0..3) of the co-resident RF wavefronts
+    int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
+    SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
+    int swd_prio_low_now = 0;              // per call: what the next dispersion launch gets
+    int swd_wpb_now = 2;                   // per call: wavefronts per workgroup of the next dispersion launch
+    bool rf_coresident_now = false;        // per call: RF kernels run in the co-resident mode
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
@@ -387,9 +398,12 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
         if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
     }
+    a.started = e->started;
+    a.prio_low = e->swd_prio_low_now;
     ev_begin(e, 0, st);
-    const int lrc = bh_launch_swd_group(a, G, st);
+    const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now);
     ev_end(e, 0, st);
+    if (lrc == 0 && e->started) e->started_expected += e->last_swd.workgroups;
     if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
@@ -397,7 +411,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
 
 int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
               ptrdiff_t sb, double p, double gauss, int nsamp, double fsamp, double tshift,
-              double nsv, int waveno, int nkeep, double *rf, int ldr)
+              double nsv, int waveno, int nkeep, double *rf, int ldr, bool beside_swd = false)
 {
     if (B == 0) return BH_OK;
     int rc;
@@ -408,9 +422,17 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     a.sl = sl; a.sb = sb;
     a.p_s_per_deg = p; a.gauss = gauss; a.fsamp = fsamp; a.tshift = tshift; a.nsv = nsv;
     a.coef = (double *)e->coef.p; a.rf = rf; a.ldr = ldr;
+    // Beside a dispersion launch (fused call, second stream): the synthesis workgroups must not take wave slots before
+    // the dispersion kernel's wavefronts are resident -- that kernel counts on all of them being co-resident (one round
+    // of wavefronts; displaced ones wait for a whole lifetime: 3.6 -> 7 ms measured when the 17.7 KB workgroups of
+    // round 3 slipped into the 18 KB of LDS the dispersion wavefronts leave free on a CU).  Asking for more LDS than
+    // that remainder keeps them out of CUs whose dispersion wavefronts are still running, as in round 2 (40 KB).
+    a.lds_min = (beside_swd && !e->rf_coresident_now) ? e->rf_lds_beside_swd : 0;
+    a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
     ev_begin(e, 1, st);
-    bh_launch_rf(a, st);
+    const int lrc = bh_launch_rf(a, st);
     ev_end(e, 1, st);
+    if (lrc != 0) return fail(e, BH_EUNSUPPORTED, "receiver function: nsamp does not fit a workgroup's LDS");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
 }
@@ -440,8 +462,12 @@ int prepare_like_target(bh_engine *e, hipStream_t st, int B, int ldy, const doub
 
 int rf_args_ok(bh_engine *e, int nsamp, int nkeep, double gauss, double fsamp, int waveno)
 {
-    if (nsamp < 4 || (nsamp & (nsamp - 1)) != 0 || nsamp > 4096)
-        return fail(e, BH_EINVAL, "nsamp must be a power of two in 4..4096");
+    if (nsamp < 4 || (nsamp & (nsamp - 1)) != 0)
+        return fail(e, BH_EINVAL, "nsamp must be a power of two >= 4");
+    // rfmini_modrf.py:62 derives nsamp = 2^ceil(log2(2 ndata)) with no upper bound; here one workgroup holds a
+    // model's half-length complex spectrum in LDS: up to 16384 samples (observed traces of up to 8192 samples)
+    if (bh_rf_lds_bytes(nsamp) > BH_RF_MAX_LDS)
+        return fail(e, BH_EUNSUPPORTED, "nsamp above 16384 is not supported (the spectrum of one model must fit a CU's 160 KB of LDS)");
     if (nkeep < 0 || nkeep > nsamp) return fail(e, BH_EINVAL, "nkeep must be 0..nsamp");
     if (!(gauss > 0.0) || !(fsamp > 0.0)) return fail(e, BH_EINVAL, "gauss and fsamp must be > 0");
     if (waveno != BH_RF_P && waveno != BH_RF_SV) return fail(e, BH_EINVAL, "waveno must be 0 (P) or 1 (SV)");
@@ -475,6 +501,23 @@ int bh_engine_create(int device, bh_engine **out)
         return BH_EHIP;
     }
     if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
+    if (const char *g = std::getenv("BH_RF_LDS_BESIDE")) e->rf_lds_beside_swd = std::atoi(g);
+    if (std::getenv("BH_RF_BESIDE")) e->rf_beside = true;
+    if (const char *g = std::getenv("BH_RF_BESIDE_PRIO")) e->rf_beside_prio = std::atoi(g) & 3;
+    if (const char *g = std::getenv("BH_SWD_PRIO_LOW")) e->swd_prio_low = std::atoi(g) != 0 ? 1 : 0;
+    {   // the counter the dispersion kernel's workgroups bump at start; hipStreamWaitValue32 polls it from the RF stream
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
+        if (std::getenv("BH_NO_STARTED")) can = 0; // experiment switch
+        // plain device memory: the wait packet polls it just as well, and atomics on signal memory
+        // (hipMallocSignalMemory) cost the dispersion kernel 1 ms per launch (976 workgroups, one atomic each)
+        if (can && hipMalloc((void **)&e->started, 8) != hipSuccess) e->started = nullptr;
+        if (e->started && hipMemset(e->started, 0, 8) != hipSuccess) {
+            (void)hipFree(e->started);
+            e->started = nullptr;
+        }
+        (void)hipGetLastError();
+    }
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
@@ -530,6 +573,7 @@ void bh_engine_destroy(bh_engine *e)
     for (auto &s : e->evsets)
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
+    if (e->started) (void)hipFree(e->started);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
@@ -859,7 +903,53 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         HIPCHK(e, hipEventRecord(e->ev_fork, st));
         HIPCHK(e, hipStreamWaitEvent(e->aux, e->ev_fork, 0));
     }
-    if ((rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs))) return rc;
+    // Start gate.  The dispersion group kernel counts on ALL its wavefronts being co-resident (one round of wavefronts,
+    // two per SIMD); an RF workgroup that takes a wave slot first displaces a dispersion wavefront for a whole lifetime
+    // (3.6 -> 7 ms when the 17.7 KB workgroups of round 3 slipped into the LDS the dispersion wavefronts leave free), and
+    // even the small coefficient kernel, dispatched while the dispersion kernel's workgroups are being placed, stretched
+    // that kernel's span by 0.3 ms in round 2.  The kernel's workgroups therefore count themselves in `started` as they
+    // begin, and the RF stream waits for the count (hipStreamWaitValue32) before anything of the RF is dispatched:
+    // c3 4.15 -> 4.04 ms, the dispersion kernel's time inside c3 = its time in c2 (3.62 ms).
+    // Co-resident receiver function (BH_RF_BESIDE=1, an experiment that is NOT the default).  The dispersion wavefronts
+    // leave the FP64 pipe idle 38 % of the time, but RF workgroups of the usual build (128 registers) cannot become
+    // resident beside two 208-register wavefronts per SIMD and run in the kernel's tail.  A 96-register build fits
+    // (2 x 208 + 96 = 512; LDS: dispersion workgroups of four wavefronts, two copies of the libm tables per CU instead of
+    // four), one workgroup per CU.  Measured (c3, round 3): such a workgroup -- one wavefront per SIMD, 43 spilled
+    // registers -- advances at a tenth of the RF's full-chip rate whatever its issue priority, 60 % of the RF is
+    // done when the dispersion kernel ends, that kernel is 3 % slower and the rest still runs in the tail with the
+    // slower build: 4.33 ms instead of 4.04.  Kept behind the switch with these numbers; what would make it pay is an
+    // RF recursion that needs half the registers per lane (a frequency spread over two lanes).
+    const bool want_gate = fork && e->started != nullptr;
+    const bool want_beside = want_gate && e->rf_beside;
+    if (e->started != nullptr && e->started_expected > 0x70000000u) { // (the counter is cumulative: rewind it long before it wraps)
+        HIPCHK(e, hipStreamSynchronize(st));
+        HIPCHK(e, hipStreamSynchronize(e->aux));
+        HIPCHK(e, hipMemset(e->started, 0, sizeof(unsigned)));
+        e->started_expected = 0;
+    }
+    e->swd_prio_low_now = want_beside ? e->swd_prio_low : 0;
+    e->swd_wpb_now = want_beside ? 4 : 2;  // (two copies of the libm tables per CU instead of four: LDS room for an RF workgroup)
+    e->last_swd = SwdLaunchInfo{};
+    rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs);
+    e->swd_prio_low_now = 0;
+    e->swd_wpb_now = 2;
+    if (rc) return rc;
+    e->rf_coresident_now = false;
+    if (want_gate && e->last_swd.workgroups > 0) {
+        size_t rf_lds = 0;
+        for (int t = 0; t < nt; ++t)
+            if (e->targets[(size_t)t].d.kind == BH_TARGET_RF) {
+                const size_t l = bh_rf_lds_bytes(e->targets[(size_t)t].d.nsamp);
+                rf_lds = l > rf_lds ? l : rf_lds;
+            }
+        // more than one dispersion wavefront per SIMD (else the usual build finds room by itself), and the LDS fits
+        e->rf_coresident_now = want_beside && e->last_swd.waves > 1024 && 2 * e->last_swd.lds + rf_lds <= BH_RF_MAX_LDS;
+        static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
+        if (dbg)
+            std::fprintf(stderr, "[bh] fused call B=%d: dispersion launch %u workgroups, %ld wavefronts, %zu B LDS per workgroup; RF LDS %zu B; "
+                         "co-resident RF: %d\n", B, e->last_swd.workgroups, e->last_swd.waves, e->last_swd.lds, rf_lds, (int)e->rf_coresident_now);
+        HIPCHK(e, hipStreamWaitValue32(e->aux, e->started, e->started_expected, hipStreamWaitValueGte, 0xffffffffu));
+    }
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];
         const bh_target_desc &d = T.d;
@@ -868,7 +958,7 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
                              (const double *)T.x.p, ymod_d + T.off, ldy, st);
         if (d.kind != BH_TARGET_RF) continue;
         rc = launch_rf(e, rst, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
-                       d.nsv, d.waveno, d.n, ymod_d + T.off, ldy);
+                       d.nsv, d.waveno, d.n, ymod_d + T.off, ldy, fork);
         if (rc) return rc;
     }
     if (fork) {

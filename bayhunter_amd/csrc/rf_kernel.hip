@@ -26,8 +26,8 @@
 #include <cstdlib>
 
 namespace {
-// w / a beyond which the Gauss low-pass exp(-(w/a)^2 / 4) is below 1e-30: 2 sqrt(30 ln 10)
-constexpr double RF_CUT_WA = 16.6226;
+// w / a beyond which the Gauss low-pass exp(-(w/a)^2 / 4) is below RF_CUT = 1e-20: 2 sqrt(20 ln 10)
+constexpr double RF_CUT_WA = 13.5725;
 
 struct cd {
     double re, im;
@@ -67,11 +67,15 @@ __device__ __forceinline__ cd csqrt_d(cd z)
 // instructions of a layer step.  These are the same functions to ~2 ulp for the arguments that occur here
 // (finite, normal range): hardware seed + two Newton steps, Cody-Waite reduction + minimax polynomials
 // (coefficients: fdlibm's __kernel_sin / __kernel_cos).
+// (v_rcp_f64 / v_rsq_f64 are good to ~2^-23 or better; one Newton step squares that: ~1e-14 relative, five orders below
+// the 1e-9 the tests assert; RF_NEWTON2 restores the second step)
 __device__ __forceinline__ double rcp_nr(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(r, fma(-x, r, 1.0), r);
+#ifdef RF_NEWTON2
     r = fma(r, fma(-x, r, 1.0), r);
+#endif
     return r;
 }
 // 1/sqrt(x), x > 0
@@ -80,7 +84,9 @@ __device__ __forceinline__ double rsq_nr(double x)
     double y = __builtin_amdgcn_rsq(x);
     const double hx = 0.5 * x;
     y = fma(y, fma(-hx * y, y, 0.5), y);
+#ifdef RF_NEWTON2
     y = fma(y, fma(-hx * y, y, 0.5), y);
+#endif
     return y;
 }
 // sin and cos of a moderate argument (|x| < 2^20: |k| * 2^-107 of reduction error)
@@ -191,11 +197,13 @@ __device__ __forceinline__ cm2 load_cm2(const double *p)
 {
     return cm2{cd{p[0], p[1]}, cd{p[2], p[3]}, cd{p[4], p[5]}, cd{p[6], p[7]}};
 }
-// 0 for finite entries, NaN as soon as one is NaN or +-inf (x - x is 0 for finite x only)
+// number of entries that are NaN or +-inf (a bit test: under -ffp-contract=fast "x - x" of an expression is not
+// reliably zero -- one copy may be contracted into an fma, the other not)
+__device__ __forceinline__ double nf1(double x) { return __builtin_isfinite(x) ? 0.0 : 1.0; }
 __device__ __forceinline__ double nonfinite(const cm2 &m)
 {
-    return (m.c11.re - m.c11.re) + (m.c11.im - m.c11.im) + (m.c12.re - m.c12.re) + (m.c12.im - m.c12.im) +
-           (m.c21.re - m.c21.re) + (m.c21.im - m.c21.im) + (m.c22.re - m.c22.re) + (m.c22.im - m.c22.im);
+    return nf1(m.c11.re) + nf1(m.c11.im) + nf1(m.c12.re) + nf1(m.c12.im) + nf1(m.c21.re) + nf1(m.c21.im) + nf1(m.c22.re) +
+           nf1(m.c22.im);
 }
 
 // greens.cpp:19-85 (P/SV part)
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
         double *lay = rec + REC_HEAD + 8 * l;
         lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
         lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
-        for (int k = 0; k < 7; ++k) nf += lay[k] - lay[k];
+        for (int k = 0; k < 7; ++k) nf += nf1(lay[k]);
         // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
         const double vv = (A.waveno == 0) ? vp : vs;
         t0 += hh * sqrt(1. / (vv * vv) - p2);
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
         m12 = 2. * p * vstop * vstop / vptop;
         m21 = -2. * p * vstop;
         m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
-        nf += (m11 - m11) + (m12 - m12) + (m21 - m21) + (m22 - m22);
+        nf += nf1(m11) + nf1(m12) + nf1(m21) + nf1(m22);
     }
     // A non-finite coefficient makes every bin of the reference's spectrum non-finite, hence the whole trace (the
     // inverse FFT sums all bins); with the spectral cut-off the bins above it are not formed here, so the record
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         double *lay = rec + REC_HEAD + 8 * l;
         lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
         lay[3] = 1.0 / (M_PI * qp); lay[4] = 1.0 / (2.0 * qp); lay[5] = 1.0 / (M_PI * qs); lay[6] = 1.0 / (2.0 * qs);
-        for (int k = 0; k < 7; ++k) nf += lay[k] - lay[k];
+        for (int k = 0; k < 7; ++k) nf += nf1(lay[k]);
     }
     // direct-wave delay (greens.cpp:510-526); only its NaN-ness can reach the RF
     const double vv = (A.waveno == 0) ? vp : vs;
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
             m12 = 2. * p * vstop * vstop / vptop;
             m21 = -2. * p * vstop;
             m22 = (1. - 2. * vstop * vstop * p * p) / (vstop * bb);
-            nfall += (m11 - m11) + (m12 - m12) + (m21 - m21) + (m22 - m22);
+            nfall += nf1(m11) + nf1(m12) + nf1(m21) + nf1(m22);
         }
         // non-finite coefficients anywhere in the record: the whole trace is non-finite in the reference (see rf_coef_kernel)
         nfall += nonfinite(ru) + nonfinite(hm);
@@ -577,82 +585,166 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
     }
 }
 
-// Spectrum of one model into LDS (bit-reversed, Hermitian-extended), inverse FFT of length N = nsamp in LDS:
-// iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) sum_k X[k] e^{+2 pi i k n / N}.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void rf_synth_kernel(RfKernelArgs A, int logn, int jcut)
+// Spectrum of one model into LDS, then the inverse real FFT there:
+// iftr (greens.cpp:136-158) + ccfork(+1) (fork.cpp:11-60): f[n] = (1/N) Re sum_k X[k] e^{+2 pi i k n / N} with the
+// Hermitian extension X[N-k] = conj(X[k]) of the bins k = 0..N/2 the frequency loop produces.
+// A real trace of N samples is a COMPLEX transform of length M = N/2 (round 3; round 2 ran the full length-N
+// complex transform on the extended spectrum: twice the LDS, twice the butterflies):
+//     Z[k] = (X[k] + conj(X[M-k])) + i w^k (X[k] - conj(X[M-k])),  w = e^{+2 pi i / N},  k = 0..M-1
+//     z[m] = sum_k Z[k] e^{+2 pi i k m / M}        ->  f[2m] = Re z[m] / N,  f[2m+1] = Im z[m] / N
+// (the even samples come from X[k] + X[k+M], the odd ones from (X[k] - X[k+M]) w^k, and X[k+M] = conj(X[M-k]);
+// only the real parts of X[0] and X[N/2] reach a real output).  Pairs (k, M-k) share their work:
+// with E = X[k] + conj(X[M-k]), T = i w^k (X[k] - conj(X[M-k])):  Z[k] = E + T,  Z[M-k] = conj(E - T).
+// The transform is decimation in frequency (natural order in, bit-reversed out), so that the bins go to LDS in
+// natural order and only the nkeep output samples are read through the bit reversal.
+// Twiddles: w^k = TW1[k >> 6] TW0[k & 63] (two small tables instead of N/4 entries: one more complex product per
+// butterfly, 1-3 KB of LDS instead of 8-64 KB).  LDS per workgroup: 8 N + 16 + 1024 + N/8 bytes --
+// 17.7 KB at nsamp = 2048 (round 2: 40 KB), 134 KB at nsamp = 16384, the largest trace one workgroup holds.
+template <bool BESIDE>
+__device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, int jcut)
 {
+    if (BESIDE) { // issue priority of a wavefront that runs beside dispersion wavefronts (those alternate between 3 and 1)
+        if (A.beside == 1) __builtin_amdgcn_s_setprio(0);
+        else if (A.beside == 2) __builtin_amdgcn_s_setprio(1);
+        else if (A.beside == 3) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
     extern __shared__ __align__(16) unsigned char smem[];
-    const int N = A.nsamp, half = N / 2;
-    double2 *x = reinterpret_cast<double2 *>(smem);       // [N]
-    double2 *tw = x + N;                                   // [N/4]  e^{+2 pi i k / N}, k < N/4; e^{i(t + pi/2)} = i e^{it} gives the rest
+    const int N = A.nsamp, M = N / 2;
+    double2 *z = reinterpret_cast<double2 *>(smem);       // [M]
+    double2 *nyq = z + M;                                  // [1]   Re X[N/2]
+    double2 *tw0 = nyq + 1;                                // [64]  w^r
+    double2 *tw1 = tw0 + 64;                               // [max(1, N/128)]  w^(64 q)
     const int ib = blockIdx.x;
     const int tid = threadIdx.x;
     const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
     const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
     const size_t recsz = rec_doubles(A.Lmax);
     const double *rec = A.coef + (size_t)ib * recsz;
-    const int quarter = N / 4;
-    for (int k = tid; k < quarter; k += 256) {
-        double s, c;
-        sincos_cw((2.0 * M_PI / (double)N) * (double)k, &s, &c);
-        tw[k] = make_double2(c, s);
+    const int n1 = (N >= 128) ? N / 128 : 1;
+    for (int k = tid; k < 64 + n1; k += 256) {
+        const int idx = (k < 64) ? k : (k - 64) * 64;
+        double sn, cs;
+        sincos_cw((2.0 * M_PI / (double)N) * (double)idx, &sn, &cs);
+        tw0[k] = make_double2(cs, sn); // (tw1 follows tw0)
     }
-    const int shift = 32 - logn;
-    for (int j = tid; j < half; j += 256) {
-        // bins from jcut on: the Gauss low-pass has them below 1e-30 of the pass band (see bh_launch_rf)
-        const cd s = (j < jcut) ? rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
-        x[(int)(__brev((unsigned)j) >> shift)] = make_double2(s.re, s.im);
-        if (j > 0) x[(int)(__brev((unsigned)(N - j)) >> shift)] = make_double2(s.re, -s.im); // cx[N-j] = conj(cx[j])
+    for (int j = tid; j < M; j += 256) {
+        // bins from jcut on: the Gauss low-pass has them below RF_CUT of the pass band (see bh_launch_rf)
+        cd s = (j < jcut) ? rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
+        if (j == 0) s.im = __builtin_isfinite(s.im) ? 0.0 : s.im; // Re X[0] only (a non-finite bin stays non-finite)
+        z[j] = make_double2(s.re, s.im);
     }
     if (tid == 0) { // the Nyquist bin: one more frequency for one thread, and only when the filter keeps it
-        const cd s = (half < jcut) ? rf_one_frequency(rec, A.Lmax, half, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
-        x[(int)(__brev((unsigned)half) >> shift)] = make_double2(s.re, s.im);
+        const cd s = (M < jcut) ? rf_one_frequency(rec, A.Lmax, M, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
+        nyq[0] = make_double2(s.re, __builtin_isfinite(s.im) ? 0.0 : s.im);
     }
     __syncthreads();
-    for (int s = 0; s < logn; ++s) {
+    auto twiddle = [&](int k) {
+        const double2 a = tw1[k >> 6], b = tw0[k & 63];
+        return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    };
+    for (int k = tid; k <= M / 2; k += 256) {
+        const double2 xa = z[k];
+        const double2 xb = (k == 0) ? nyq[0] : z[M - k];
+        const double2 w = twiddle(k);
+        const double ex = xa.x + xb.x, ey = xa.y - xb.y;    // E = X[k] + conj(X[M-k])
+        const double dx = xa.x - xb.x, dy = xa.y + xb.y;    // D = X[k] - conj(X[M-k])
+        const double px = w.x * dx - w.y * dy, py = w.x * dy + w.y * dx; // w^k D
+        const double tx = -py, ty = px;                     // T = i w^k D
+        z[k] = make_double2(ex + tx, ey + ty);
+        if (k > 0 && 2 * k < M) z[M - k] = make_double2(ex - tx, -(ey - ty));
+    }
+    __syncthreads();
+    for (int s = logm - 1; s >= 0; --s) {
         const int l = 1 << s;          // half-size of the butterflies of this stage
-        const int tstride = half >> s; // twiddle stride
-        for (int bfly = tid; bfly < half; bfly += 256) {
+        for (int bfly = tid; bfly < M / 2; bfly += 256) {
             const int m = bfly & (l - 1);
             const int i = ((bfly >> s) << (s + 1)) + m;
-            const int ti = m * tstride;
-            const double2 w0 = tw[ti & (quarter - 1)];
-            const double2 w = (ti < quarter) ? w0 : make_double2(-w0.y, w0.x);
-            const double2 u = x[i], v = x[i + l];
-            const double2 t = make_double2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
-            x[i + l] = make_double2(u.x - t.x, u.y - t.y);
-            x[i] = make_double2(u.x + t.x, u.y + t.y);
+            const double2 w = twiddle(m << (logm - s));     // e^{2 pi i m / (2l)} = w^(m M / l)
+            const double2 u = z[i], v = z[i + l];
+            const double dx = u.x - v.x, dy = u.y - v.y;
+            z[i] = make_double2(u.x + v.x, u.y + v.y);
+            z[i + l] = make_double2(w.x * dx - w.y * dy, w.x * dy + w.y * dx);
         }
         __syncthreads();
     }
     const double scale = 1.0 / (double)N;
+    const int shift = 32 - logm;
     double *out = A.rf + (size_t)ib * A.ldr;
-    for (int n = tid; n < A.nkeep; n += 256) out[n] = scale * x[n].x;
+    for (int m = tid; 2 * m < A.nkeep; m += 256) {
+        const double2 v = z[(int)(__brev((unsigned)m) >> shift)];
+        out[2 * m] = scale * v.x;
+        if (2 * m + 1 < A.nkeep) out[2 * m + 1] = scale * v.y;
+    }
+}
+// Two register budgets of the same text: 4 wavefronts per SIMD (128 VGPRs, a few spilled) and 3 (168, none);
+// bh_launch_rf picks (BH_RF_WAVES overrides, for measurements).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void rf_synth_kernel(RfKernelArgs A, int logm, int jcut)
+{
+    rf_synth_body<false>(A, logm, jcut);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_synth_kernel_w3(RfKernelArgs A, int logm, int jcut)
+{
+    rf_synth_body<false>(A, logm, jcut);
+}
+// 96 registers: what two dispersion wavefronts of 208 leave of a SIMD's 512.  In the fused call (bh_evaluate_batch) one
+// such workgroup per CU runs BESIDE the dispersion kernel's eight wavefronts, at the lowest issue priority: it takes the
+// issue slots those leave idle (their FP64 pipe is busy 62 % of the time) instead of waiting for them to end.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rf_synth_kernel_beside(RfKernelArgs A, int logm, int jcut)
+{
+    rf_synth_body<true>(A, logm, jcut);
 }
 
 } // namespace
 
 size_t bh_rf_coef_doubles(int Lmax) { return rec_doubles(Lmax); }
 
-void bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
+size_t bh_rf_lds_bytes(int nsamp)
+{
+    return (size_t)(nsamp / 2) * 16 + 16 + 64 * 16 + (size_t)(nsamp >= 128 ? nsamp / 128 : 1) * 16;
+}
+
+int bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
 {
     const int half = a.nsamp / 2;
-    int logn = 0;
-    while ((1 << logn) < a.nsamp) ++logn;
+    int logm = 0;
+    while ((1 << logm) < half) ++logm;
+    size_t lds = bh_rf_lds_bytes(a.nsamp); // half-length complex spectrum + Nyquist bin + two twiddle tables
+    if (lds > BH_RF_MAX_LDS) return -1;
+    if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;
+    if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit: a workgroup may take the CU's whole 160 KB
+        static size_t allowed = 0;
+        if (lds > allowed) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)BH_RF_MAX_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel_w3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)BH_RF_MAX_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel_beside), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)BH_RF_MAX_LDS) != hipSuccess)
+                return -1;
+            allowed = BH_RF_MAX_LDS;
+        }
+    }
     if (a.Lmax <= 16)
         hipLaunchKernelGGL((rf_coef_layers_kernel<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     else if (a.Lmax <= 32)
         hipLaunchKernelGGL((rf_coef_layers_kernel<32>), dim3((a.B + 7) / 8), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
-    const size_t lds = (size_t)a.nsamp * 16 + (size_t)(half / 2 > 0 ? half / 2 : 1) * 16; // spectrum + quarter twiddle table
     // Spectral cut-off.  Every bin carries the Gauss low-pass exp(-w^2 / (4 a^2)) (greens.cpp:343-398); where that
-    // factor is below 1e-30 the bin is below 1e-30 of the pass band (|R/Z| is of order one) and cannot change a
-    // double-precision sum of the others: such bins are set to zero instead of being computed (the reference
-    // computes them and multiplies by ~0).  With a = 2.5, 20 Hz, nsamp 2048 that is every bin above 6.6 Hz, a third.
+    // factor is below RF_CUT = 1e-20 the bin is below 1e-20 of the pass band (|R/Z| is of order one) and cannot change a
+    // double-precision sum of the others (2^-53 = 1.1e-16): such bins are set to zero instead of being computed (the
+    // reference computes them and multiplies by ~0).  With a = 2.5, 20 Hz, nsamp 2048 that is every bin above 5.4 Hz, 46 %.
     const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch, read per launch (tests toggle it)
     const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
     const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
-    hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logn, jcut);
+    const char *wv = std::getenv("BH_RF_WAVES");
+    if (a.beside)
+        hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+    else if (wv != nullptr && std::atoi(wv) == 3)
+        hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+    else
+        hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+    return 0;
 }

@@ -162,8 +162,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
+// WPB = wavefronts per workgroup (they only share the libm tables): 2 by default; 4 when receiver-function workgroups
+// are to run beside the kernel -- a CU's eight wavefronts then hold two copies of the tables instead of four, which is
+// what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
+template <int WPB>
+__global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
+    // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
+    if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
     const int cls = (A.split != nullptr) ? (int)blockIdx.z : 1; // 0 = the deep models of a ragged batch, 1 = the rest
     // Wavefront -> (target, index).  Two targets in a one-dimensional grid are INTERLEAVED wavefront by wavefront in
     // proportion to their wavefront counts, so that every CU gets its share of both: dispatched target after
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
     // Rayleigh wavefronts runs them up to 30 % slower than a mixed one (LDS traffic: 150 LDS instructions per
     // Rayleigh round, 61 per Love round).  A workgroup's wavefronts only share the libm tables.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / BH_WAVE));
-    int wid = (int)blockIdx.x * GROUP_WPB + wave, ty = (int)blockIdx.y;
+    int wid = (int)blockIdx.x * WPB + wave, ty = (int)blockIdx.y;
     bool beyond = false; // (interleaved grid: a last, odd wavefront may have nothing to do)
     if (A.wg_n1 > 0) {
         const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
         if (cls == 0) hi = ndeep;
         else lo = ndeep;
     }
-    if (A.wg_n1 == 0 && lo + (int)blockIdx.x * GROUP_WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
-    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * GROUP_WPB);
+    if (A.wg_n1 == 0 && lo + (int)blockIdx.x * WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
+    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * WPB);
     __syncthreads();
     if (beyond || lo + wid * MPW >= hi) return;
     unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(BH_WAVE * GROUP_WPB) __attribute__((amdgpu_waves_pe
                 if ((other >> 16) == A.stamp && (other & 0xffffu) != frac) high = frac < (other & 0xffffu);
             }
             if (high) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(0);
+            else if (A.prio_low == 0) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
         }
         ++nrounds;
         // All lanes take part in the evaluation (finished models compute on stale values).
@@ -583,8 +590,9 @@ size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 constexpr size_t WAVE_LDS_TARGET = (160 * 1024 / 4 - LIBM_TAB_PAD) / GROUP_WPB;
 constexpr size_t WG_LDS_CAP = 64 * 1024;
 
-int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
+int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdLaunchInfo *info, int wpb)
 {
+    if (wpb != 4) wpb = GROUP_WPB;
     int kmax = 0, maxmode = 1;
     for (int t = 0; t < a0.ntargets; ++t) {
         kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
@@ -642,6 +650,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
             }
         }
         while (most_models(G) > 1 && wave_bytes(G) > WAVE_LDS_TARGET) G += 1;
+        // (the cap is what a workgroup of GROUP_WPB wavefronts may ask for by default; the same models per wavefront with 4)
         while (G < BH_WAVE && LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) G += 1;
         if (LIBM_TAB_PAD + GROUP_WPB * wave_bytes(G) > WG_LDS_CAP) return -1;
         a.rows[cls] = rows;
@@ -658,7 +667,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
         a.rows[0] = a.rows[1];
         a.lanes[0] = a.lanes[1];
     }
-    dim3 grid((nwaves + GROUP_WPB - 1) / GROUP_WPB, a.ntargets, two ? 2 : 1);
+    dim3 grid((nwaves + wpb - 1) / wpb, a.ntargets, two ? 2 : 1);
     a.wg_n0 = a.wg_n1 = 0;
     static const bool no_mix = std::getenv("BH_SWD_NO_MIX") != nullptr; // experiment switch
     if (a.ntargets == 2 && !two && !no_mix) { // two targets, one depth class: interleave their wavefronts (see the kernel)
@@ -671,10 +680,26 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream)
         }
         a.wg_n0 = n[0];
         a.wg_n1 = n[1];
-        grid = dim3((n[0] + n[1] + GROUP_WPB - 1) / GROUP_WPB, 1, 1);
+        grid = dim3((n[0] + n[1] + wpb - 1) / wpb, 1, 1);
     }
-    const size_t lds = LIBM_TAB_PAD + GROUP_WPB * wave_lds;
-    hipLaunchKernelGGL(swd_group_kernel, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+    const size_t lds = LIBM_TAB_PAD + wpb * wave_lds;
+    if (info != nullptr) {
+        info->workgroups = grid.x * grid.y * grid.z;
+        info->waves = (a.wg_n1 > 0) ? (long)a.wg_n0 + a.wg_n1 : (long)nwaves * a.ntargets;
+        info->lds = lds;
+    }
+    if (wpb == 4) {
+        static bool big_lds = false;
+        if (lds > WG_LDS_CAP && !big_lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return -1;
+            big_lds = true;
+        }
+        hipLaunchKernelGGL(swd_group_kernel<4>, grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
+    } else {
+        hipLaunchKernelGGL(swd_group_kernel<GROUP_WPB>, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+    }
     return 0;
 }
 

@@ -54,7 +54,7 @@ FP64_VALU_PEAK_TF = 78.6    # CDNA4 FP64 vector peak; this path
 FLOP_PER_LPS = {2: 320.0, 1: 65.0}
 NPOOL = 4                   # distinct batches rotated through the steps
 CLOCK_WARMUP_MS = 150.0     # untimed launches of the step before the --warmup steps (clock ramp of an idle GPU)
-RF_CUT_WA = 16.6226         # csrc/rf_kernel.hip: w/a beyond which the Gauss low-pass is below 1e-30
+RF_CUT_WA = 13.5725         # csrc/rf_kernel.hip: w/a beyond which the Gauss low-pass is below 1e-20
 RF_FLOP_PER_LAYER_STEP = 600.0   # flop-equivalents of one layer of the reflectivity recursion for one frequency
 
 

@@ -21,14 +21,38 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_write_what_one_rank_writes(tmp_path):
-    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+def _two_rank_job(outdir, backend):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "sharded_rank.py"), two, "gloo"]
+           "--master-port", str(_free_port()), os.path.join(HERE, "sharded_rank.py"), outdir, backend]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "accepted swaps" in r.stdout
+
+
+def test_two_ranks_over_rccl_one_gpu_each(tmp_path):
+    """The sharded job with the REAL collective path: two ranks, one GPU each, nccl (= RCCL over xGMI): chain layout
+    gather, the exchange sweeps on the device (all_gather_into_tensor of (logL, beta)), the end-of-run gather -- and the
+    files equal those of one rank running all 24 chains.  Needs two GPUs (skipped on the one-GPU boxes of the build; the
+    ranks do NOT call torch.cuda.set_device: every buffer must follow DeviceChains(device=))."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    _two_rank_job(two, "nccl")
+    sys.path.insert(0, HERE)
+    from sharded_rank import job
+    job(24, 0, 24, None, one)
+    names = sorted(n for n in os.listdir(os.path.join(one, "data")) if n.endswith(".npy"))
+    assert sorted(os.listdir(os.path.join(one, "data"))) == sorted(os.listdir(os.path.join(two, "data"))) and len(names) == 60
+    for n in names:
+        a, b = np.load(os.path.join(one, "data", n)), np.load(os.path.join(two, "data", n))
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), n
+
+
+def test_two_ranks_write_what_one_rank_writes(tmp_path):
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    _two_rank_job(two, "gloo")
     sys.path.insert(0, HERE)
     from sharded_rank import job
     dc = job(24, 0, 24, None, one)
