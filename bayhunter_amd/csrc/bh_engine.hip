@@ -50,9 +50,11 @@ struct bh_engine {
     int rf_beside_prio = 0;                // BH_RF_BESIDE_PRIO env: issue priority (0..3) of the co-resident RF wavefronts
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
     SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
+    int err_t_nt = -1, err_t_B = -1;       // layout for which err_t's untouched rows are known to be zero
     int swd_prio_low_now = 0;              // per call: what the next dispersion launch gets
     int swd_wpb_now = 2;                   // per call: wavefronts per workgroup of the next dispersion launch
     bool rf_coresident_now = false;        // per call: RF kernels run in the co-resident mode
+    bool rf_gated_now = false;             // per call: the RF stream waits for the dispersion kernel's workgroups to be resident
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
@@ -66,6 +68,7 @@ struct bh_engine {
     bool timing = false, counting = false;
     bool no_mfma = false; // BH_NO_MFMA env: Gauss law through the in-kernel mat-vec (A/B testing)
     bool no_order = false; // BH_NO_ORDER env: wavefronts take the models in batch order (A/B testing)
+    bool as_given = false; // bh_engine_set_model_order(e, 0): the caller's batches need no sorting by depth
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
@@ -312,7 +315,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     // processing order: deepest models first, wavefronts of (nearly) one depth
     const int32_t *perm = nullptr, *split = nullptr;
     int Lcut = Lmax;
-    if (B > 1 && !e->no_order) {
+    if (B > 1 && !e->no_order && !e->as_given) {
         if ((rc = ensure(e, e->perm, ((size_t)B + 4) * sizeof(int32_t)))) return rc;
         int32_t *p = (int32_t *)e->perm.p;
         // LDS rows for the bulk of the batch: its typical depth plus a margin; deeper models get their own launch
@@ -427,7 +430,9 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     // of wavefronts; displaced ones wait for a whole lifetime: 3.6 -> 7 ms measured when the 17.7 KB workgroups of
     // round 3 slipped into the 18 KB of LDS the dispersion wavefronts leave free on a CU).  Asking for more LDS than
     // that remainder keeps them out of CUs whose dispersion wavefronts are still running, as in round 2 (40 KB).
-    a.lds_min = (beside_swd && !e->rf_coresident_now) ? e->rf_lds_beside_swd : 0;
+    // (with the start gate of bh_evaluate_batch in force the LDS floor is not needed: RF workgroups are dispatched
+    // after every dispersion wavefront is resident and only take what finished wavefronts have freed)
+    a.lds_min = (beside_swd && !e->rf_coresident_now && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
     a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
     ev_begin(e, 1, st);
     const int lrc = bh_launch_rf(a, st);
@@ -537,6 +542,13 @@ int bh_engine_set_typical_layers(bh_engine *e, int nlay)
     if (!e) return BH_EINVAL;
     if (nlay < 0 || nlay > BH_MAX_LAYERS) return fail(e, BH_EINVAL, "typical layer count must be 0 (unknown) or 1..100");
     e->hint_layers = nlay;
+    return BH_OK;
+}
+
+int bh_engine_set_model_order(bh_engine *e, int sort_by_depth)
+{
+    if (!e) return BH_EINVAL;
+    e->as_given = (sort_by_depth == 0);
     return BH_OK;
 }
 
@@ -825,6 +837,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     e->targets.swap(tmp);
     e->nt = nt;
     e->ldy = off;
+    e->err_t_nt = e->err_t_B = -1;
     return BH_OK;
 }
 
@@ -865,7 +878,11 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         if ((rc = ensure(e, e->ymod, (size_t)B * ldy * sizeof(double)))) return rc;
         ymod_d = (double *)e->ymod.p;
     }
-    if ((rc = ensure(e, e->err_t, (size_t)nt * B * sizeof(int32_t)))) return rc;
+    {
+        const size_t cap0 = e->err_t.cap;
+        if ((rc = ensure(e, e->err_t, (size_t)nt * B * sizeof(int32_t)))) return rc;
+        if (e->err_t.cap != cap0) e->err_t_nt = e->err_t_B = -1; // a new buffer: not zeroed yet
+    }
     if (!m.rho) { // rho = 0.32 vp + 0.77 (Targets.py:319)
         const size_t nel = span_elems(B, Lmax, sl, sb);
         if ((rc = ensure(e, e->rho, nel * sizeof(double)))) return rc;
@@ -873,7 +890,13 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         m.rho = (const double *)e->rho.p;
     }
     call_begin(e, st);
-    HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
+    // per-target failure flags [nt][B]: the dispersion kernels write every entry of their target's row on every call,
+    // nothing writes the rows of the other targets -- they are zeroed once per (nt, B) layout, not once per call
+    if (e->err_t_nt != nt || e->err_t_B != B) {
+        HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
+        e->err_t_nt = nt;
+        e->err_t_B = B;
+    }
     LikeKernelArgs la{};
     la.B = B; la.nt = nt; la.ldy = ldy; la.ymod = ymod_d; la.err_t = (const int32_t *)e->err_t.p;
     la.noise = noise_d; la.logL = logL_d; la.misfits = misf_d; la.err = err_d;
@@ -935,7 +958,9 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     e->swd_wpb_now = 2;
     if (rc) return rc;
     e->rf_coresident_now = false;
+    e->rf_gated_now = false;
     if (want_gate && e->last_swd.workgroups > 0) {
+        e->rf_gated_now = std::getenv("BH_RF_KEEP_FLOOR") == nullptr;
         size_t rf_lds = 0;
         for (int t = 0; t < nt; ++t)
             if (e->targets[(size_t)t].d.kind == BH_TARGET_RF) {
@@ -996,6 +1021,7 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
     const bool host = (memspace != BH_DEVICE);
     hipStream_t st = (!host && stream) ? (hipStream_t)stream : e->stream;
     if ((rc = ensure(e, e->err_t, (size_t)nt * B * sizeof(int32_t)))) return rc;
+    e->err_t_nt = e->err_t_B = -1; // (this call may fill the flag rows with the caller's: bh_evaluate_batch zeroes them again)
     LikeKernelArgs la{};
     la.B = B; la.nt = nt; la.ldy = ldy;
     la.ymod = ymod; la.noise = noise; la.logL = logL; la.misfits = misfits; la.err = err;

@@ -185,6 +185,9 @@ __device__ __forceinline__ cm2 operator+(const cm2 &x, const cm2 &y)
 //  [16..23] free-surface ru (4 complex)
 //  [24 + 8*l ...]           layer l = 0..Lmax-1 : 1/vp^2, 1/vs^2, h (flattened), 1/(pi qp), 1/(2 qp), 1/(pi qs), 1/(2 qs), -
 //  [24 + 8*Lmax + 32*i ...] interface below layer i (i = 0..Lmax-2): rd, td, ru, tu (4 complex each)
+//  [24 + 40*Lmax]           1 when every interface matrix and the free-surface ru are REAL (no post-critical wave at any
+//                           interface: vertical slownesses of the elastic, real velocities all real) -- the synthesis kernel
+//                           then multiplies by real matrices (rf_one_frequency<true>)
 constexpr int REC_HEAD = 24;
 __host__ __device__ inline size_t rec_doubles(int Lmax) { return REC_HEAD + 8 * (size_t)Lmax + 32 * (size_t)Lmax + 2; }
 
@@ -197,6 +200,32 @@ __device__ __forceinline__ cm2 load_cm2(const double *p)
 {
     return cm2{cd{p[0], p[1]}, cd{p[2], p[3]}, cd{p[4], p[5]}, cd{p[6], p[7]}};
 }
+// a real 2x2 matrix: the real parts of a stored complex one whose imaginary parts are zero
+struct rm2 {
+    double c11, c12, c21, c22;
+};
+__device__ __forceinline__ rm2 load_rm2(const double *p) { return rm2{p[0], p[2], p[4], p[6]}; }
+__device__ __forceinline__ cm2 operator*(const rm2 &x, const cm2 &y)
+{
+    return cm2{cd{x.c11 * y.c11.re + x.c12 * y.c21.re, x.c11 * y.c11.im + x.c12 * y.c21.im},
+               cd{x.c11 * y.c12.re + x.c12 * y.c22.re, x.c11 * y.c12.im + x.c12 * y.c22.im},
+               cd{x.c21 * y.c11.re + x.c22 * y.c21.re, x.c21 * y.c11.im + x.c22 * y.c21.im},
+               cd{x.c21 * y.c12.re + x.c22 * y.c22.re, x.c21 * y.c12.im + x.c22 * y.c22.im}};
+}
+__device__ __forceinline__ cm2 operator*(const cm2 &x, const rm2 &y)
+{
+    return cm2{cd{x.c11.re * y.c11 + x.c12.re * y.c21, x.c11.im * y.c11 + x.c12.im * y.c21},
+               cd{x.c11.re * y.c12 + x.c12.re * y.c22, x.c11.im * y.c12 + x.c12.im * y.c22},
+               cd{x.c21.re * y.c11 + x.c22.re * y.c21, x.c21.im * y.c11 + x.c22.im * y.c21},
+               cd{x.c21.re * y.c12 + x.c22.re * y.c22, x.c21.im * y.c12 + x.c22.im * y.c22}};
+}
+__device__ __forceinline__ cm2 operator+(const rm2 &x, const cm2 &y)
+{
+    return cm2{cd{x.c11 + y.c11.re, y.c11.im}, cd{x.c12 + y.c12.re, y.c12.im}, cd{x.c21 + y.c21.re, y.c21.im},
+               cd{x.c22 + y.c22.re, y.c22.im}};
+}
+// sum of |imaginary parts|: 0 exactly when the matrix is real
+__device__ __forceinline__ double imag_mass(const cm2 &m) { return fabs(m.c11.im) + fabs(m.c12.im) + fabs(m.c21.im) + fabs(m.c22.im); }
 // number of entries that are NaN or +-inf (a bit test: under -ffp-contract=fast "x - x" of an expression is not
 // reliably zero -- one copy may be contracted into an fma, the other not)
 __device__ __forceinline__ double nf1(double x) { return __builtin_isfinite(x) ? 0.0 : 1.0; }
@@ -254,6 +283,10 @@ __device__ void interface_coeffs(double u, double vp1, double vs1, double rho1, 
 }
 
 // One frequency of one model: greens.cpp:528-585 + :343-398.  `rec` may be wave-uniform.
+// REALC: the record's interface matrices are real (its flag says so): products with them take half the operations of a
+// complex 2x2 product -- 76 of the ~580 vector instructions of a layer step.  Same values (the general form multiplies
+// the same numbers by imaginary parts that are exactly zero).
+template <bool REALC>
 __device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, int Lmax, int j,
                                                double dw, double qg, double gauss, double tshift,
                                                int waveno)
@@ -289,17 +322,20 @@ __device__ __forceinline__ cd rf_one_frequency(const double *__restrict__ rec, i
             nt = load_cm2(rec + 16);
         else {
             const double *ic = ifc + 32 * (i - 2); // interface above layer i
-            nt = load_cm2(ic + 16) + (load_cm2(ic + 8) * nb) * q; // ru[i] + td[i]*nb[i-1]*q
+            if (REALC) nt = load_rm2(ic + 16) + (load_rm2(ic + 8) * nb) * q;
+            else nt = load_cm2(ic + 16) + (load_cm2(ic + 8) * nb) * q; // ru[i] + td[i]*nb[i-1]*q
         }
         const cd e12 = e11 * e22;
         nb = cm2{nt.c11 * (e11 * e11), nt.c12 * e12, nt.c21 * e12, nt.c22 * (e22 * e22)};
         const double *icn = ifc + 32 * (i - 1); // interface below layer i
-        const cm2 rdn = load_cm2(icn), tun = load_cm2(icn + 24);
-        const cm2 rn = rdn * nb;
+        cm2 rn;
+        if (REALC) rn = load_rm2(icn) * nb;
+        else rn = load_cm2(icn) * nb;
         const cm2 m = cm2{C(1.) - rn.c11, -rn.c12, -rn.c21, C(1.) - rn.c22};
         const cd idet = crecip_f(m.c11 * m.c22 - m.c12 * m.c21);
         const cm2 minv = cm2{idet * m.c22, -(idet * m.c12), -(idet * m.c21), idet * m.c11};
-        q = minv * tun;
+        if (REALC) q = minv * load_rm2(icn + 24);
+        else q = minv * load_cm2(icn + 24);
         if (i == 1)
             g = cm2{e11 * q.c11, e11 * q.c12, e22 * q.c21, e22 * q.c22};
         else {
@@ -350,6 +386,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
     const double p2 = p * p;
     double bad = 0.0;
     double nf = 0.0; // stays 0 while every coefficient of the record is finite
+    double im = 0.0; // stays 0 while every interface matrix is real
 
     // top-layer quantities before flattening (q = 1 for the top layer anyway)
     const double vp0 = A.vp[base], vs0 = A.vs[base];
@@ -419,6 +456,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
             hm.c11 = 2.0 * hm.c11; hm.c12 = 2.0 * hm.c12; hm.c21 = 2.0 * hm.c21; hm.c22 = 2.0 * hm.c22;
             store_cm2(rec + 8, hm);
             nf += nonfinite(ru) + nonfinite(hm);
+            im += imag_mass(ru);
             (void)vp2;
         } else {
             cm2 rd, td, ru, tu;
@@ -429,6 +467,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
             store_cm2(ic + 16, ru);
             store_cm2(ic + 24, tu);
             nf += nonfinite(rd) + nonfinite(td) + nonfinite(ru) + nonfinite(tu);
+            im += imag_mass(rd) + imag_mass(td) + imag_mass(ru) + imag_mass(tu);
         }
         pvp = vp; pvs = vs; prh = rh;
         ztop = znext;
@@ -452,6 +491,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
     if (nf != 0.0) bad = 1.0;
     rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
     rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
+    rec[REC_HEAD + 40 * (size_t)Lmax] = (im == 0.0) ? 1.0 : 0.0;
 }
 
 // The same record with LP lanes per model, lane l = layer l (LP = 16 or 32 >= Lmax): the serial kernel above is a
@@ -501,6 +541,7 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         }
     }
     double nf = 0.0; // stays 0 while every coefficient this lane writes is finite
+    double im = 0.0; // stays 0 while the interface matrices this lane writes are real
     if (on) {
         double *lay = rec + REC_HEAD + 8 * l;
         lay[0] = 1.0 / (vp * vp); lay[1] = 1.0 / (vs * vs); lay[2] = hh;
@@ -521,13 +562,15 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         store_cm2(ic + 16, ru);
         store_cm2(ic + 24, tu);
         nf += nonfinite(rd) + nonfinite(td) + nonfinite(ru) + nonfinite(tu);
+        im = imag_mass(rd) + imag_mass(td) + imag_mass(ru) + imag_mass(tu);
     }
-    double t0 = 0.0, nfall = 0.0;
+    double t0 = 0.0, nfall = 0.0, imall = 0.0;
     for (int i = 0; i < LP; ++i) {
-        const double ti = __shfl(term, lbase + i), ni = __shfl(nf, lbase + i);
+        const double ti = __shfl(term, lbase + i), ni = __shfl(nf, lbase + i), ii = __shfl(im, lbase + i);
         if (i < nlay) {
             t0 += ti;
             nfall += ni;
+            imall += ii;
         }
     }
     if (vm && l == 0) {
@@ -582,6 +625,7 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         if (nfall != 0.0) bad = 1.0;
         rec[0] = (double)nlay; rec[1] = p; rec[2] = do_decomp; rec[3] = bad;
         rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
+        rec[REC_HEAD + 40 * (size_t)Lmax] = (imall + imag_mass(ru) == 0.0 && nfall == 0.0) ? 1.0 : 0.0;
     }
 }
 
@@ -616,26 +660,36 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
     double2 *tw0 = nyq + 1;                                // [64]  w^r
     double2 *tw1 = tw0 + 64;                               // [max(1, N/128)]  w^(64 q)
     const int ib = blockIdx.x;
+    const int nthr = blockDim.x; // 256 (four wavefronts) or 128
+    // Which wavefront takes the bins of the last, partly filled pass rotates with the workgroup (553 bins are 3 + 2 + 2 + 2
+    // passes of 64 lanes: without the rotation the same hardware wave slot of every workgroup carries the third pass)
+    const int rot = (blockIdx.x * 64) & (nthr - 1);
     const int tid = threadIdx.x;
+    const int tbin = (A.no_rot ? tid : ((tid + rot) & (nthr - 1)));
     const double dw = 2.0 * M_PI * A.fsamp / A.nsamp;
     const double qg = sqrt(M_PI) * A.fsamp / A.gauss;
     const size_t recsz = rec_doubles(A.Lmax);
     const double *rec = A.coef + (size_t)ib * recsz;
     const int n1 = (N >= 128) ? N / 128 : 1;
-    for (int k = tid; k < 64 + n1; k += 256) {
+    for (int k = tid; k < 64 + n1; k += nthr) {
         const int idx = (k < 64) ? k : (k - 64) * 64;
         double sn, cs;
         sincos_cw((2.0 * M_PI / (double)N) * (double)idx, &sn, &cs);
         tw0[k] = make_double2(cs, sn); // (tw1 follows tw0)
     }
-    for (int j = tid; j < M; j += 256) {
+    const bool realc = rec[REC_HEAD + 40 * (size_t)A.Lmax] != 0.0 && !A.no_realc; // (uniform over the workgroup)
+    for (int j = tbin; j < M; j += nthr) {
         // bins from jcut on: the Gauss low-pass has them below RF_CUT of the pass band (see bh_launch_rf)
-        cd s = (j < jcut) ? rf_one_frequency(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
+        cd s = cd{0.0, 0.0};
+        if (j < jcut) {
+            if (realc) s = rf_one_frequency<true>(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
+            else s = rf_one_frequency<false>(rec, A.Lmax, j, dw, qg, A.gauss, A.tshift, A.waveno);
+        }
         if (j == 0) s.im = __builtin_isfinite(s.im) ? 0.0 : s.im; // Re X[0] only (a non-finite bin stays non-finite)
         z[j] = make_double2(s.re, s.im);
     }
     if (tid == 0) { // the Nyquist bin: one more frequency for one thread, and only when the filter keeps it
-        const cd s = (M < jcut) ? rf_one_frequency(rec, A.Lmax, M, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
+        const cd s = (M < jcut) ? rf_one_frequency<false>(rec, A.Lmax, M, dw, qg, A.gauss, A.tshift, A.waveno) : cd{0.0, 0.0};
         nyq[0] = make_double2(s.re, __builtin_isfinite(s.im) ? 0.0 : s.im);
     }
     __syncthreads();
@@ -643,7 +697,7 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
         const double2 a = tw1[k >> 6], b = tw0[k & 63];
         return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
     };
-    for (int k = tid; k <= M / 2; k += 256) {
+    for (int k = tid; k <= M / 2; k += nthr) {
         const double2 xa = z[k];
         const double2 xb = (k == 0) ? nyq[0] : z[M - k];
         const double2 w = twiddle(k);
@@ -657,7 +711,7 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
     __syncthreads();
     for (int s = logm - 1; s >= 0; --s) {
         const int l = 1 << s;          // half-size of the butterflies of this stage
-        for (int bfly = tid; bfly < M / 2; bfly += 256) {
+        for (int bfly = tid; bfly < M / 2; bfly += nthr) {
             const int m = bfly & (l - 1);
             const int i = ((bfly >> s) << (s + 1)) + m;
             const double2 w = twiddle(m << (logm - s));     // e^{2 pi i m / (2l)} = w^(m M / l)
@@ -671,7 +725,7 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
     const double scale = 1.0 / (double)N;
     const int shift = 32 - logm;
     double *out = A.rf + (size_t)ib * A.ldr;
-    for (int m = tid; 2 * m < A.nkeep; m += 256) {
+    for (int m = tid; 2 * m < A.nkeep; m += nthr) {
         const double2 v = z[(int)(__brev((unsigned)m) >> shift)];
         out[2 * m] = scale * v.x;
         if (2 * m + 1 < A.nkeep) out[2 * m + 1] = scale * v.y;
@@ -704,8 +758,13 @@ size_t bh_rf_lds_bytes(int nsamp)
     return (size_t)(nsamp / 2) * 16 + 16 + 64 * 16 + (size_t)(nsamp >= 128 ? nsamp / 128 : 1) * 16;
 }
 
-int bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
+int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
 {
+    RfKernelArgs a = a_in;
+    a.no_realc = std::getenv("BH_RF_NO_REALC") != nullptr ? 1 : 0; // experiment switches
+    a.no_rot = std::getenv("BH_RF_NO_ROT") != nullptr ? 1 : 0;
+    const char *tv = std::getenv("BH_RF_THREADS");
+    const int nthr = (tv != nullptr && std::atoi(tv) == 128) ? 128 : 256;
     const int half = a.nsamp / 2;
     int logm = 0;
     while ((1 << logm) < half) ++logm;
@@ -741,10 +800,10 @@ int bh_launch_rf(const RfKernelArgs &a, hipStream_t stream)
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
     const char *wv = std::getenv("BH_RF_WAVES");
     if (a.beside)
-        hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+        hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else if (wv != nullptr && std::atoi(wv) == 3)
-        hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+        hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else
-        hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+        hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     return 0;
 }

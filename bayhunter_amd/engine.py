@@ -105,6 +105,7 @@ def load_library():
     L.bh_engine_set_swd_group.argtypes = [vp, C.c_int]
     L.bh_engine_set_swd_lookahead.argtypes = [vp, C.c_int]
     L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
+    L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
     L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -124,7 +125,7 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
@@ -136,7 +137,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -213,6 +214,10 @@ class Engine(object):
     def set_typical_layers(self, nlay):
         """Hint for device-resident batches: typical layer count (0 = unknown)."""
         self._check(self._L.bh_engine_set_typical_layers(self._h, int(nlay)))
+
+    def set_model_order(self, sort_by_depth=True):
+        """False: batches are of uniform depth (or sorted already): skip the on-device sort by layer count."""
+        self._check(self._L.bh_engine_set_model_order(self._h, int(bool(sort_by_depth))))
 
     def set_swd_lookahead(self, trials_per_round):
         """0 = automatic; 1..12 trial phase velocities per round of the dispersion root search."""

@@ -89,6 +89,10 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  * The lanes-per-model choice is sized for it; 0 = unknown (Lmax is used).  BH_HOST calls look at nlay
  * themselves.  Results do not depend on it. */
 int bh_engine_set_typical_layers(bh_engine *e, int nlay);
+/* Scheduling hint: by default a call first sorts its batch by layer count on the device (a counting sort, ~12 us + a
+ * launch gap) so that a wavefront holds models of one depth -- what ragged (transdimensional) batches need.  A caller
+ * whose batches are of uniform depth (or already sorted) turns it off with sort_by_depth = 0.  Results do not depend on it. */
+int bh_engine_set_model_order(bh_engine *e, int sort_by_depth);
 /* The engine's own stream as a hipStream_t cast to void*. */
 void *bh_engine_stream(bh_engine *e);
 /* Block until everything enqueued on the engine's stream has finished. */

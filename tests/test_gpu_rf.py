@@ -87,6 +87,27 @@ def test_spectral_cutoff_changes_nothing_and_nonfinite_models_stay_nonfinite(eng
     assert np.max(np.abs(rf[ok] - orf[ok]) / np.abs(orf[ok]).max(axis=1, keepdims=True)) <= TOL
 
 
+def test_real_coefficient_recursion_equals_the_general_one(engine, oracle, monkeypatch):
+    """Where no wave is post-critical at any interface the interface matrices are real and the synthesis kernel multiplies
+    by real 2x2 matrices (rf_one_frequency<true>); BH_RF_NO_REALC forces the general form.  Same traces to 1e-13 of the
+    peak; and a ray parameter beyond the critical one for the fast layers (complex matrices: the flag must say so and the
+    general form run) still matches the oracle."""
+    rs = np.random.RandomState(123)
+    nlay, h, vp, vs, rho = synth_models(rs, 48, 12, lvz_frac=0.3, ragged=True)
+    for p_ray, waveno in ((6.4, 0), (6.4, 1), (14.0, 0), (14.0, 1)):     # 14 s/deg = 0.126 s/km: evanescent P above 7.9 km/s
+        monkeypatch.delenv("BH_RF_NO_REALC", raising=False)
+        fast = engine.rf_batch(nlay, h, vp, vs, rho, p_ray, 2.0, 1024, 10.0, 5.0, waveno, 512)
+        monkeypatch.setenv("BH_RF_NO_REALC", "1")
+        gen = engine.rf_batch(nlay, h, vp, vs, rho, p_ray, 2.0, 1024, 10.0, 5.0, waveno, 512)
+        monkeypatch.delenv("BH_RF_NO_REALC")
+        orf = oracle.rf_batch(nlay, h.T, vp.T, vs.T, rho.T, p_ray, 2.0, 1024, 10.0, 5.0, waveno, 512)
+        ok = np.isfinite(orf).all(axis=1)
+        assert ok.sum() >= 20 and np.array_equal(np.isfinite(fast).all(axis=1), ok)
+        peak = np.abs(orf[ok]).max(axis=1, keepdims=True)
+        assert np.max(np.abs(fast[ok] - gen[ok]) / peak) <= 1e-13
+        assert np.max(np.abs(fast[ok] - orf[ok]) / peak) <= TOL
+
+
 def test_bad_arguments_fail_loudly(engine):
     from bayhunter_amd.engine import EngineError
     nlay, h, vp, vs, rho = synth_models(np.random.RandomState(1), 2, 3)
