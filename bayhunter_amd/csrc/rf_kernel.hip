@@ -26,8 +26,8 @@
 #include <cstdlib>
 
 namespace {
-// w / a beyond which the Gauss low-pass exp(-(w/a)^2 / 4) is below RF_CUT = 1e-20: 2 sqrt(20 ln 10)
-constexpr double RF_CUT_WA = 13.5725;
+// w / a beyond which the Gauss low-pass exp(-(w/a)^2 / 4) is below RF_CUT = 1e-17: 2 sqrt(17 ln 10)
+constexpr double RF_CUT_WA = 12.5132;
 
 struct cd {
     double re, im;
@@ -791,9 +791,11 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     else
         hipLaunchKernelGGL(rf_coef_kernel, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
     // Spectral cut-off.  Every bin carries the Gauss low-pass exp(-w^2 / (4 a^2)) (greens.cpp:343-398); where that
-    // factor is below RF_CUT = 1e-20 the bin is below 1e-20 of the pass band (|R/Z| is of order one) and cannot change a
-    // double-precision sum of the others (2^-53 = 1.1e-16): such bins are set to zero instead of being computed (the
-    // reference computes them and multiplies by ~0).  With a = 2.5, 20 Hz, nsamp 2048 that is every bin above 5.4 Hz, 46 %.
+    // factor is below RF_CUT = 1e-17 the bin is below 1e-17 of the pass band (|R/Z| is of order one): a tenth of the
+    // rounding unit (2^-53 = 1.1e-16) of the sums the transform forms, i.e. it is lost in the reference's own additions.
+    // Such bins are set to zero instead of being computed (the reference computes them and multiplies by ~0).  With
+    // a = 2.5, 20 Hz, nsamp 2048 that is every bin above 5.0 Hz: 510 of 1025 are computed, 8 passes of 64 lanes per model
+    // (round 2 cut at 1e-30: 678 bins, 11 passes).  tests/test_gpu_rf.py compares with the uncut transform (1e-13).
     const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch, read per launch (tests toggle it)
     const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
     const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
