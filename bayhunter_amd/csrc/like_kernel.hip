@@ -107,6 +107,75 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
     }
 }
 
+// All targets short (n <= 64, e.g. dispersion curves): one WAVEFRONT per model, four models per workgroup, no LDS and
+// no barrier -- the workgroup-per-model form above spends most of its 37 us (B = 4096, two targets of 30 periods) in
+// two barriers per reduction.  Lane i holds sample i, the sums are the same xor-shuffle tree over the same 64 slots
+// (the other three wavefronts of the form above only add zeros): identical bits.
+__global__ __launch_bounds__(256) void like_small_kernel(LikeKernelArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int ib = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ib >= A.B) return;
+    const double *y = A.ymod + (size_t)ib * A.ldy;
+    double logL = 0.0, joint = 0.0;
+    bool failed = false;
+    for (int t = 0; t < A.nt; ++t) failed = failed || (A.err_t[(size_t)t * A.B + ib] != 0);
+    for (int t = 0; t < A.nt && !failed; ++t) {
+        const LikeTargetDev T = A.t[t];
+        const int n = T.n;
+        const double *ym = y + T.off;
+        const double corr = A.noise[(size_t)ib * 2 * A.nt + 2 * t];
+        const double sigma = A.noise[(size_t)ib * 2 * A.nt + 2 * t + 1];
+        double s0 = 0.0, s1 = 0.0, sw = 0.0;
+        if (lane < n) {
+            const double d = ym[lane] - T.yobs[lane];
+            s0 += d * d;
+            if (T.law == 2 && lane + 1 < n) s1 += d * (ym[lane + 1] - T.yobs[lane + 1]);
+            if (T.law == 1) sw += d * d / T.yerr_scaled[lane];
+        }
+        if (T.law == 3 && lane == 0)
+            for (int sidx = 0; sidx < T.nsplit; ++sidx) sw += T.quad[(size_t)ib * T.nsplit + sidx];
+        for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off);
+        if (T.law == 2)
+            for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+        if (T.law == 1 || T.law == 3)
+            for (int off = 32; off > 0; off >>= 1) sw += __shfl_xor(sw, off);
+        const double s2 = sigma * sigma;
+        double phi, logdet = (2.0 * n) * log(sigma);
+        if (T.law == 0) {
+            phi = s0 / s2;
+        } else if (T.law == 1) {
+            phi = sw / s2;
+            logdet += T.logdet_extra;
+        } else if (T.law == 2) {
+            const double d0 = ym[0] - T.yobs[0], dn = ym[n - 1] - T.yobs[n - 1];
+            const double edge = (n > 1) ? (d0 * d0 + dn * dn) : (d0 * d0);
+            const double r2 = corr * corr;
+            phi = ((1.0 + r2) * s0 - r2 * edge - 2.0 * corr * s1) / (s2 * (1.0 - r2));
+            logdet += (n - 1) * log(1.0 - r2);
+        } else {
+            phi = sw / s2;
+            logdet += T.logdet_extra;
+        }
+        const double part = -0.5 * ((double)n * log(2.0 * M_PI) + logdet);
+        logL += part - phi / 2.0;
+        const double rms = sqrt(s0 / (double)n);
+        joint += rms;
+        if (lane == 0) A.misfits[(size_t)ib * (A.nt + 1) + t] = rms;
+    }
+    if (lane == 0) {
+        if (failed) { // Targets.py:325-328
+            A.logL[ib] = -1e15;
+            for (int t = 0; t <= A.nt; ++t) A.misfits[(size_t)ib * (A.nt + 1) + t] = 1e15;
+            A.err[ib] = 1;
+        } else {
+            A.logL[ib] = logL;
+            A.misfits[(size_t)ib * (A.nt + 1) + A.nt] = joint;
+            A.err[ib] = 0;
+        }
+    }
+}
+
 __global__ void probe_kernel(int op, int n, const double *in, double *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,7 +217,10 @@ void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream)
     for (int t = 0; t < a.nt; ++t)
         if (a.t[t].law == 3 && a.t[t].quad == nullptr && (size_t)a.t[t].n * sizeof(double) > lds)
             lds = (size_t)a.t[t].n * sizeof(double);
-    hipLaunchKernelGGL(like_kernel, dim3(a.B), dim3(256), lds, stream, a);
+    bool small = true; // every target fits one wavefront (and a Gauss law has its slab sums from the MFMA contraction)
+    for (int t = 0; t < a.nt; ++t) small = small && a.t[t].n <= 64 && !(a.t[t].law == 3 && a.t[t].quad == nullptr);
+    if (small) hipLaunchKernelGGL(like_small_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(like_kernel, dim3(a.B), dim3(256), lds, stream, a);
 }
 
 void bh_launch_probe(int op, int n, const double *in, double *out, hipStream_t stream)

@@ -1,43 +1,61 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- the rocprofv3 evidence of one round, run ON THE GPU BOX:
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
-# Bench lines of every workload; kernel-trace statistics of c2 / c3 / the B = 65536 throughput regime / the
-# receiver function alone / the chain workloads; and, in SEPARATE passes (never together with a trace domain),
-# the HBM counters (FETCH_SIZE / WRITE_SIZE) and the SQ activity counters of the c2 and c3 commands.
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
+# Bench lines; kernel-trace statistics of c2 / c3 / the chain workloads / the receiver function alone (ONE batch
+# shape per pass) / the Gauss-law contraction / the B = 65536 throughput regime; and, in SEPARATE passes (never
+# together with a trace domain), the HBM counters (FETCH_SIZE / WRITE_SIZE) and the SQ activity counters of the c2, c3
+# and RF-alone (c3 shape) commands, plus the c2 HBM passes with the progress board off (attribution of its traffic).
 # Raw output lands in gpurun_out/<TAG>/; tools/summarize_profiles.py condenses it into the files kept under profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2"
-$BENCH > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-$BENCH --workload c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
-$BENCH --workload c2g --no-cpu-baseline > "$OUT/bench_c2g.json" 2> "$OUT/bench_c2g.err"
-$BENCH --workload c3g --no-cpu-baseline > "$OUT/bench_c3g.json" 2> "$OUT/bench_c3g.err"
-python $R/bench.py --workload c4 --steps 400 --warmup 100 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
-python $R/bench.py --workload c5 --steps 400 --warmup 100 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
-python $R/bench.py --batch 65536 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c2_b65536.json" 2> "$OUT/bench_c2_b65536.err"
-python $R/bench.py --batch 512 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_c2_b512.json" 2> "$OUT/bench_c2_b512.err"
-cd /tmp
 NB="--no-cpu-baseline --no-parity"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c2" -o c2 -- $BENCH $NB > "$OUT/trace_c2.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o c3 -- $BENCH $NB --workload c3 > "$OUT/trace_c3.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c2_b65536" -o b -- python $R/bench.py --batch 65536 --steps 5 --warmup 2 $NB > "$OUT/trace_c2_b65536.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_rf" -o rf -- python $R/tools/gpu_rf_perf.py > "$OUT/trace_rf.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -o c4 -- python $R/bench.py --workload c4 --steps 300 --warmup 100 > "$OUT/trace_c4.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c5" -o c5 -- python $R/bench.py --workload c5 --steps 300 --warmup 100 > "$OUT/trace_c5.log" 2>&1
+python $R/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python $R/bench.py --workload c2g --no-cpu-baseline > "$OUT/bench_c2g.json" 2> "$OUT/bench_c2g.err"
+python $R/bench.py --workload c3g --no-cpu-baseline > "$OUT/bench_c3g.json" 2> "$OUT/bench_c3g.err"
+python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c2_b65536.json" 2> "$OUT/bench_c2_b65536.err"
+python $R/bench.py --workload c2 --batch 512 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_c2_b512.json" 2> "$OUT/bench_c2_b512.err"
+python $R/bench.py --workload c4 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c4_depth1.json" 2> "$OUT/bench_c4_depth1.err"
+python $R/bench.py --workload c5 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c5_depth1.json" 2> "$OUT/bench_c5_depth1.err"
+python $R/tools/gpu_latency.py > "$OUT/latency.txt" 2>&1
+for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
+for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
+cd /tmp
+TR="rocprofv3 --kernel-trace --stats --output-format csv"
+$TR -d "$OUT/trace_c2" -o t -- python $R/bench.py --workload c2 --steps 10 --warmup 2 $NB > "$OUT/trace_c2.log" 2>&1
+$TR -d "$OUT/trace_c3" -o t -- python $R/bench.py --workload c3 --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3.log" 2>&1
+$TR -d "$OUT/trace_c3g" -o t -- python $R/bench.py --workload c3g --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3g.log" 2>&1
+$TR -d "$OUT/trace_c2_b65536" -o t -- python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 $NB > "$OUT/trace_c2_b65536.log" 2>&1
+$TR -d "$OUT/trace_c4" -o t -- python $R/bench.py --workload c4 --steps 700 --warmup 300 > "$OUT/trace_c4.log" 2>&1
+$TR -d "$OUT/trace_c5" -o t -- python $R/bench.py --workload c5 --steps 600 --warmup 300 > "$OUT/trace_c5.log" 2>&1
+for sh in c3 tut t512u t512r n16384; do
+  $TR -d "$OUT/trace_rf_$sh" -o t -- python $R/tools/gpu_rf_perf.py $sh 20 > "$OUT/trace_rf_$sh.log" 2>&1
+done
+$TR -d "$OUT/trace_gauss" -o t -- python $R/tools/gpu_gauss_perf.py 4096 1024 20 > "$OUT/trace_gauss.log" 2>&1
+SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_SMEM"
+SQ2="SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"
+PM="rocprofv3 --output-format csv"
 for WL in c2 c3; do
+  CMD="python $R/bench.py --workload $WL --steps 4 --warmup 1 $NB --no-rf-roofline"
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${WL}_$C" -o pmc -- $BENCH $NB --workload $WL --steps 4 --warmup 1 > "$OUT/pmc_${WL}_$C.log" 2>&1
+    $PM --pmc $C -d "$OUT/pmc_${WL}_$C" -o pmc -- $CMD > "$OUT/pmc_${WL}_$C.log" 2>&1
   done
-  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_${WL}_SQ" -o pmc -- $BENCH $NB --workload $WL --steps 4 --warmup 1 > "$OUT/pmc_${WL}_SQ.log" 2>&1
+  $PM --pmc $SQ -d "$OUT/pmc_${WL}_SQ" -o pmc -- $CMD > "$OUT/pmc_${WL}_SQ.log" 2>&1
+  $PM --pmc $SQ2 -d "$OUT/pmc_${WL}_SQ2" -o pmc -- $CMD > "$OUT/pmc_${WL}_SQ2.log" 2>&1
+done
+for C in FETCH_SIZE WRITE_SIZE; do   # the progress board's share of the c2 traffic: the same passes with the board off
+  BH_SWD_NO_BOARD=1 $PM --pmc $C -d "$OUT/pmc_c2noboard_$C" -o pmc -- python $R/bench.py --workload c2 --steps 4 --warmup 1 $NB > "$OUT/pmc_c2noboard_$C.log" 2>&1
 done
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_rf_$C" -o pmc -- python $R/tools/gpu_rf_perf.py > "$OUT/pmc_rf_$C.log" 2>&1
+  $PM --pmc $C -d "$OUT/pmc_rf_c3_$C" -o pmc -- python $R/tools/gpu_rf_perf.py c3 5 > "$OUT/pmc_rf_c3_$C.log" 2>&1
 done
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_b65536_SQ" -o pmc -- python $R/bench.py --batch 65536 --steps 3 --warmup 1 $NB > "$OUT/pmc_b65536_SQ.log" 2>&1
+$PM --pmc $SQ -d "$OUT/pmc_rf_c3_SQ" -o pmc -- python $R/tools/gpu_rf_perf.py c3 5 > "$OUT/pmc_rf_c3_SQ.log" 2>&1
+$PM --pmc $SQ2 -d "$OUT/pmc_rf_c3_SQ2" -o pmc -- python $R/tools/gpu_rf_perf.py c3 5 > "$OUT/pmc_rf_c3_SQ2.log" 2>&1
+$PM --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_gauss_SQ" -o pmc -- python $R/tools/gpu_gauss_perf.py 4096 1024 5 > "$OUT/pmc_gauss_SQ.log" 2>&1
+$PM --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_b65536_SQ" -o pmc -- python $R/bench.py --workload c2 --batch 65536 --steps 3 --warmup 1 $NB > "$OUT/pmc_b65536_SQ.log" 2>&1
 cd $R
 python tools/summarize_profiles.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -25,22 +25,54 @@ def find(pattern):
     return hits[0] if hits else None
 
 
-for wl in ("c2", "c3", "c2_b65536", "rf", "c4", "c5"):
-    f = find("trace_%s/**/*kernel_stats.csv" % wl)
-    if f:
-        rows = [r for r in csv.reader(open(f))]
-        keep = [rows[0]] + [r for r in rows[1:] if not r[0].startswith("void at::") and "rocclr" not in r[0]][:8]
-        with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl)), "w") as fo:
-            csv.writer(fo, quoting=csv.QUOTE_ALL).writerows(keep)
+def trace_stats(wl):
+    """Per-kernel statistics from the per-dispatch kernel trace: all launches, and the FULL-SIZE launches only (grid =
+    the kernel's largest grid in the run) -- the bench makes a few one-model launches for its synthetic observed data,
+    which the plain kernel_stats.csv of rocprofv3 averages in."""
+    f = find("trace_%s/**/*kernel_trace.csv" % wl)
+    if not f:
+        return
+    rows = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        if name.startswith("void at::") or "rocclr" in name:
+            continue
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        rows[name].append((grid, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"])))
+    outp = os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl))
+    with open(outp, "w") as fo:
+        wr = csv.writer(fo, quoting=csv.QUOTE_ALL)
+        wr.writerow(["Name", "Calls", "AverageNs", "MinNs", "MaxNs", "FullSizeCalls", "FullSizeAverageNs", "FullSizeMinNs", "FullSizeMaxNs",
+                     "FullSizeSteadyAverageNs(after the first 6)", "VGPR_Count", "LDS_Block_Size", "Grid"])
         print("== kernel stats", wl)
-        for r in keep:
-            print("   ", r[0][:70], r[1:4])
-for wl in ("c2", "c3", "c2g", "c3g", "c4", "c5", "c2_b65536", "c2_b512"):
+        for name, v in sorted(rows.items(), key=lambda kv: -sum(d for _, d, _, _ in kv[1])):
+            gmax = max(g for g, _, _, _ in v)
+            full = [d for g, d, _, _ in v if g == gmax]
+            allv = [d for _, d, _, _ in v]
+            steady = full[6:] if len(full) > 8 else full
+            wr.writerow([name, len(allv), "%.1f" % (sum(allv) / len(allv)), min(allv), max(allv), len(full), "%.1f" % (sum(full) / len(full)),
+                         min(full), max(full), "%.1f" % (sum(steady) / len(steady)), v[0][2], max(l for _, _, _, l in v), gmax])
+            print("    %-66s calls %4d  full-size %4d  avg %10.1f us  steady %10.1f us" % (name[:66], len(allv), len(full), sum(full) / len(full) / 1e3,
+                  sum(steady) / len(steady) / 1e3))
+
+
+for wl in ("c2", "c3", "c3g", "c2_b65536", "c4", "c5", "rf_c3", "rf_tut", "rf_t512u", "rf_t512r", "rf_n16384", "gauss"):
+    trace_stats(wl)
+for name in ("latency.txt", "rf_alone.txt", "gauss_alone.txt"):
+    if os.path.exists(os.path.join(raw, name)):
+        shutil.copy(os.path.join(raw, name), os.path.join(out, "%s_%s" % (tag, name)))
+b0 = os.path.join(raw, "bench_default.json")
+if os.path.exists(b0) and os.path.getsize(b0):
+    shutil.copy(b0, os.path.join(out, "%s_bench_default.json" % tag))
+    d0 = json.loads(open(b0).read().strip().splitlines()[-1])
+    print("== bench default: c2", round(d0["value"]), "evals/s", round(d0["ms_per_step"], 3), "ms/step;",
+          " ".join("%s %s" % (k, round(d0[k]["value"])) for k in ("c3", "c4", "c5") if k in d0 and "value" in d0[k]))
+for wl in ("c2g", "c3g", "c2_b65536", "c2_b512", "c4_depth1", "c5_depth1"):
     b = os.path.join(raw, "bench_%s.json" % wl)
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(out, "%s_bench_%s.json" % (tag, wl)))
         d = json.loads(open(b).read().strip().splitlines()[-1])
-        print("== bench", wl, round(d["value"]), "evals/s", round(d["ms_per_step"], 3), "ms/step", d["kernel_ms_per_step"])
+        print("== bench", wl, round(d["value"]), d["unit"], round(d["ms_per_step"], 3), "ms/step")
 
 
 def counters(pattern):
@@ -67,7 +99,19 @@ def steady(v):
 
 
 summary = {}
-DOM = {"c2": ("swd_group_kernel", 4096), "c3": ("swd_group_kernel", 4096), "rf": ("rf_synth_kernel", 4096)}
+DOM = {"c2": ("swd_group_kernel", 4096), "c3": ("swd_group_kernel", 4096), "c2noboard": ("swd_group_kernel", 4096),
+       "rf_c3": ("rf_synth_kernel", 4096)}
+
+
+def kernel_ms(wl, dom):
+    """the dominant kernel's steady full-size duration in the kernel trace of the same workload [ms]"""
+    f = os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, wl))
+    if not os.path.exists(f):
+        return None
+    for r in csv.DictReader(open(f)):
+        if dom in r["Name"]:
+            return float(r["FullSizeSteadyAverageNs(after the first 6)"]) / 1e6
+    return None
 for wl, (dom, batch) in DOM.items():
     lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of the %s command of tools/profile_round.sh" % wl,
              "units: KB per dispatch (mean over the full-step dispatches); gfx950 correction: FETCH_SIZE x2 for wide coalesced reads "
@@ -90,17 +134,16 @@ for wl, (dom, batch) in DOM.items():
     open(os.path.join(out, "%s_pmc_hbm_%s.txt" % (tag, wl)), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     sq = counters("pmc_%s_SQ/**/*counter_collection.csv" % wl)
-    lines = ["rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU of the %s "
-             "command; per full-step dispatch, summed over XCDs; cycle counters in quad-cycles" % wl, ""]
+    for kern, cs in counters("pmc_%s_SQ2/**/*counter_collection.csv" % wl).items():
+        for k, v in cs.items():
+            sq[kern][k] = v
+    lines = ["rocprofv3 --pmc SQ_* (two passes) of the %s command; per full-size dispatch, summed over XCDs; cycle counters in quad-cycles" % wl, ""]
     for kern, cs in sq.items():
         if dom in kern:
             m = {k: steady(v) for k, v in cs.items()}
             for k in sorted(m):
                 lines.append("%-22s %16.0f" % (k, m[k]))
-            bj = os.path.join(raw, "bench_%s.json" % wl)
-            kms = None
-            if os.path.exists(bj):
-                kms = json.loads(open(bj).read().strip().splitlines()[-1])["kernel_ms_per_step"]["swd"]
+            kms = kernel_ms(wl, dom)
             if m.get("SQ_WAVE_CYCLES") and m.get("SQ_ACTIVE_INST_VALU"):
                 lines.append("VALU-active share of resident-wave cycles = %.3f" % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]))
             if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
@@ -111,6 +154,7 @@ for wl, (dom, batch) in DOM.items():
                 busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (kms * 1e-3 * NSIMD * CLOCK_HZ)
                 lines.append("VALU busy over the kernel = SQ_ACTIVE_INST_VALU x 4 / (%.3f ms x %d SIMDs x %.1f GHz) = %.3f" % (kms, NSIMD, CLOCK_HZ / 1e9, busy))
                 entry["valu_busy"] = busy
+                entry["kernel_ms"] = kms
             if m.get("SQ_INSTS_VALU"):
                 entry["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
                 entry["waves_per_launch"] = m.get("SQ_WAVES")
@@ -130,5 +174,19 @@ for kern, cs in sq.items():
             lines.append("   VALU-active share of resident-wave cycles = %.3f, active-lane fraction %.3f"
                          % (m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"], m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])))
 open(os.path.join(out, "%s_pmc_sq_b65536.txt" % tag), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+sq = counters("pmc_gauss_SQ/**/*counter_collection.csv")
+lines = ["SQ counters of the Gauss-law contraction (tools/gpu_gauss_perf.py 4096 1024), per dispatch", ""]
+for kern, cs in sq.items():
+    if "gauss_quad" in kern:
+        m = {k: steady(v) for k, v in cs.items()}
+        lines.append(kern[:90])
+        for k in sorted(m):
+            lines.append("   %-30s %16.0f" % (k, m[k]))
+        kms = kernel_ms("gauss", "gauss_quad")
+        if kms:
+            lines.append("   kernel %.4f ms (kernel trace, steady) -> 2 B n^2 / t = %.1f TFLOP/s = %.1f %% of the 78.6 TFLOP/s FP64 matrix peak"
+                         % (kms, 2.0 * 4096 * 1024 * 1024 / (kms * 1e-3) / 1e12, 2.0 * 4096 * 1024 * 1024 / (kms * 1e-3) / 1e12 / 78.6 * 100))
+open(os.path.join(out, "%s_pmc_sq_gauss.txt" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
