@@ -50,9 +50,11 @@ struct bh_engine {
     int rf_beside_prio = 0;                // BH_RF_BESIDE_PRIO env: issue priority (0..3) of the co-resident RF wavefronts
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
     SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
+    int last_swd_wpb = 2;                  // its wavefronts per workgroup
     int err_t_nt = -1, err_t_B = -1;       // layout for which err_t's untouched rows are known to be zero
     int swd_prio_low_now = 0;              // per call: what the next dispersion launch gets
     int swd_wpb_now = 2;                   // per call: wavefronts per workgroup of the next dispersion launch
+    int swd_wpb_default = 2;               // BH_SWD_WPB env (2 or 4; experiment switch)
     bool rf_coresident_now = false;        // per call: RF kernels run in the co-resident mode
     bool rf_gated_now = false;             // per call: the RF stream waits for the dispersion kernel's workgroups to be resident
     std::string err;
@@ -406,6 +408,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     ev_begin(e, 0, st);
     const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now);
     ev_end(e, 0, st);
+    e->last_swd_wpb = e->swd_wpb_now;
     if (lrc == 0 && e->started) e->started_expected += e->last_swd.workgroups;
     if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
     HIPCHK(e, hipGetLastError());
@@ -508,12 +511,17 @@ int bh_engine_create(int device, bh_engine **out)
     if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
     if (const char *g = std::getenv("BH_RF_LDS_BESIDE")) e->rf_lds_beside_swd = std::atoi(g);
     if (std::getenv("BH_RF_BESIDE")) e->rf_beside = true;
+    if (const char *g = std::getenv("BH_SWD_WPB")) e->swd_wpb_default = e->swd_wpb_now = (std::atoi(g) == 4) ? 4 : 2;
     if (const char *g = std::getenv("BH_RF_BESIDE_PRIO")) e->rf_beside_prio = std::atoi(g) & 3;
     if (const char *g = std::getenv("BH_SWD_PRIO_LOW")) e->swd_prio_low = std::atoi(g) != 0 ? 1 : 0;
     {   // the counter the dispersion kernel's workgroups bump at start; hipStreamWaitValue32 polls it from the RF stream
         int can = 0;
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
         if (std::getenv("BH_NO_STARTED")) can = 0; // experiment switch
+        // rocprofv3 --pmc (counter collection) runs the dispatches of ALL queues one at a time; the RF stream's wait
+        // packet then never sees the dispersion kernel start (measured: bench.py --workload c3 hangs under --pmc, runs
+        // under --kernel-trace).  The gate is a scheduling aid only: off in that mode.
+        if (std::getenv("ROCPROF_COUNTER_COLLECTION")) can = 0;
         // plain device memory: the wait packet polls it just as well, and atomics on signal memory
         // (hipMallocSignalMemory) cost the dispersion kernel 1 ms per launch (976 workgroups, one atomic each)
         if (can && hipMalloc((void **)&e->started, 8) != hipSuccess) e->started = nullptr;
@@ -642,6 +650,22 @@ int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family
     if (total_ms) *total_ms = tot;
     if (family_ms)
         for (int f = 0; f < 3; ++f) family_ms[f] = fam[f];
+    return BH_OK;
+}
+
+int bh_timing_steps(bh_engine *e, int max, double *step_ms, int *n)
+{
+    if (!e || !step_ms || !n || max < 0) return BH_EINVAL;
+    int k = 0;
+    for (size_t i = 0; i < e->ncalls && k < max; ++i, ++k) {
+        bh_engine::EventSet &s = e->evsets[i];
+        HIPCHK(e, hipEventSynchronize(s.ev[7]));
+        float ms = 0.f;
+        if (i + 1 < e->ncalls) HIPCHK(e, hipEventElapsedTime(&ms, s.ev[6], e->evsets[i + 1].ev[6]));
+        else HIPCHK(e, hipEventElapsedTime(&ms, s.ev[6], s.ev[7]));
+        step_ms[k] = ms;
+    }
+    *n = k;
     return BH_OK;
 }
 
@@ -892,7 +916,8 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     call_begin(e, st);
     // per-target failure flags [nt][B]: the dispersion kernels write every entry of their target's row on every call,
     // nothing writes the rows of the other targets -- they are zeroed once per (nt, B) layout, not once per call
-    if (e->err_t_nt != nt || e->err_t_B != B) {
+    static const bool always_zero = std::getenv("BH_ERR_MEMSET") != nullptr; // experiment switch
+    if (always_zero || e->err_t_nt != nt || e->err_t_B != B) {
         HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
         e->err_t_nt = nt;
         e->err_t_B = B;
@@ -951,11 +976,11 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         e->started_expected = 0;
     }
     e->swd_prio_low_now = want_beside ? e->swd_prio_low : 0;
-    e->swd_wpb_now = want_beside ? 4 : 2;  // (two copies of the libm tables per CU instead of four: LDS room for an RF workgroup)
+    e->swd_wpb_now = want_beside ? 4 : e->swd_wpb_default; // (4: two copies of the libm tables per CU instead of four: LDS room for an RF workgroup)
     e->last_swd = SwdLaunchInfo{};
     rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs);
     e->swd_prio_low_now = 0;
-    e->swd_wpb_now = 2;
+    e->swd_wpb_now = e->swd_wpb_default;
     if (rc) return rc;
     e->rf_coresident_now = false;
     e->rf_gated_now = false;
@@ -973,7 +998,12 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         if (dbg)
             std::fprintf(stderr, "[bh] fused call B=%d: dispersion launch %u workgroups, %ld wavefronts, %zu B LDS per workgroup; RF LDS %zu B; "
                          "co-resident RF: %d\n", B, e->last_swd.workgroups, e->last_swd.waves, e->last_swd.lds, rf_lds, (int)e->rf_coresident_now);
-        HIPCHK(e, hipStreamWaitValue32(e->aux, e->started, e->started_expected, hipStreamWaitValueGte, 0xffffffffu));
+        // all workgroups of the launch, or -- a launch of more workgroups than the chip holds at once (2048 wavefronts) --
+        // as many as can be resident together (the rest start as others end: waiting for them would be waiting for the kernel)
+        const unsigned resident = 2048u / (unsigned)(e->last_swd.lds > 0 && e->last_swd.workgroups > 0 ? (e->last_swd_wpb > 0 ? e->last_swd_wpb : 2) : 2);
+        const unsigned need = e->last_swd.workgroups < resident ? e->last_swd.workgroups : resident;
+        HIPCHK(e, hipStreamWaitValue32(e->aux, e->started, e->started_expected - e->last_swd.workgroups + need, hipStreamWaitValueGte,
+                                       0xffffffffu));
     }
     for (int t = 0; t < nt; ++t) {
         TargetHost &T = e->targets[(size_t)t];

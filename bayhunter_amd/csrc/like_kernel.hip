@@ -66,9 +66,20 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
                 sw += acc * dl[i];
             }
         }
-        s0 = block_sum(s0, red);
-        if (T.law == 2) s1 = block_sum(s1, red);
-        if (T.law == 1 || T.law == 3) sw = block_sum(sw, red);
+        if (n <= 64 && !(T.law == 3 && T.quad == nullptr)) {
+            // a short target (a dispersion curve beside a long receiver function): its samples all sit in the first
+            // wavefront, the other three would only add zeros -- no barrier (same bits as block_sum); only thread 0's
+            // values are used below
+            for (int off = 32; off > 0; off >>= 1) s0 += __shfl_xor(s0, off);
+            if (T.law == 2)
+                for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+            if (T.law == 1 || T.law == 3)
+                for (int off = 32; off > 0; off >>= 1) sw += __shfl_xor(sw, off);
+        } else {
+            s0 = block_sum(s0, red);
+            if (T.law == 2) s1 = block_sum(s1, red);
+            if (T.law == 1 || T.law == 3) sw = block_sum(sw, red);
+        }
         const double s2 = sigma * sigma;
         double phi, logdet = (2.0 * n) * log(sigma);
         if (T.law == 0) {

@@ -108,6 +108,7 @@ def load_library():
     L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
     L.bh_timing_collect.argtypes = [vp, C.POINTER(C.c_int), _d, _d]
+    L.bh_timing_steps.argtypes = [vp, C.c_int, _d, C.POINTER(C.c_int)]
     L.bh_last_neval.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bh_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.bh_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
@@ -126,7 +127,7 @@ def load_library():
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
     for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
-                 "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                 "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
@@ -138,7 +139,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
                     "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
-                    "bh_timing_reset", "bh_timing_collect", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
+                    "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
 
@@ -234,6 +235,14 @@ class Engine(object):
         fam = (C.c_double * 3)()
         self._check(self._L.bh_timing_collect(self._h, C.byref(n), C.byref(tot), fam))
         return n.value, tot.value, {"swd": fam[0], "rf": fam[1], "like": fam[2]}
+
+    def timing_steps(self, maxn=4096):
+        """Per-call times [ms] of the timed calls since timing_reset(): start of call i -> start of call i+1 (the last:
+        its own span), from the engine's own events."""
+        out = np.zeros(int(maxn))
+        n = C.c_int(0)
+        self._check(self._L.bh_timing_steps(self._h, int(maxn), out.ctypes.data_as(_d), C.byref(n)))
+        return out[:n.value].copy()
 
     def last_timing(self):
         """(total_ms, families) of the calls since the last reset, then resets."""

@@ -53,7 +53,7 @@ FP64_VALU_PEAK_TF = 78.6    # CDNA4 FP64 vector peak; this path
 # flop-equivalents per layer-propagator step: Rayleigh ~320, Love ~65
 FLOP_PER_LPS = {2: 320.0, 1: 65.0}
 NPOOL = 4                   # distinct batches rotated through the steps
-CLOCK_WARMUP_MS = 150.0     # untimed launches of the step before the --warmup steps (clock ramp of an idle GPU)
+CLOCK_WARMUP_MS = float(os.environ.get("BH_BENCH_CLOCK_WARMUP_MS", "150"))   # untimed launches of the step before the --warmup steps (clock ramp of an idle GPU)
 RF_CUT_WA = 12.5132         # csrc/rf_kernel.hip: w/a beyond which the Gauss low-pass is below 1e-17
 RF_FLOP_PER_LAYER_STEP = 600.0   # flop-equivalents of one layer of the reflectivity recursion for one frequency
 
@@ -399,7 +399,8 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     observed_data(eng, spec, truth, nrs)
     eng.set_targets(spec)
     eng._owner = None
-    eng.set_model_order(sort_by_depth=False)      # the batches of this workload are uniform (L layers each): nothing to sort
+    if os.environ.get("BH_BENCH_SORT", "0") != "1":   # (experiment switch: keep the on-device sort)
+        eng.set_model_order(sort_by_depth=False)  # the batches of this workload are uniform (L layers each): nothing to sort
     nt = len(spec)
 
     def to_dev(a):
@@ -442,19 +443,19 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     counters = eng.debug_counters() if args.warmup > 0 else None   # evaluations / layer steps of one step (last warm-up)
     eng.set_instrumentation(timing=True, counting=False)
     eng.timing_reset()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    evs[0].record()
     for i in range(args.steps):
         step(args.warmup + i)
-        evs[i + 1].record()                # (the kernels are launched on torch's current stream: these events see them)
     fence()
     elapsed = time.perf_counter() - t0
     ncalls, tot_ms, fam_ms = eng.timing_collect()
+    # per-step times from the engine's own events (start of a call -> start of the next); NOT from further events on the
+    # launch stream: a marker between two steps changed how the next step's two lane-kernel launches pair up on the SIMDs
+    # (8.1 -> 10.6 ms per step at B = 16 384; no effect on the one-launch group kernel of B = 4096)
+    per_step = eng.timing_steps()
     eng.set_instrumentation(timing=False, counting=False)
     eng.set_model_order(sort_by_depth=True)
-    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
     n_failed = int((d_err != 0).sum().item())
     finite = bool(torch.isfinite(d_logL).all().item())
     rank_ms = [elapsed / args.steps * 1e3]
@@ -511,7 +512,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
                    "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
                    "parallelism": "models sharded one batch per GPU, no data-path collective"},
         "ms_per_step_stats": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max()),
-                              "source": "HIP events on the launch stream around each of the K timed steps (rank 0)"},
+                              "source": "the engine's HIP events on the launch stream: start of a step -> start of the next (last: its own span), rank 0"},
         "clock_warmup": {"ms": CLOCK_WARMUP_MS, "steps": n_clock, "note": "untimed launches of the same step before the --warmup steps"},
         "roofline": roof,
         "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},

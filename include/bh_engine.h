@@ -290,6 +290,11 @@ int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
 int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
 int bh_timing_reset(bh_engine *e);
 int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3]);
+/* Per-call timing of the calls since bh_timing_reset(), from the same events: step_ms[i] = start of call i -> start of
+ * call i+1 (back-to-back calls: one "step" each, gaps included), for the last call its own span.  Writes at most
+ * `max` entries and returns their number in *n.  (No further events: a marker recorded on the launch stream between
+ * two calls changes how the next call's two lane-kernel launches pair up on the SIMDs -- 8.1 -> 10.6 ms at B = 16 384.) */
+int bh_timing_steps(bh_engine *e, int max, double *step_ms, int *n);
 int bh_last_neval(bh_engine *e, uint64_t *neval);
 /* raw counter block of the last counted call: [0] secular evaluations, [1..3] / [4..6] wave-cycles per phase
  * (development aid), [7] wavefronts, [8] / [9] evaluations of the Rayleigh / Love targets, [10] / [11] their

@@ -66,6 +66,17 @@ def test_noise_law_selection_rules():
     assert t_rf.valuation.corr_inv.shape == (201, 201)
 
 
+def test_speculation_depth_stays_in_the_latency_regime():
+    """device_chains.auto_spec_depth: chains x (2^d - 1) evaluations per launch within the budget, 1 <= d <= 7."""
+    from bayhunter_amd.device_chains import auto_spec_depth
+    assert [auto_spec_depth(c, 1024) for c in (1, 8, 9, 64, 68, 146, 341, 342, 4096)] == [7, 7, 6, 4, 4, 3, 2, 1, 1]
+    assert auto_spec_depth(8, 512) == 6 and auto_spec_depth(8, 0) == 1 and auto_spec_depth(64, 2048) == 5
+    for c in (1, 3, 8, 64, 500):
+        d = auto_spec_depth(c, 1024)
+        assert d == 7 or c * ((1 << (d + 1)) - 1) > 1024
+        assert d == 1 or c * ((1 << d) - 1) <= 1024
+
+
 def test_law_is_read_back_from_the_installed_accessor():
     """SingleChain.py:159-205 assigns target.get_covariance; SingleTarget.law() identifies it (host logic only)."""
     import copy

@@ -5,14 +5,23 @@
 # shape per pass) / the Gauss-law contraction / the B = 65536 throughput regime; and, in SEPARATE passes (never
 # together with a trace domain), the HBM counters (FETCH_SIZE / WRITE_SIZE) and the SQ activity counters of the c2, c3
 # and RF-alone (c3 shape) commands, plus the c2 HBM passes with the progress board off (attribution of its traffic).
+# (Under --pmc the engine runs without its start gate between the dispersion kernel and the RF stream -- counter
+# collection serialises the dispatches of all queues, see bh_engine_create -- so the c3 counter passes show the RF kernels'
+# own figures, not their placement beside the dispersion kernel.)
 # Raw output lands in gpurun_out/<TAG>/; tools/summarize_profiles.py condenses it into the files kept under profiles/.
+# A second argument selects sections (default "bench trace pmc"): e.g. `bash tools/profile_round.sh r03 "bench trace"`.
 set -u
 TAG=${1:-r03}
+SECTIONS=${2:-"bench trace pmc"}
+has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
+stamp() { echo "[profile_round] $(date +%T) $*"; }
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 NB="--no-cpu-baseline --no-parity"
+if has bench; then
+stamp "bench lines"
 python $R/bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python $R/bench.py --workload c2g --no-cpu-baseline > "$OUT/bench_c2g.json" 2> "$OUT/bench_c2g.err"
 python $R/bench.py --workload c3g --no-cpu-baseline > "$OUT/bench_c3g.json" 2> "$OUT/bench_c3g.err"
@@ -23,8 +32,11 @@ python $R/bench.py --workload c5 --steps 700 --warmup 300 --spec-depth 1 > "$OUT
 python $R/tools/gpu_latency.py > "$OUT/latency.txt" 2>&1
 for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
 for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
+fi
 cd /tmp
 TR="rocprofv3 --kernel-trace --stats --output-format csv"
+if has trace; then
+stamp "kernel traces"
 $TR -d "$OUT/trace_c2" -o t -- python $R/bench.py --workload c2 --steps 10 --warmup 2 $NB > "$OUT/trace_c2.log" 2>&1
 $TR -d "$OUT/trace_c3" -o t -- python $R/bench.py --workload c3 --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3.log" 2>&1
 $TR -d "$OUT/trace_c3g" -o t -- python $R/bench.py --workload c3g --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3g.log" 2>&1
@@ -35,6 +47,9 @@ for sh in c3 tut t512u t512r n16384; do
   $TR -d "$OUT/trace_rf_$sh" -o t -- python $R/tools/gpu_rf_perf.py $sh 20 > "$OUT/trace_rf_$sh.log" 2>&1
 done
 $TR -d "$OUT/trace_gauss" -o t -- python $R/tools/gpu_gauss_perf.py 4096 1024 20 > "$OUT/trace_gauss.log" 2>&1
+fi
+if has pmc; then
+stamp "counter passes"
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_SMEM"
 SQ2="SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"
 PM="rocprofv3 --output-format csv"
@@ -56,6 +71,8 @@ $PM --pmc $SQ -d "$OUT/pmc_rf_c3_SQ" -o pmc -- python $R/tools/gpu_rf_perf.py c3
 $PM --pmc $SQ2 -d "$OUT/pmc_rf_c3_SQ2" -o pmc -- python $R/tools/gpu_rf_perf.py c3 5 > "$OUT/pmc_rf_c3_SQ2.log" 2>&1
 $PM --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_gauss_SQ" -o pmc -- python $R/tools/gpu_gauss_perf.py 4096 1024 5 > "$OUT/pmc_gauss_SQ.log" 2>&1
 $PM --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d "$OUT/pmc_b65536_SQ" -o pmc -- python $R/bench.py --workload c2 --batch 65536 --steps 3 --warmup 1 $NB > "$OUT/pmc_b65536_SQ.log" 2>&1
+fi
+stamp "summaries"
 cd $R
 python tools/summarize_profiles.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
