@@ -133,6 +133,7 @@ struct RfKernelArgs {
     int ldr;
     int lds_min;   // lower bound of the synthesis kernel's LDS request in bytes (0 = what the trace needs), see bh_engine.hip
     int no_realc;  // experiment switch: 1 = always the general (complex-coefficient) recursion
+    int coef_small; // 1: the 96-register build of the coefficient kernel (fused call: resident beside the dispersion wavefronts)
     int no_rot;    // experiment switch: 1 = no rotation of the bins over a workgroup's wavefronts
     int beside;    // > 0: the 96-register build that runs beside two dispersion wavefronts per SIMD, at issue priority beside - 1
 };

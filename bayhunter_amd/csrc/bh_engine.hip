@@ -437,6 +437,7 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     // after every dispersion wavefront is resident and only take what finished wavefronts have freed)
     a.lds_min = (beside_swd && !e->rf_coresident_now && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
     a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
+    a.coef_small = (beside_swd && e->rf_gated_now && std::getenv("BH_RF_COEF_BIG") == nullptr) ? 1 : 0;
     ev_begin(e, 1, st);
     const int lrc = bh_launch_rf(a, st);
     ev_end(e, 1, st);

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void rf_coef_kernel(RfKernelArgs A)
 // Same operations per layer: the depth of a layer's top is the reference's running sum, formed in its order; the
 // direct-wave delay is summed by the model's first lane in layer order.  (The Nyquist bin is the synthesis kernel's.)
 template <int LP>
-__global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
+__device__ __forceinline__ void rf_coef_layers_body(const RfKernelArgs &A)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int ibr = t / LP, l = t % LP, lane = threadIdx.x & 63, lbase = lane - l;
@@ -627,6 +627,21 @@ __global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
         rec[4] = m11; rec[5] = m12; rec[6] = m21; rec[7] = m22;
         rec[REC_HEAD + 40 * (size_t)Lmax] = (imall + imag_mass(ru) == 0.0 && nfall == 0.0) ? 1.0 : 0.0;
     }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void rf_coef_layers_kernel(RfKernelArgs A)
+{
+    rf_coef_layers_body<LP>(A);
+}
+// The same with at most 96 registers (a few spilled): in the fused call the coefficient kernel is dispatched behind
+// the start gate, when two dispersion wavefronts of 208 registers sit on every SIMD -- the 124-register build could
+// only start where such wavefronts have ended (3.4 ms later), right before the synthesis kernel that waits for it; this
+// one becomes resident beside them and is long done when the first synthesis workgroup finds room.
+template <int LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rf_coef_layers_kernel_small(RfKernelArgs A)
+{
+    rf_coef_layers_body<LP>(A);
 }
 
 // Spectrum of one model into LDS, then the inverse real FFT there:
@@ -784,7 +799,11 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
             allowed = BH_RF_MAX_LDS;
         }
     }
-    if (a.Lmax <= 16)
+    if (a.Lmax <= 16 && a.coef_small)
+        hipLaunchKernelGGL((rf_coef_layers_kernel_small<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    else if (a.Lmax <= 32 && a.coef_small)
+        hipLaunchKernelGGL((rf_coef_layers_kernel_small<32>), dim3((a.B + 7) / 8), dim3(256), 0, stream, a);
+    else if (a.Lmax <= 16)
         hipLaunchKernelGGL((rf_coef_layers_kernel<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     else if (a.Lmax <= 32)
         hipLaunchKernelGGL((rf_coef_layers_kernel<32>), dim3((a.B + 7) / 8), dim3(256), 0, stream, a);
