@@ -385,7 +385,7 @@ def rf_roofline(eng, spec, d_batch, B, L, dev, reps=20):
             "binding": {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (flop-equivalents)",
                         "frac": tf / FP64_VALU_PEAK_TF, "flop_equivalents_per_layer_step": RF_FLOP_PER_LAYER_STEP,
                         "valu_busy": pmc.get("valu_busy"),
-                        "note": "computed bins only (the bins the Gauss low-pass puts below 1e-30 are not computed, rf_kernel.hip)"},
+                        "note": "computed bins only (the bins the Gauss low-pass puts below 1e-17 are not computed, rf_kernel.hip)"},
             "rf_per_s": B / (ms * 1e-3)}
 
 
