@@ -98,18 +98,34 @@ __device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, 
 enum { MV_VS = 0, MV_Z = 1, MV_BIRTH = 2, MV_DEATH = 3, MV_NOISE = 4, MV_VPVS = 5 };
 __device__ __forceinline__ int par_index(int mv) { return mv <= 1 ? mv : (mv <= 3 ? 2 : mv - 1); } // PAR_MAP
 
-// A chain's model parameters in registers / scratch
+// A chain's model parameters: n, vp/vs and pointers to the arrays (vs, z: nuclei; noise; h: layer thicknesses), which live
+// in the lane's private memory (lane = chain kernel) or in the node's LDS record (window kernel) -- the arithmetic on
+// them is the same text either way.
 struct Params {
     int n;
-    double vs[BH_CHAIN_MAXLAYERS + 1], z[BH_CHAIN_MAXLAYERS + 1];
     double vpvs;
-    double noise[2 * BH_MAX_TARGETS];
+    double *vs, *z, *noise, *h;
 };
+// LDS record of one tree node (doubles): [0] n  [1] valid  [2] vp/vs  [3 .. 3+2nt) noise  then vs[ML+1], z[ML+1], h[ML+1]
+__host__ __device__ inline int node_rec_doubles(int nt, int ML) { return 3 + 2 * nt + 3 * (ML + 1); }
 
 // The state a tree node's proposal starts from: the proposal of the nearest ancestor that is entered through
 // its "accepted" edge (and was valid), else the chain's current state.  node < 0: the chain's current state.
-__device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, int c, int from_node, Params &P)
+// lds_from: the LDS record of `from_node` when the window kernel keeps the tree there (same values as the global copy)
+__device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, int ML, int c, int from_node, Params &P,
+                          const double *lds_from = nullptr)
 {
+    if (from_node >= 0 && lds_from != nullptr) {
+        P.n = (int)lds_from[0];
+        P.vpvs = lds_from[2];
+        for (int i = 0; i < 2 * nt; ++i) P.noise[i] = lds_from[3 + i];
+        const double *fv = lds_from + 3 + 2 * nt, *fz = fv + (ML + 1);
+        for (int i = 0; i < P.n; ++i) {
+            P.vs[i] = fv[i];
+            P.z[i] = fz[i];
+        }
+        return;
+    }
     if (from_node < 0) {
         P.n = S.n[c];
         for (int i = 0; i < P.n; ++i) {
@@ -130,7 +146,7 @@ __device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, in
     }
 }
 
-__device__ void layer_thicknesses(const Params &P, double *h)
+__device__ __forceinline__ void layer_thicknesses(const Params &P, double *h)
 {
     double prev = 0.0;
     for (int i = 0; i + 1 < P.n; ++i) {
@@ -143,8 +159,9 @@ __device__ void layer_thicknesses(const Params &P, double *h)
 
 // One proposal (SingleChain.py:246-420, :511-556; Models.py:26-52): from the state of `from_node`, with the draws of
 // iteration `iiter`, into column node*C + c of the proposal arrays (leading dimension ldp).
-__device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S, int C, size_t ldp, int c, int iiter, int k,
-                             int from_node, int node)
+// `P` brings the storage; `lds_from` as in load_base.
+__device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S, int C, size_t ldp, int c, int iiter,
+                                             int k, int from_node, int node, Params &P, const double *lds_from, bool *valid_out)
 {
     const int ML = cfg.maxlayers, nt = cfg.nt;
     const Draws d = get_draws(cfg, S, c, C, iiter, k);
@@ -167,8 +184,7 @@ __device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S
     const int mv = moves[mi];
 
     // ---- proposal -----------------------------------------------------------------------------------
-    Params P;
-    load_base(S, C, ldp, nt, c, from_node, P);
+    load_base(S, C, ldp, nt, ML, c, from_node, P, lds_from);
     double *vs = P.vs, *z = P.z, *noise = P.noise;
     int n = P.n;
     double vpvs = P.vpvs;
@@ -250,7 +266,7 @@ __device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S
     P.n = n;
     P.vpvs = vpvs;
     // ---- nuclei -> layers (Models.py:39-52), validity with the CURRENT vp/vs (:330-392) ------------
-    double h[BH_CHAIN_MAXLAYERS + 1];
+    double *h = P.h;
     layer_thicknesses(P, h);
     if (valid && (mv <= MV_DEATH)) {
         const int layermodel = n - 1;
@@ -273,11 +289,14 @@ __device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S
     S.valid[col] = valid ? 1 : 0;
     S.dvs2[col] = dvs2;
     if (!valid) { // keep the evaluate batch well-formed: it sees the unchanged model, result ignored
-        load_base(S, C, ldp, nt, c, from_node, P);
+        load_base(S, C, ldp, nt, ML, c, from_node, P, lds_from);
         layer_thicknesses(P, h);
         n = P.n;
         vpvs = P.vpvs;
     }
+    P.n = n;
+    P.vpvs = vpvs;
+    *valid_out = valid;
     S.pn[col] = n;
     S.pvpvs[col] = vpvs;
     for (int i = 0; i < n; ++i) {
@@ -291,7 +310,9 @@ __device__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S
         if (cfg.mantle_vs > 0.0 && vs[i] >= cfg.mantle_vs) deep = true;
         S.lay_h[(size_t)i * ldp + col] = h[i];
         S.lay_vs[(size_t)i * ldp + col] = vs[i];
-        S.lay_vp[(size_t)i * ldp + col] = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
+        const double vpi = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
+        S.lay_vp[(size_t)i * ldp + col] = vpi;
+        if (S.lay_rho != nullptr) S.lay_rho[(size_t)i * ldp + col] = vpi * 0.32 + 0.77; // as rho_from_vp_kernel (Targets.py:319)
     }
     S.lay_n[col] = n;
 }
@@ -301,19 +322,32 @@ __global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int 
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    propose_node(cfg, S, C, (size_t)C, c, iiter, 0, -1, 0);
+    double vs[BH_CHAIN_MAXLAYERS + 1], z[BH_CHAIN_MAXLAYERS + 1], h[BH_CHAIN_MAXLAYERS + 1], noise[2 * BH_MAX_TARGETS];
+    Params P;
+    P.vs = vs; P.z = z; P.h = h; P.noise = noise;
+    bool valid;
+    propose_node(cfg, S, C, (size_t)C, c, iiter, 0, -1, 0, P, nullptr, &valid);
 }
 
 // Speculative window: T = 2^(depth-1) lanes per chain (64 / T chains per single-wavefront workgroup); level k of the
-// tree is proposed by the first 2^k lanes of a chain, the levels one after the other (a node reads the proposal of
-// an ancestor written in an earlier level: __syncthreads orders them).
-__global__ void __launch_bounds__(64) chain_propose_window_kernel(bh_chain_config cfg, bh_chain_state S, int C, size_t ldp,
+// tree is proposed by the first 2^k lanes of a chain, the levels one after the other.  The tree lives in LDS while it
+// is built (one record per node, node_rec_doubles): a node starts from its ancestor's record and works in its own --
+// no private arrays (dynamic indexing would put them in scratch memory) and no wait for global stores between the
+// levels (round 3, first form: state through global memory and __syncthreads -- 128 us per launch at depth 7, 7 % of a
+// c4 launch).  A workgroup is one wavefront: its LDS operations execute in order, the barrier only pins the compiler.
+__global__ __launch_bounds__(64) void chain_propose_window_kernel(bh_chain_config cfg, bh_chain_state S, int C, size_t ldp,
                                                                    int iiter, int depth)
 {
+    extern __shared__ __align__(16) double tree[];
     const int T = 1 << (depth - 1);
     const int per_wg = 64 / T;
-    const int c = blockIdx.x * per_wg + (int)threadIdx.x / T;
+    const int N = (1 << depth) - 1;
+    const int slot = (int)threadIdx.x / T;
+    const int c = blockIdx.x * per_wg + slot;
     const int p = (int)threadIdx.x % T;
+    const int nt = cfg.nt, ML = cfg.maxlayers;
+    const int RS = node_rec_doubles(nt, ML) | 1; // odd stride: neighbouring nodes start in different banks
+    double *mine = tree + (size_t)slot * N * RS;  // this chain's records
     for (int k = 0; k < depth; ++k) {
         if (c < C && p < (1 << k)) {
             const int node = (1 << k) - 1 + p;
@@ -321,14 +355,26 @@ __global__ void __launch_bounds__(64) chain_propose_window_kernel(bh_chain_confi
             int from = -1;
             for (int j = node; j > 0; j = (j - 1) >> 1) {
                 const int parent = (j - 1) >> 1;
-                if ((j & 1) == 0 && S.valid[(size_t)parent * C + c]) {
+                if ((j & 1) == 0 && mine[(size_t)parent * RS + 1] != 0.0) {
                     from = parent;
                     break;
                 }
             }
-            propose_node(cfg, S, C, ldp, c, iiter + k, k, from, node);
+            double *rec = mine + (size_t)node * RS;
+            Params P;
+            P.noise = rec + 3;
+            P.vs = rec + 3 + 2 * nt;
+            P.z = P.vs + (ML + 1);
+            P.h = P.z + (ML + 1);
+            bool valid;
+            propose_node(cfg, S, C, ldp, c, iiter + k, k, from, node, P, from >= 0 ? mine + (size_t)from * RS : nullptr, &valid);
+            rec[0] = (double)P.n;
+            rec[1] = valid ? 1.0 : 0.0;
+            rec[2] = P.vpvs;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -427,7 +473,16 @@ int bh_chain_propose_window(void *stream, const bh_chain_config *cfg, const bh_c
         hipLaunchKernelGGL(chain_propose_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, iiter);
     } else {
         const int per_wg = 64 >> (depth - 1);
-        hipLaunchKernelGGL(chain_propose_window_kernel, dim3((C + per_wg - 1) / per_wg), dim3(64), 0, (hipStream_t)stream, *cfg,
+        const size_t lds = (size_t)per_wg * ((1 << depth) - 1) * (node_rec_doubles(cfg->nt, cfg->maxlayers) | 1) * sizeof(double);
+        if (lds > 160 * 1024) return BH_EUNSUPPORTED;
+        if (lds > 64 * 1024) {
+            static bool big = false;
+            if (!big && hipFuncSetAttribute(reinterpret_cast<const void *>(chain_propose_window_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return BH_EHIP;
+            big = true;
+        }
+        hipLaunchKernelGGL(chain_propose_window_kernel, dim3((C + per_wg - 1) / per_wg), dim3(64), lds, (hipStream_t)stream, *cfg,
                            *state, C, (size_t)ld, iiter, depth);
     }
     return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;

@@ -179,7 +179,7 @@ class DeviceChains(object):
         ld = self.ld                                      # node j of chain c in column j*C + c
         for k in ("pn", "move", "valid", "lay_n"):
             t[k] = torch.zeros(ld, **i32)
-        for k in ("pvs", "pz", "lay_h", "lay_vp", "lay_vs"):
+        for k in ("pvs", "pz", "lay_h", "lay_vp", "lay_vs", "lay_rho"):
             t[k] = torch.zeros((ML, ld), **f64)
         t["pvpvs"], t["dvs2"] = torch.zeros(ld, **f64), torch.zeros(ld, **f64)
         t["pnoise"] = torch.zeros((ld, 2 * nt), **f64)
@@ -227,7 +227,7 @@ class DeviceChains(object):
         B = Cn * ((1 << w) - 1)
         e.chain_propose_window(self.cfg, self.state, Cn, self.iiter, w, self.ld)
         e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
-                             t["lay_vs"].data_ptr(), None, self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
+                             t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
                              self.mis.data_ptr(), self.err.data_ptr())
         e.chain_accept_window(self.cfg, self.state, Cn, self.iiter, w, self.ld, self.logL.data_ptr(), self.mis.data_ptr())
         self.iiter += w

@@ -64,7 +64,7 @@ class ChainConfig(C.Structure):
 
 CHAIN_STATE_FIELDS = ("n", "vs", "z", "vpvs", "noise", "like", "misfits", "propdist", "proposed", "accepted", "naccepted",
                       "beta", "pn", "move", "valid", "pvs", "pz", "pvpvs", "pnoise", "dvs2", "lay_n", "lay_h", "lay_vp", "lay_vs",
-                      "inject")
+                      "inject", "lay_rho")
 
 
 class ChainState(C.Structure):
@@ -131,7 +131,7 @@ def load_library():
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 3:
+    if L.bh_abi_version() != 4:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 3
+#define BH_ABI_VERSION 4
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -246,6 +246,8 @@ typedef struct bh_chain_state {
     int32_t *lay_n;    /* [C] layers incl. half space */
     double *lay_h, *lay_vp, *lay_vs; /* [maxlayers][C] */
     const double *inject; /* NULL or [6][C] */
+    double *lay_rho;   /* NULL or [maxlayers][C]: density of the proposal's layers, 0.32 vp + 0.77 (Targets.py:319), so that
+                          bh_evaluate_batch need not derive it in a launch of its own */
 } bh_chain_state;
 
 int bh_chain_propose(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter);
