@@ -81,6 +81,7 @@ struct SwdTarget {
     const double *periods;
     double *vel;  // [B][ldv] (+ column offset already applied)
     int32_t *err; // [B]
+    const int32_t *perm; // optional: this target's own processing order (bh_launch_pair_order); else SwdMultiArgs::perm
 };
 struct SwdMultiArgs {
     int B, Lmax, ntargets;
@@ -107,12 +108,33 @@ struct SwdMultiArgs {
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
 double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, int *G, int *look);
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode);
+// Work space of the SIMD-pairing order (swd_kernel.hip: pair_order_kernel; swd_group_kernel.hip: the launcher).  The
+// dispersion kernel's time is that of its slowest SIMD, a SIMD's time follows the SUM of the root-search lengths of the
+// two wavefronts it holds, and which wavefronts of a launch share a SIMD is a fixed function of their grid index; so the
+// models are dealt to the wavefronts by PREDICTED search length such that every SIMD gets a long and a short wavefront
+// and the SIMDs that hold one wavefront only get the longest.  Scheduling only: per-model results do not depend on it.
+struct SwdPairWork {
+    int ncu = 0;                      // compute units of the device (the placement rule below is per CU)
+    int32_t *perm[2] = {nullptr, nullptr};      // device, [B] each: processing order of target 0 / 1
+    int32_t *slot_rank[2] = {nullptr, nullptr}; // device, [wavefronts of the target]: rank of the wavefront's load (0 = longest models)
+    int cap_perm = 0, cap_rank[2] = {0, 0};
+    int key_n0 = -1, key_n1 = -1, key_wpb = -1; // geometry the slot_rank tables were built for
+};
+struct PairOrderTarget {
+    int mpw, nwaves;          // models per wavefront, wavefronts of the target
+    const int32_t *slot_rank; // [nwaves - 1]: load rank of every wavefront but the last (which may be partly filled)
+    int32_t *perm;            // out [B]
+};
+bool bh_pair_order_fits(int B);
+void bh_launch_pair_order(int B, int Lmax, const int32_t *nlay, const double *vs, ptrdiff_t sl, ptrdiff_t sb, int nt,
+                          const PairOrderTarget *tg, hipStream_t stream);
 struct SwdLaunchInfo {
     unsigned workgroups; // of the launch (what SwdMultiArgs::started is advanced by)
     long waves;          // wavefronts that do work
     size_t lds;          // bytes per workgroup
 };
-int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2);
+int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
+                        SwdPairWork *pair = nullptr);
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

@@ -49,6 +49,8 @@ struct bh_engine {
     bool rf_beside = false;                // BH_RF_BESIDE env turns the co-resident mode on (measured slower, see bh_evaluate_batch)
     int rf_beside_prio = 0;                // BH_RF_BESIDE_PRIO env: issue priority (0..3) of the co-resident RF wavefronts
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
+    SwdPairWork pairwork{};                // SIMD-pairing order of the group kernel (bh_device.h)
+    bool no_pair = false;                  // BH_SWD_NO_PAIR env: order by depth only (A/B testing)
     SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
     int last_swd_wpb = 2;                  // its wavefronts per workgroup
     int err_t_nt = -1, err_t_B = -1;       // layout for which err_t's untouched rows are known to be zero
@@ -317,7 +319,29 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     // processing order: deepest models first, wavefronts of (nearly) one depth
     const int32_t *perm = nullptr, *split = nullptr;
     int Lcut = Lmax;
-    if (B > 1 && !e->no_order && !e->as_given) {
+    // One depth class, lanes per model > 1: the launcher orders the models itself, by predicted search length and paired
+    // over the SIMDs (SwdPairWork); mixed depths are ordered by depth there as well.
+    // Measured (bench.py c2, B = 2048 ... 4096, same session with / without): -3 % at 4096 and -4 % at 3800, where the
+    // launch nearly fills two wavefronts per SIMD and the Rayleigh wavefronts (look-ahead 2) outnumber the Love ones
+    // (trials inside the lane groups) 7 : 3; neutral at 3500; +2.5 % at 2048 / 3072, where the planner gives both targets
+    // the same look-ahead and every SIMD holds one Rayleigh and one Love wavefront (why the one-to-one mix loses is not
+    // understood).  Hence: two targets, >= 7/8 of two wavefronts per SIMD, unequal wavefront counts.
+    long plan_waves = 0, wmin = 0, wmax = 0;
+    if (G > 1)
+        for (int t = 0; t < nlive; ++t) {
+            int J = look[t] > 1 ? look[t] : 1;
+            while (J > 1 && G * J > 64) --J;
+            const int mpw = 64 / (G * J);
+            const long w = (B + mpw - 1) / mpw;
+            plan_waves += w;
+            wmin = (t == 0 || w < wmin) ? w : wmin;
+            wmax = w > wmax ? w : wmax;
+        }
+    static const int pair_min = std::getenv("BH_SWD_PAIR_MINWAVES") ? std::atoi(std::getenv("BH_SWD_PAIR_MINWAVES")) : -1;
+    const bool use_pair = B > 1 && !e->no_order && !e->as_given && !e->no_pair && G > 1 && nlive == 2 && bh_pair_order_fits(B) &&
+                          plan_waves >= (pair_min >= 0 ? pair_min : 7 * (long)e->pairwork.ncu) && (pair_min >= 0 || 2 * wmax >= 3 * wmin) &&
+                          !(((m.typ_layers > 0 ? m.typ_layers : e->hint_layers) > 0) && (m.typ_layers > 0 ? m.typ_layers : e->hint_layers) + 2 < Lmax);
+    if (B > 1 && !e->no_order && !e->as_given && !use_pair) {
         if ((rc = ensure(e, e->perm, ((size_t)B + 4) * sizeof(int32_t)))) return rc;
         int32_t *p = (int32_t *)e->perm.p;
         // LDS rows for the bulk of the batch: its typical depth plus a margin; deeper models get their own launch
@@ -406,7 +430,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     a.started = e->started;
     a.prio_low = e->swd_prio_low_now;
     ev_begin(e, 0, st);
-    const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now);
+    const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
     ev_end(e, 0, st);
     e->last_swd_wpb = e->swd_wpb_now;
     if (lrc == 0 && e->started) e->started_expected += e->last_swd.workgroups;
@@ -512,6 +536,11 @@ int bh_engine_create(int device, bh_engine **out)
     if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
     if (const char *g = std::getenv("BH_RF_LDS_BESIDE")) e->rf_lds_beside_swd = std::atoi(g);
     if (std::getenv("BH_RF_BESIDE")) e->rf_beside = true;
+    if (std::getenv("BH_SWD_NO_PAIR")) e->no_pair = true;
+    {
+        hipDeviceProp_t prop;
+        e->pairwork.ncu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
     if (const char *g = std::getenv("BH_SWD_WPB")) e->swd_wpb_default = e->swd_wpb_now = (std::atoi(g) == 4) ? 4 : 2;
     if (const char *g = std::getenv("BH_RF_BESIDE_PRIO")) e->rf_beside_prio = std::atoi(g) & 3;
     if (const char *g = std::getenv("BH_SWD_PRIO_LOW")) e->swd_prio_low = std::atoi(g) != 0 ? 1 : 0;
@@ -595,6 +624,10 @@ void bh_engine_destroy(bh_engine *e)
         for (auto &ev : s.ev)
             if (ev) (void)hipEventDestroy(ev);
     if (e->started) (void)hipFree(e->started);
+    for (int t = 0; t < 2; ++t) {
+        if (e->pairwork.perm[t]) (void)hipFree(e->pairwork.perm[t]);
+        if (e->pairwork.slot_rank[t]) (void)hipFree(e->pairwork.slot_rank[t]);
+    }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
@@ -976,7 +1009,9 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         HIPCHK(e, hipMemset(e->started, 0, sizeof(unsigned)));
         e->started_expected = 0;
     }
-    e->swd_prio_low_now = want_beside ? e->swd_prio_low : 0;
+    // (RF wavefronts move in beside the last dispersion wavefronts of a SIMD as its short ones end: the dispersion
+    // wavefronts' unfavoured phase runs at priority 1 then, above the RF's 0)
+    e->swd_prio_low_now = want_gate ? e->swd_prio_low : 0;
     e->swd_wpb_now = want_beside ? 4 : e->swd_wpb_default; // (4: two copies of the libm tables per CU instead of four: LDS room for an RF workgroup)
     e->last_swd = SwdLaunchInfo{};
     rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs);

@@ -4,7 +4,10 @@
 // glibc-exact sincos / exp; hoisted out of the loop they cost more registers than the kernel has.
 #include "../../include/bh_engine.h"
 #include "bh_device.h"
+#include <algorithm>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 #define BH_HD __device__ __forceinline__
 #define BH_TAB static __device__ const
 #include "bh_libm.h"
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const int slot = g * J + rr;                 // group index inside the wave
     const int sidx = lo + wid * MPW + g; // position in the processing order
     const bool valid = sidx < hi;
-    const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
+    const int32_t *perm = T.perm != nullptr ? T.perm : A.perm; // processing order: the target's own (SIMD pairing) or the batch's
+    const int ib = valid ? (perm ? perm[sidx] : sidx) : 0;
     const int Lmax = A.rows[cls]; // LDS rows per model of this class (>= every layer count it meets)
     const int K = T.K;
     const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) {
         const int l = idx / MPW, mg = idx % MPW;
         const int sb = lo + wid * MPW + mg;
-        const int b = sb < hi ? (A.perm ? A.perm[sb] : sb) : 0;
+        const int b = sb < hi ? (perm ? perm[sb] : sb) : 0;
         float fd = 0.f, fa = 1.f, fb = 1.f, fr = 1.f;
         if (sb < hi && l < A.nlay[b]) {
             const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                 hwid = (hwid & 0xffffu) | ((xcc & 0xfu) << 16);
                 r[0] = w_start;
                 r[1] = wall_clock64();
-                r[2] = clock64() - c_start;
+                r[2] = ((unsigned long long)(clock64() - c_start) & 0xffffffffffull) | ((unsigned long long)(unsigned)(blockIdx.x * WPB + wave) << 40); // cycles | grid wavefront index << 40
                 r[3] = (unsigned long long)nrounds | ((unsigned long long)ifunc << 32) | ((unsigned long long)hwid << 36);
             }
         }
@@ -590,7 +594,70 @@ size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 constexpr size_t WAVE_LDS_TARGET = (160 * 1024 / 4 - LIBM_TAB_PAD) / GROUP_WPB;
 constexpr size_t WG_LDS_CAP = 64 * 1024;
 
-int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdLaunchInfo *info, int wpb)
+namespace {
+// Load ranks of the wavefronts of a launch for the SIMD-pairing order (SwdPairWork).  Placement rule of the workgroup
+// dispatcher, read off the wavefront trace (tools/gpu_trace.py, MAP=...; identical from run to run): workgroup g of a
+// one-dimensional grid runs on CU g mod ncu in pass g / ncu, and its two wavefronts sit on SIMD (pass + j) mod 4 -- so SIMD
+// s of a CU holds wavefront 0 of its pass-s workgroup and wavefront 1 of its pass-(s-1) workgroup, and the SIMDs whose
+// partner workgroup does not exist (the last pass is not full) hold one wavefront only.
+// Every wavefront gets a wanted load quantile q (0 = longest models): 0 for a wavefront alone on its SIMD, u and 1 - u for
+// the two of a pair (u spread over (0, 1/2) across the pairs); per target the wavefronts are ranked by q.
+bool build_slot_ranks(int n0, int n1, int ncu, std::vector<int32_t> rank[2])
+{
+    const int NW = n0 + n1, nwg = (NW + 1) / 2;
+    if (ncu <= 0 || nwg > 4 * ncu) return false; // more than one round of workgroups: placement not fixed by the index
+    auto target_of = [&](int W, int &ty, int &wid) {
+        if (n1 > 0) {
+            const long long N = NW;
+            const int l0 = (int)(((long long)W * n1) / N), l1 = (int)((((long long)W + 1) * n1) / N);
+            ty = (l1 > l0) ? 1 : 0;
+            wid = (l1 > l0) ? l0 : W - l0;
+        } else {
+            ty = 0;
+            wid = W;
+        }
+    };
+    std::vector<int> on_simd[2]; // per (cu, simd): wavefront 0 / wavefront 1 member (grid wavefront index or -1)
+    on_simd[0].assign((size_t)ncu * 4, -1);
+    on_simd[1].assign((size_t)ncu * 4, -1);
+    for (int W = 0; W < NW; ++W) {
+        const int g = W / 2, j = W % 2, cu = g % ncu, pass = g / ncu, simd = (pass + j) % 4;
+        on_simd[j][(size_t)cu * 4 + simd] = W;
+    }
+    std::vector<double> q((size_t)NW, 0.0);
+    int npairs = 0;
+    for (size_t k = 0; k < on_simd[0].size(); ++k) npairs += (on_simd[0][k] >= 0 && on_simd[1][k] >= 0);
+    int ip = 0;
+    for (size_t k = 0; k < on_simd[0].size(); ++k) {
+        const int a = on_simd[0][k], b = on_simd[1][k];
+        if (a >= 0 && b >= 0) {
+            const double u = (ip + 0.5) / (2.0 * npairs);
+            q[(size_t)((ip & 1) ? a : b)] = u;        // (alternating which member takes the long share spreads the long
+            q[(size_t)((ip & 1) ? b : a)] = 1.0 - u;  //  models evenly over the two targets)
+            ++ip;
+        } else if (a >= 0) {
+            q[(size_t)a] = 0.0;
+        } else if (b >= 0) {
+            q[(size_t)b] = 0.0;
+        }
+    }
+    const int nw[2] = {n0, n1};
+    for (int t = 0; t < 2; ++t) {
+        std::vector<std::pair<double, int>> v;
+        for (int W = 0; W < NW; ++W) {
+            int ty, wid;
+            target_of(W, ty, wid);
+            if (ty == t && wid < nw[t] - 1) v.emplace_back(q[(size_t)W], wid); // (the last wavefront keeps the tail)
+        }
+        std::sort(v.begin(), v.end());
+        rank[t].assign((size_t)(nw[t] > 0 ? nw[t] : 1), 0);
+        for (size_t r = 0; r < v.size(); ++r) rank[t][(size_t)v[r].second] = (int32_t)r;
+    }
+    return true;
+}
+} // namespace
+
+int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdLaunchInfo *info, int wpb, SwdPairWork *pair)
 {
     if (wpb != 4) wpb = GROUP_WPB;
     int kmax = 0, maxmode = 1;
@@ -681,6 +748,56 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         a.wg_n0 = n[0];
         a.wg_n1 = n[1];
         grid = dim3((n[0] + n[1] + wpb - 1) / wpb, 1, 1);
+    }
+    // SIMD-pairing order of the models (SwdPairWork): a one-dimensional grid of one class, workgroups of two wavefronts
+    if (pair != nullptr && !two && wpb == 2 && grid.y == 1 && grid.z == 1 && a.ntargets <= 2 && bh_pair_order_fits(a.B)) {
+        int n[2] = {0, 0}, mpw[2] = {1, 1};
+        for (int t = 0; t < a.ntargets; ++t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && a.lanes[1] * J > BH_WAVE) --J;
+            mpw[t] = BH_WAVE / (a.lanes[1] * J);
+            n[t] = (a.B + mpw[t] - 1) / mpw[t];
+        }
+        bool ok = true, geom = true;
+        const bool by_depth_only = false; // (whether the pairing applies is the engine's decision: launch_swd_jobs)
+        if (!by_depth_only && (pair->key_n0 != n[0] || pair->key_n1 != n[1] || pair->key_wpb != wpb)) { // (rare: the batch shape changed)
+            std::vector<int32_t> rank[2];
+            geom = build_slot_ranks(n[0], n[1], pair->ncu, rank); // false: placement unknown -> plain sorted order
+            for (int t = 0; ok && geom && t < a.ntargets; ++t) {
+                if (pair->cap_rank[t] < n[t]) {
+                    if (pair->slot_rank[t]) (void)hipFree(pair->slot_rank[t]);
+                    pair->slot_rank[t] = nullptr;
+                    ok = hipMalloc((void **)&pair->slot_rank[t], (size_t)(n[t] + 64) * sizeof(int32_t)) == hipSuccess;
+                    pair->cap_rank[t] = ok ? n[t] + 64 : 0;
+                }
+                if (ok) {
+                    ok = hipStreamSynchronize(stream) == hipSuccess && // (an earlier launch may still read the old table)
+                         hipMemcpy(pair->slot_rank[t], rank[t].data(), (size_t)n[t] * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+                }
+            }
+            pair->key_n0 = (ok && geom) ? n[0] : -1;
+            pair->key_n1 = (ok && geom) ? n[1] : -1;
+            pair->key_wpb = (ok && geom) ? wpb : -1;
+        }
+        if (ok && pair->cap_perm < a.B) {
+            for (int t = 0; t < 2; ++t) {
+                if (pair->perm[t]) (void)hipFree(pair->perm[t]);
+                pair->perm[t] = nullptr;
+                ok = ok && hipStreamSynchronize(stream) == hipSuccess &&
+                     hipMalloc((void **)&pair->perm[t], (size_t)(a.B + a.B / 4 + 64) * sizeof(int32_t)) == hipSuccess;
+            }
+            pair->cap_perm = ok ? a.B + a.B / 4 + 64 : 0;
+        }
+        if (ok && by_depth_only) {
+            bh_launch_order(a.B, a.nlay, pair->perm[0], a.Lmax, nullptr, stream);
+            a.perm = pair->perm[0];
+        } else if (ok) {
+            PairOrderTarget tg[2];
+            for (int t = 0; t < a.ntargets; ++t) tg[t] = PairOrderTarget{mpw[t], n[t], geom ? pair->slot_rank[t] : nullptr, pair->perm[t]};
+            bh_launch_pair_order(a.B, a.Lmax, a.nlay, a.t[0].vs, a.t[0].sl, a.t[0].sb, a.ntargets, tg, stream);
+            for (int t = 0; t < a.ntargets; ++t) a.t[t].perm = pair->perm[t];
+        }
+        (void)hipGetLastError();
     }
     const size_t lds = LIBM_TAB_PAD + wpb * wave_lds;
     if (info != nullptr) {

@@ -399,8 +399,8 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     observed_data(eng, spec, truth, nrs)
     eng.set_targets(spec)
     eng._owner = None
-    if os.environ.get("BH_BENCH_SORT", "0") != "1":   # (experiment switch: keep the on-device sort)
-        eng.set_model_order(sort_by_depth=False)  # the batches of this workload are uniform (L layers each): nothing to sort
+    if os.environ.get("BH_BENCH_AS_GIVEN", "0") == "1":   # (experiment switch: no on-device ordering of the batch)
+        eng.set_model_order(sort_by_depth=False)
     nt = len(spec)
 
     def to_dev(a):

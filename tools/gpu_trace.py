@@ -42,7 +42,8 @@ t0 = tr[:, 0].min()
 start = (tr[:, 0] - t0) / 100.0          # us
 end = (tr[:, 1] - t0) / 100.0
 dur = end - start
-cyc = tr[:, 2].astype(float)
+cyc = (tr[:, 2] & 0xffffffffff).astype(float)
+gwid = (tr[:, 2] >> 40).astype(np.int64)          # wavefront index in the grid (blockIdx.x * wavefronts per workgroup + wave)
 rounds = (tr[:, 3] & 0xffffffff).astype(int)
 ifn = ((tr[:, 3] >> 32) & 0xf).astype(int)
 hw = (tr[:, 3] >> 36).astype(np.int64)
@@ -92,3 +93,17 @@ nr = np.array([int((ifn[cukey == c] == 2).sum()) for c in cukey])
 for k in sorted(set(nr[ifn == 2])):
     m = (ifn == 2) & (nr == k)
     print("  Rayleigh waves on CUs with %d Rayleigh wave(s): n %4d, kcycles/round med %.2f max %.2f" % (k, m.sum(), np.median(cyc[m] / rounds[m]) / 1e3, (cyc[m] / rounds[m]).max() / 1e3))
+
+# which grid wavefronts share a SIMD?  (placement map: does the dispatcher pair them regularly?)
+if os.environ.get("MAP"):
+    pairs = []
+    for k in u:
+        w = np.sort(gwid[key == k])
+        pairs.append(tuple(w))
+    pairs.sort()
+    d = np.array([p[1] - p[0] for p in pairs if len(p) == 2])
+    print("SIMD pairs (grid wavefront indices): first 24:", pairs[:24])
+    print("index distance inside a pair: histogram of the 10 most common:", sorted(zip(*np.unique(d, return_counts=True)), key=lambda t: -t[1])[:10])
+    single = sorted(p[0] for p in pairs if len(p) == 1)
+    print("wavefronts alone on a SIMD:", single)
+    np.save(os.environ["MAP"], np.column_stack((gwid, key, ifn, rounds, dur)))
