@@ -587,6 +587,11 @@ def main():
         sock.close()
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    # stdout carries ONE line, the JSON record: everything libraries print there on the way (RCCL's version banner at
+    # the first collective, gloo's connection messages) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -643,7 +648,10 @@ def main():
     if rank == 0 and out is not None:
         if comm is not None:
             out["collective_check"] = comm
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
