@@ -62,6 +62,7 @@ struct SwdKernelArgs {
     int look;         // trial velocities per round and model = lanes per model (1, 2, 4, 8 or 16), see SearchT::candidate
     int fair;         // alternate the issue priority of the two wavefronts of a SIMD (scheduling only)
     double *nev_high; // work array [bh_swd_nev_high_doubles(B, look)]: Neville orders the kernel does not keep in LDS
+    int fast;         // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
@@ -103,6 +104,7 @@ struct SwdMultiArgs {
     unsigned *started; // optional: every workgroup adds 1 when it starts (cumulative over launches): a second stream waits
                        // for "all workgroups of this launch are resident" before it dispatches work beside them
     int prio_low;      // s_setprio level of a wavefront's unfavoured phase (0; 1 when receiver-function wavefronts at 0 run beside it)
+    int fast;          // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);

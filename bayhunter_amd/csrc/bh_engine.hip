@@ -76,6 +76,7 @@ struct bh_engine {
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
+    int swd_search = 0;  // bh_engine_set_swd_search / BH_SWD_SEARCH=fast: 1 = the short refinement for phase-velocity targets
     int love_inlook = 0; // BH_SWD_LOVE_INLOOK env (experiment switch): Love trials inside a lane group, 0 = automatic
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -386,6 +387,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             // their own are left alone (a low-priority phase costs them 8 %: the CU's front end is shared)
             a.fair = lane_waves <= 1024 ? -1 : (lane_waves <= 2048 ? 18 : 12);
             a.nev_high = (double *)e->nevhi.p + nev_off[nth];
+            a.fast = e->swd_search;
             bh_launch_swd(a, J.iwave, (fork2 && (nth & 1)) ? e->aux2 : st);
             ++nth;
         }
@@ -429,6 +431,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     a.started = e->started;
     a.prio_low = e->swd_prio_low_now;
+    a.fast = e->swd_search;
     ev_begin(e, 0, st);
     const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
     ev_end(e, 0, st);
@@ -563,6 +566,7 @@ int bh_engine_create(int device, bh_engine **out)
     }
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
+    if (const char *g = std::getenv("BH_SWD_SEARCH")) e->swd_search = (g[0] == 'f' || g[0] == '1') ? 1 : 0;
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
         e->love_inlook = std::atoi(g);
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
@@ -589,6 +593,17 @@ int bh_engine_set_model_order(bh_engine *e, int sort_by_depth)
     e->as_given = (sort_by_depth == 0);
     return BH_OK;
 }
+
+int bh_engine_set_swd_search(bh_engine *e, int search)
+{
+    if (!e) return BH_EINVAL;
+    if (search != BH_SEARCH_REFERENCE && search != BH_SEARCH_FAST)
+        return fail(e, BH_EINVAL, "search must be BH_SEARCH_REFERENCE (0) or BH_SEARCH_FAST (1)");
+    e->swd_search = search;
+    return BH_OK;
+}
+
+int bh_engine_get_swd_search(const bh_engine *e) { return e ? e->swd_search : 0; }
 
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round)
 {

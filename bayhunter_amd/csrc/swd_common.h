@@ -439,7 +439,12 @@ enum : int {
     ST_STEP = 1,  // del2 at c2 = c1 +- dc                           (:447-449)
     ST_NEV0 = 2,  // first midpoint inside nevill                    (:582-583)
     ST_NEVL = 3,  // midpoint / Neville estimate, then top of loop   (:586-...)
-    ST_NEVF = 4   // forced midpoint after the estimate left the bracket (:594-598)
+    ST_NEVF = 4,  // forced midpoint after the estimate left the bracket (:594-598)
+    // the optional short refinement (SearchT<.., FAST = true>; not the reference's sequence, see there)
+    ST_FX = 5,    // single point: regula falsi / bisection
+    ST_FP1 = 6,   // x - tau (towards c1) of the acceptance pair around the estimate x
+    ST_FP2 = 7,   // x + tau (towards c2)
+    ST_FB = 8     // the fastest S velocity, first, when the bracket reaches beyond it
 };
 
 // ---- the per-model search state machine -------------------------------------------------------
@@ -450,7 +455,17 @@ enum : int {
 // NLO: Neville entries kept in LDS; the orders from NLO on (rarely reached: the order only grows through
 // consecutive interpolation steps) live in a second array (`set_high`, global memory in the lane-per-evaluation
 // kernel, whose residency is bounded by LDS).  NLO = NEV_MAX: everything in LDS, no second array.
-template <int XSC, int NLO = NEV_MAX> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+// FAST = true compiles in the engine's OPTIONAL short refinement (bh_engine_set_swd_search), taken by phase-velocity
+// targets: the bracket scan in steps of dc is the reference's, evaluation for evaluation -- the same bracket, the same
+// root -- but inside the bracket nevill's 10-12 evaluations (its stop test is the bracket WIDTH, which one-sided
+// interpolation steps close slowly) are replaced by ~3: one regula-falsi point, then an inverse-quadratic estimate x
+// through the three known points, accepted as soon as the function changes sign between x - tau and x + tau
+// (tau = 5e-8 |x|; the reference stops at a bracket of 1e-6 c1 and returns one of its ends).  A miss moves the
+// bracket and repeats; bisection from the seventh pass on.  Result: within 1.2e-6 relative of the reference's
+// (measured: tests/test_gpu_swd.py), against north_star's 1e-5; NOT bit-identical, hence off by default.  The sequence
+// of evaluations is a function of the model alone (not of the launch plan): results do not depend on the batch.
+// oracle/swd_oracle.c (refine_root_fast) restates it for the bit-level check of the device.
+template <int XSC, int NLO = NEV_MAX, bool FAST = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
     int XS = XSC;
     // constants of the reference's driver (compile-time: they cost no registers)
@@ -505,6 +520,11 @@ struct SearchT {
     double c1, c2, clow, del1, del2, del1st, c3, del3, ck, t1, omega, ceval;
     float t1a, t1b;
     unsigned int evals;
+    // FAST only: the third point of the inverse-quadratic estimate (the bracket end last replaced), pass counter
+    static constexpr double fast_tau = 5.0e-8;
+    double cp = 0.0, delp = 0.0;
+    bool have_p = false;
+    int fit = 0;
 
     __device__ __forceinline__ void set_period(int kk)
     {
@@ -649,6 +669,13 @@ struct SearchT {
     __device__ __forceinline__ double candidate(int r) const
     {
         double q = ceval;
+        if (FAST && st >= ST_FX) { // the only request that can be foreseen: the second point of an acceptance pair
+            if (st == ST_FP1 && r == 1) {
+                const double tau = fast_tau * fabs(c3);
+                q = (c2 > c1) ? c3 + tau : c3 - tau;
+            }
+            return q;
+        }
         if (st == ST_FIRST || st == ST_STEP) {
             const bool up = (st == ST_FIRST) || (idir > 0);
             for (int j = 0; j < r; ++j) q = up ? q + dc : q - dc;
@@ -674,6 +701,52 @@ struct SearchT {
         // 3 refinement finished with c3, 4 nevill top-of-loop, 5 nevill post-bracket section,
         // 6 root found
         int todo = 0;
+        if (FAST && st >= ST_FX) { // the short refinement's own states (kept out of the switch: the reference build's text stays as it was)
+            if (st == ST_FX) {
+                if (signs_differ(del, del1)) {
+                    cp = c2; delp = del2;
+                    c2 = ceval; del2 = del;
+                } else {
+                    cp = c1; delp = del1;
+                    c1 = ceval; del1 = del;
+                }
+                have_p = true;
+                todo = 7;
+            } else if (st == ST_FB) {
+                const bool low_is_1 = c1 < c2;
+                const bool below = signs_differ(del, low_is_1 ? del1 : del2); // sign change below betmx: it replaces the upper end
+                if (below == low_is_1) {
+                    cp = c2; delp = del2;
+                    c2 = betmxd; del2 = del;
+                } else {
+                    cp = c1; delp = del1;
+                    c1 = betmxd; del1 = del;
+                }
+                have_p = true;
+                todo = 7;
+            } else if (st == ST_FP1) {
+                if (signs_differ(del, del1)) { // the root is on the c1 side of x - tau
+                    cp = c2; delp = del2;
+                    c2 = ceval; del2 = del;
+                    todo = 7;
+                } else {
+                    const double tau = fast_tau * fabs(c3);
+                    const double x2 = (c2 > c1) ? c3 + tau : c3 - tau; // (the expression of candidate(1))
+                    cp = c1; delp = del1;
+                    c1 = ceval; del1 = del;
+                    ceval = x2;
+                    st = ST_FP2;
+                }
+                have_p = true;
+            } else {
+                if (signs_differ(del, del1)) {
+                    todo = 3; // sign change inside [x - tau, x + tau]: c3 = x is the root
+                } else {      // the root is beyond x + tau (the third point stays)
+                    c1 = ceval; del1 = del;
+                    todo = 7;
+                }
+            }
+        } else
         switch (st) {
         case ST_FIRST:
             del1 = del;
@@ -684,9 +757,23 @@ struct SearchT {
         case ST_STEP:
             del2 = del;
             if (signs_differ(del1, del2)) { // bracketed: enter nevill with (c1,c2,del1,del2)
-                c3 = 0.5 * (c1 + c2);
-                ceval = c3;
-                st = ST_NEV0;
+                if (FAST && !group) {
+                    have_p = false;
+                    fit = 0;
+                    // A bracket that reaches beyond the fastest S velocity (a root up there is rejected, :468-471, and the
+                    // secular function has further sign changes there): look at betmx first and keep the side below it
+                    // if the root is there -- the one nevill walks into from its midpoint.
+                    if (fmax(c1, c2) > betmxd && fmin(c1, c2) < betmxd) {
+                        ceval = betmxd;
+                        st = ST_FB;
+                    } else {
+                        todo = 7;
+                    }
+                } else {
+                    c3 = 0.5 * (c1 + c2);
+                    ceval = c3;
+                    st = ST_NEV0;
+                }
             } else {
                 c1 = c2;
                 del1 = del2;
@@ -709,6 +796,42 @@ struct SearchT {
             del3 = del;
             todo = 5;
             break;
+        }
+        if (FAST && todo == 7) { // next estimate inside the bracket (c1, del1), (c2, del2)
+            fit = fit + 1;
+            const double w = c2 - c1;
+            if (fit >= 100 || fabs(w) <= 2.0 * (fast_tau * fabs(c1))) {
+                c3 = 0.5 * (c1 + c2);
+                todo = 3;
+            } else {
+                const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+                double x = 0.0;
+                bool ok = false;
+                if (have_p) {
+                    const double d12 = del1 - del2, d1p = del1 - delp, d2p = del2 - delp;
+                    if (d12 != 0.0 && d1p != 0.0 && d2p != 0.0) {
+                        const double q1 = c1 * del2 * delp / (d12 * d1p);
+                        const double q2 = c2 * del1 * delp / (d12 * d2p);
+                        const double q3 = cp * del1 * del2 / (d1p * d2p);
+                        x = q1 - q2 + q3;
+                        ok = (x > lo && x < hi);
+                    }
+                }
+                if (!ok) {
+                    x = c1 - del1 * (c2 - c1) / (del2 - del1);
+                    if (!(x > lo && x < hi)) x = 0.5 * (c1 + c2);
+                }
+                if (fit > 6) x = 0.5 * (c1 + c2);
+                const double tau = fast_tau * fabs(x);
+                const bool up = c2 > c1;
+                const double x1 = up ? x - tau : x + tau;
+                const double x2 = up ? x + tau : x - tau;
+                const bool single = (fit == 1 || fit > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
+                c3 = x;
+                ceval = single ? x : x1;
+                st = single ? ST_FX : ST_FP1;
+                todo = 0;
+            }
         }
         if (todo == 4) { // label 100 of nevill
             nctrl = nctrl + 1;
@@ -849,4 +972,5 @@ struct SearchT {
     }
 };
 using SearchRt = SearchT<0>;
+using SearchRtFast = SearchT<0, NEV_MAX, true>;
 

@@ -168,7 +168,8 @@ __device__ __forceinline__ void wave_sync()
 // WPB = wavefronts per workgroup (they only share the libm tables): 2 by default; 4 when receiver-function workgroups
 // are to run beside the kernel -- a CU's eight wavefronts then hold two copies of the tables instead of four, which is
 // what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
-template <int WPB>
+// FAST: the build with the optional short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
+template <int WPB, bool FAST>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
     const int col = li % 5;                          // the 5-vector component this lane owns
 
-    SearchRt S;
+    SearchT<0, NEV_MAX, FAST> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
            T.mode, cpl + g, cpl + (size_t)K * MPW + g);
@@ -805,17 +806,25 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         info->waves = (a.wg_n1 > 0) ? (long)a.wg_n0 + a.wg_n1 : (long)nwaves * a.ntargets;
         info->lds = lds;
     }
+    // (group-velocity targets keep the reference sequence: a launch of those alone takes the reference build, 10 % faster)
+    bool any_phase = false;
+    for (int t = 0; t < a.ntargets; ++t) any_phase = any_phase || a.t[t].igr == 0;
+    a.fast = (a.fast && any_phase) ? 1 : 0;
     if (wpb == 4) {
         static bool big_lds = false;
         if (lds > WG_LDS_CAP && !big_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return -1;
             big_lds = true;
         }
-        hipLaunchKernelGGL(swd_group_kernel<4>, grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
+        if (a.fast) hipLaunchKernelGGL((swd_group_kernel<4, true>), grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
+        else hipLaunchKernelGGL((swd_group_kernel<4, false>), grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
     } else {
-        hipLaunchKernelGGL(swd_group_kernel<GROUP_WPB>, grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+        if (a.fast) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, true>), grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, false>), grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
     }
     return 0;
 }

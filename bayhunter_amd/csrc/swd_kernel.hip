@@ -72,7 +72,7 @@ __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 // work array) and a workgroup is WPB wavefronts sharing ONE copy of the libm tables: WPB = 1 gives 7 wavefronts per
 // CU at 10 layers (10.2 + 5.1 + 0.25 + 5.5 KB; it was 5 with all 11 orders in LDS), WPB = 2 gives 8 -- 5-9 % faster
 // from 100 000 models on, 2.5 % slower below (the launcher picks).
-template <int IFUNC, bool LOOK, int LANE_WPB>
+template <int IFUNC, bool LOOK, int LANE_WPB, bool FAST> // FAST: the build with the optional short refinement (SearchT, swd_common.h)
 __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem_all[];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
     md.rho = mdl + 3 * Lmax * BH_WAVE + lane;
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
 
-    SearchT<BH_WAVE, NEV_LO> S;
+    SearchT<BH_WAVE, NEV_LO, FAST> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
            cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
     {
@@ -461,27 +461,19 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     // count class: 12 = more than 2048 wavefronts in the call)
     const bool two = a.fair == 12 && LANE_TAB_PAD + 2 * lane_wave_bytes(a.Lmax, a.K, a.mode) <= 64 * 1024;
     const size_t wb = lane_wave_bytes(a.Lmax, a.K, a.mode);
-    if (two) {
-        const dim3 grid((waves + 1) / 2), block(2 * BH_WAVE);
-        const size_t lds = LANE_TAB_PAD + 2 * wb;
-        if (iwave == 1) {
-            if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true, 2>), grid, block, lds, stream, b);
-            else hipLaunchKernelGGL((swd_kernel<1, false, 2>), grid, block, lds, stream, b);
-        } else {
-            if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true, 2>), grid, block, lds, stream, b);
-            else hipLaunchKernelGGL((swd_kernel<2, false, 2>), grid, block, lds, stream, b);
-        }
-    } else {
-        const dim3 grid(waves), block(BH_WAVE);
-        const size_t lds = LANE_TAB_PAD + wb;
-        if (iwave == 1) {
-            if (J > 1) hipLaunchKernelGGL((swd_kernel<1, true, 1>), grid, block, lds, stream, b);
-            else hipLaunchKernelGGL((swd_kernel<1, false, 1>), grid, block, lds, stream, b);
-        } else {
-            if (J > 1) hipLaunchKernelGGL((swd_kernel<2, true, 1>), grid, block, lds, stream, b);
-            else hipLaunchKernelGGL((swd_kernel<2, false, 1>), grid, block, lds, stream, b);
-        }
-    }
+    const size_t lds = LANE_TAB_PAD + (two ? 2 : 1) * wb;
+    const dim3 grid(two ? (waves + 1) / 2 : waves), block((two ? 2 : 1) * BH_WAVE);
+    // (wave type, look-ahead, wavefronts per workgroup, refinement) -> instantiation
+#define BH_LANE_LAUNCH(IF, LK, WP, FS) hipLaunchKernelGGL((swd_kernel<IF, LK, WP, FS>), grid, block, lds, stream, b)
+#define BH_LANE_PICK_FS(IF, LK, WP) do { if (a.fast && a.igr == 0) BH_LANE_LAUNCH(IF, LK, WP, true); else BH_LANE_LAUNCH(IF, LK, WP, false); } while (0)
+#define BH_LANE_PICK_WP(IF, LK) do { if (two) BH_LANE_PICK_FS(IF, LK, 2); else BH_LANE_PICK_FS(IF, LK, 1); } while (0)
+#define BH_LANE_PICK_LK(IF) do { if (J > 1) BH_LANE_PICK_WP(IF, true); else BH_LANE_PICK_WP(IF, false); } while (0)
+    if (iwave == 1) BH_LANE_PICK_LK(1);
+    else BH_LANE_PICK_LK(2);
+#undef BH_LANE_PICK_LK
+#undef BH_LANE_PICK_WP
+#undef BH_LANE_PICK_FS
+#undef BH_LANE_LAUNCH
 }
 
 // ---- launch plan ------------------------------------------------------------------------------------

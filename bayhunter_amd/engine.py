@@ -25,6 +25,7 @@ VEL_PHASE, VEL_GROUP = 0, 1
 RF_P, RF_SV = 0, 1
 LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
 TARGET_SWD, TARGET_RF, TARGET_USER = 0, 1, 2
+SEARCH_REFERENCE, SEARCH_FAST = 0, 1  # bh_engine_set_swd_search
 MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
 
 _d = C.POINTER(C.c_double)
@@ -104,6 +105,8 @@ def load_library():
     L.bh_engine_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
     L.bh_engine_set_swd_group.argtypes = [vp, C.c_int]
     L.bh_engine_set_swd_lookahead.argtypes = [vp, C.c_int]
+    L.bh_engine_set_swd_search.argtypes = [vp, C.c_int]
+    L.bh_engine_get_swd_search.argtypes = [vp]
     L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
     L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
@@ -126,19 +129,19 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 4:
+    if L.bh_abi_version() != 5:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -223,6 +226,18 @@ class Engine(object):
     def set_swd_lookahead(self, trials_per_round):
         """0 = automatic; 1..12 trial phase velocities per round of the dispersion root search."""
         self._check(self._L.bh_engine_set_swd_lookahead(self._h, int(trials_per_round)))
+
+    def set_swd_search(self, search):
+        """"reference" (default): the reference's sequence of secular-function evaluations, velocities bit-identical to
+        surfdisp96.  "fast": the same brackets, ~3 evaluations inside each instead of nevill's 10-12; phase-velocity
+        targets only; within 1.2e-6 relative of the reference (include/bh_engine.h: bh_engine_set_swd_search)."""
+        code = {"reference": SEARCH_REFERENCE, "fast": SEARCH_FAST, SEARCH_REFERENCE: SEARCH_REFERENCE, SEARCH_FAST: SEARCH_FAST}.get(search)
+        if code is None:
+            raise ValueError("search must be 'reference' or 'fast'")
+        self._check(self._L.bh_engine_set_swd_search(self._h, code))
+
+    def swd_search(self):
+        return "fast" if self._L.bh_engine_get_swd_search(self._h) == SEARCH_FAST else "reference"
 
     def timing_reset(self):
         self._check(self._L.bh_timing_reset(self._h))

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 4
+#define BH_ABI_VERSION 5
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -84,6 +84,21 @@ int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
  * lanes, the velocities the search will most probably ask for next and hands them over if and only
  * if it does.  Results do not depend on it. */
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
+/* Root refinement of the dispersion search.
+ *   BH_SEARCH_REFERENCE (default): the reference's sequence of secular-function evaluations (getsol + nevill,
+ *     surfdisp96.f:390-686), evaluation for evaluation: velocities bit-identical to the reference's.
+ *   BH_SEARCH_FAST: the same bracket scan (the same bracket, hence the same root), but inside the bracket ~3 evaluations
+ *     (regula falsi, then an inverse-quadratic estimate accepted on a sign change within +-5e-8 relative) instead of
+ *     nevill's 10-12, whose stop test is the bracket width.  Phase-velocity targets only (group-velocity targets keep
+ *     the reference sequence: a group velocity is a difference quotient of two roots and amplifies their scatter a
+ *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5), failure
+ *     flags identical; a deterministic function of the model (independent of batch and launch plan), but NOT the
+ *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
+ * Also BH_SWD_SEARCH=fast in the environment at engine creation. */
+#define BH_SEARCH_REFERENCE 0
+#define BH_SEARCH_FAST 1
+int bh_engine_set_swd_search(bh_engine *e, int search);
+int bh_engine_get_swd_search(const bh_engine *e);
 /* Tuning hint for BH_DEVICE calls: the typical number of layers (incl. the half-space) of the models in
  * the batches to come, when it is well below Lmax (transdimensional chains: capacity 21, typically 5-7).
  * The lanes-per-model choice is sized for it; 0 = unknown (Lmax is used).  BH_HOST calls look at nlay

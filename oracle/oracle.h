@@ -34,6 +34,11 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
                    int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
                    const double *t, double *cg, int64_t *neval);
 
+/* 1: bho_surfdisp96 / bho_swd_batch refine a bracketed root by the engine's optional short sequence (phase velocities
+ * only) instead of the reference's nevill -- a restatement of THIS repo's swd_common.h, not of the reference; 0 (default):
+ * the reference's sequence.  Process-wide switch. */
+void bho_swd_set_search(int fast);
+
 /* Secular functions, exposed so that tests can compare them 1:1 with the reference's
  * exported dltar1_/dltar4_ symbols.  surfdisp96.f:710-769 and :773-871. */
 double bho_dltar1(double wvno, double omega, const float *d, const float *b,

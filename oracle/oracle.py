@@ -45,6 +45,8 @@ def lib():
         L.bho_dltar1.argtypes = [C.c_double, C.c_double, _f, _f, _f, C.c_int, C.c_int]
         L.bho_dltar4.restype = C.c_double
         L.bho_dltar4.argtypes = [C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int]
+        L.bho_swd_set_search.restype = None
+        L.bho_swd_set_search.argtypes = [C.c_int]
         L.bho_gtsolh.restype = C.c_float
         L.bho_gtsolh.argtypes = [C.c_float, C.c_float]
         L.bho_swd_batch.restype = None
@@ -85,6 +87,23 @@ def surfdisp96(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, 
                                int(iflsph), int(iwave), int(mode), int(igr), int(kmax), _pd(t),
                                _pd(cg), C.byref(ne))
     return (err, ne.value) if return_neval else err
+
+
+def set_swd_search(fast):
+    """True: the engine's optional short refinement (a restatement of swd_common.h, NOT of the reference) instead of the
+    reference's nevill; process-wide.  Use `with swd_search(True): ...` in tests."""
+    lib().bho_swd_set_search(1 if fast else 0)
+
+
+class swd_search:
+    def __init__(self, fast):
+        self.fast = fast
+
+    def __enter__(self):
+        set_swd_search(self.fast)
+
+    def __exit__(self, *a):
+        set_swd_search(False)
 
 
 def dltar(wvno, omega, ifunc, d, a, b, rho):

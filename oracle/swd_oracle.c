@@ -369,9 +369,99 @@ static double refine_root(const medium *md, double t, double c1, double c2, doub
     return c3; /* the last point evaluated, not a bracket end (:672) */
 }
 
+/* ---- the engine's OPTIONAL short refinement (bh_engine_set_swd_search(e, 1)) -------------------------------
+ * NOT the reference's algorithm: a CPU restatement of bayhunter_amd/csrc/swd_common.h (SearchT, FAST) so that the
+ * device's sequence of evaluations in that mode can be checked bit for bit.  The gate of the mode itself is the
+ * tolerance against the reference sequence above (north_star: 1e-5 relative on the velocities), see
+ * tests/test_oracle_swd.py and tests/test_gpu_swd.py.
+ * Same bracket as the reference (the scan in steps of dc is untouched); inside it: one regula-falsi point, then an
+ * inverse-quadratic estimate x through the three known points, accepted when the function changes sign between
+ * x - tau and x + tau (tau = 5e-8 |x|: the root is known twenty times closer than the reference's own stop test
+ * |c1 - c2| <= 1e-6 c1 leaves it); a miss moves the bracket and repeats, bisection from the seventh pass on. */
+#define BHO_FAST_TAU 5.0e-8
+static int g_fast_search = 0;
+void bho_swd_set_search(int fast) { g_fast_search = fast ? 1 : 0; }
+
+static double refine_root_fast(const medium *md, double t, double c1, double c2, double del1, double del2, double betmx)
+{
+    const double twopi = 2.0 * 3.141592653589793;
+    const double omega = twopi / t;
+    double cp = 0.0, delp = 0.0;
+    int have_p = 0;
+    /* A bracket that reaches beyond the fastest S velocity (a root up there is rejected, :468-471, and the secular
+     * function has further sign changes there): look at betmx first and keep the side below it if the root is there --
+     * the one nevill walks into from its midpoint. */
+    if (fmax(c1, c2) > betmx && fmin(c1, c2) < betmx) {
+        const double fb = secular(md, omega / betmx, omega);
+        const int low_is_1 = c1 < c2;
+        const double flow = low_is_1 ? del1 : del2;
+        if (signs_differ(fb, flow)) { /* sign change below betmx: betmx replaces the upper end */
+            if (low_is_1) { cp = c2; delp = del2; c2 = betmx; del2 = fb; }
+            else { cp = c1; delp = del1; c1 = betmx; del1 = fb; }
+        } else {                      /* only above: betmx replaces the lower end (the search will fail) */
+            if (low_is_1) { cp = c1; delp = del1; c1 = betmx; del1 = fb; }
+            else { cp = c2; delp = del2; c2 = betmx; del2 = fb; }
+        }
+        have_p = 1;
+    }
+    for (int it = 1; it < 100; ++it) {
+        const double w = c2 - c1;
+        if (fabs(w) <= 2.0 * (BHO_FAST_TAU * fabs(c1))) break;
+        const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+        double x = 0.0;
+        int ok = 0;
+        if (have_p) {
+            const double d12 = del1 - del2, d1p = del1 - delp, d2p = del2 - delp;
+            if (d12 != 0.0 && d1p != 0.0 && d2p != 0.0) {
+                const double t1 = c1 * del2 * delp / (d12 * d1p);
+                const double t2 = c2 * del1 * delp / (d12 * d2p);
+                const double t3 = cp * del1 * del2 / (d1p * d2p);
+                x = t1 - t2 + t3;
+                ok = (x > lo && x < hi);
+            }
+        }
+        if (!ok) {
+            x = c1 - del1 * (c2 - c1) / (del2 - del1);
+            if (!(x > lo && x < hi)) x = 0.5 * (c1 + c2);
+        }
+        if (it > 6) x = 0.5 * (c1 + c2);
+        const double tau = BHO_FAST_TAU * fabs(x);
+        const int up = c2 > c1;
+        const double x1 = up ? x - tau : x + tau; /* towards c1 */
+        const double x2 = up ? x + tau : x - tau; /* towards c2 */
+        const int single = (it == 1 || it > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
+        if (single) {
+            const double fx = secular(md, omega / x, omega);
+            if (signs_differ(fx, del1)) {
+                cp = c2; delp = del2;
+                c2 = x; del2 = fx;
+            } else {
+                cp = c1; delp = del1;
+                c1 = x; del1 = fx;
+            }
+            have_p = 1;
+            continue;
+        }
+        const double f1 = secular(md, omega / x1, omega);
+        if (signs_differ(f1, del1)) { /* the root is on the c1 side of x1 */
+            cp = c2; delp = del2;
+            c2 = x1; del2 = f1;
+            have_p = 1;
+            continue;
+        }
+        cp = c1; delp = del1;
+        c1 = x1; del1 = f1;
+        have_p = 1;
+        const double f2 = secular(md, omega / x2, omega);
+        if (signs_differ(f2, del1)) return x; /* sign change inside [x1, x2] */
+        c1 = x2; del1 = f2;                   /* the root is beyond x2 (the third point stays) */
+    }
+    return 0.5 * (c1 + c2);
+}
+
 /* ---- bracket search.  surfdisp96.f:390-482 (`getsol`).  Returns 1 ok / -1 failed. ------- */
 static int bracket_and_refine(const medium *md, double t1, double *c1io, double clow, double dc,
-                              double cm, double betmx, int ifirst, double *del1st)
+                              double cm, double betmx, int ifirst, double *del1st, int fast)
 {
     const double twopi = 2.0 * 3.141592653589793;
     double c1 = *c1io, c2;
@@ -390,7 +480,7 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
         omega = twopi / t1;
         double del2 = secular(md, omega / c2, omega);
         if (signs_differ(del1, del2)) {
-            double cn = refine_root(md, t1, c1, c2, del1, del2);
+            double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx) : refine_root(md, t1, c1, c2, del1, del2);
             *c1io = cn;
             if (cn > betmx) return -1;
             return 1;
@@ -553,7 +643,10 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
                 c1 = c[k - 2] - onea * dc;
                 clow = cm;
             }
-            int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st);
+            /* (the short refinement applies to phase-velocity runs only: a group velocity is a difference quotient of
+               two roots and amplifies their 1e-6 scatter a hundredfold) */
+            const int fast = g_fast_search && igr == 0;
+            int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st, fast);
             if (iret == -1) {
                 failed = 1;
                 break;
@@ -563,7 +656,7 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
                 t1 = (double)t1b;
                 clow = cb[k - 1] + one * dc;
                 c1 = c1 - onea * dc;
-                iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, 0, &del1st);
+                iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, 0, &del1st, 0);
                 if (iret == -1) c1 = c[k - 1];
                 cb[k - 1] = c1;
             } else {

@@ -24,7 +24,7 @@ def test_library_built_and_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), "missing export %s" % name
     assert sorted(E.EXPORTED_SYMBOLS) == decl
-    assert lib.bh_abi_version() == 4
+    assert lib.bh_abi_version() == 5
 
 
 def test_library_contains_gfx950_code_object():

@@ -99,3 +99,39 @@ def test_oracle_matches_compiled_reference_random(oracle):
         om = 2 * np.pi / rs.uniform(1, 60); c = rs.uniform(1.7, 5.0)
         for ifunc in (1, 2):
             assert oracle.dltar(om / c, om, ifunc, h, vp, vs, rho) == refshim.dltar(om / c, om, ifunc, h, vp, vs, rho)
+
+
+def test_short_refinement_restatement_stays_within_tolerance_of_the_reference(oracle):
+    """`oracle.swd_search(True)` = the CPU restatement of the engine's OPTIONAL short root refinement
+    (bh_engine_set_swd_search; swd_common.h) -- not the reference's algorithm.  Its gate, on the CPU: phase velocities
+    within north_star's 1e-5 relative (achieved: 1.2e-6) of the reference's golden vectors and of the reference
+    sequence on random models, the same models failing, fewer evaluations; group velocities untouched."""
+    from bayhunter_amd.synth import synth_models
+    g = golden("swd_golden.npz")
+    nlay = g["nlay"]
+    a = [np.ascontiguousarray(g[k], dtype=np.float64) for k in ("h", "vp", "vs", "rho")]
+    for pset in ("p21", "p30"):
+        per = g["x_" + pset]
+        for ir, ref in enumerate(g["refs"]):
+            iwave, igr = REFS[str(ref)]
+            with oracle.swd_search(True):
+                v, e, _ = oracle.swd_batch(nlay, *a, per, iwave, igr)
+            ok = g["ok_" + pset][:, ir].astype(bool)
+            y = g["y_" + pset][:, ir]
+            assert np.array_equal(e == 0, ok)
+            assert np.max(np.abs(v[ok] - y[ok]) / y[ok]) <= (1e-5 if igr == 0 else 0.0)
+    rs = np.random.RandomState(2024)
+    nlay, h, vp, vs, rho = synth_models(rs, 3000, 12, lvz_frac=0.25, ragged=True)
+    per = np.linspace(2, 60, 30)
+    a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+    for iwave in (2, 1):
+        ov, oe, nref = oracle.swd_batch(nlay, *a, per, iwave, 0)
+        with oracle.swd_search(True):
+            v, e, nfast = oracle.swd_batch(nlay, *a, per, iwave, 0)
+        assert np.array_equal(e, oe)
+        both = (v != 0) & (ov != 0)
+        assert np.max(np.abs(v[both] - ov[both]) / ov[both]) <= 1.2e-6
+        assert np.array_equal(v[oe == 0] == 0, ov[oe == 0] == 0)
+        assert nfast < 0.8 * nref
+    v0, _, n0 = oracle.swd_batch(nlay, *a, per, 1, 0)                # (the switch is off again)
+    assert np.array_equal(v0, ov) and n0 == nref
