@@ -276,6 +276,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
     const int col = li % 5;                          // the 5-vector component this lane owns
 
+    constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
     SearchT<0, NEV_MAX, FAST> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
@@ -514,7 +515,50 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
         if (prof) t2c = clock64();
         // Every lane of the model can read all J (velocity, value) pairs; the search consumes them for
         // as long as its next request is the very velocity (at the same omega) the next group evaluated.
-        {
+        if (BULK && J * JL > 2) { // (measured: pays from three trials per round on; with two it costs 6 % at B = 4096)
+            // The same consumption with the runs of plain bracket steps taken in one go.  A trial is PLAIN for its model
+            // when the search is scanning (ST_STEP), the value has the sign of del1, the velocity is inside the scan's
+            // bounds and the request after it is again the plain next step: consuming it only moves (c1, del1) on.
+            // Every lane judges the trial it carried; a ballot hands every model the verdicts of all its trials; the
+            // leading run of plain trials is consumed by copying the last one's (velocity, value) -- what advance()
+            // would have left after stepping through them one by one.  Anything else goes through advance().
+            const int Jtot = J * JL;
+            bool live = S.active;
+            int jn = 0; // this model's next trial
+            while (__ballot(live) != 0ull) {
+                // trial jn must be the very request (trial 0 IS the pending request)
+                const int tj = live ? jn : 0;
+                const int srcn = (g * J + tj / JL) * G + (tj % JL);
+                const double cj = __shfl(cev, srcn), dj = __shfl(del, srcn);
+                if (jn > 0) live = live && S.ceval == cj && S.omega == omg;
+                const double nxt = (S.idir > 0) ? cev + S.dc : cev - S.dc;
+                const bool plain = S.active && S.st == ST_STEP && !signs_differ(S.del1, del) &&
+                                   !(cev < S.cm || cev >= S.betmxd + S.dc) && nxt > S.clow;
+                const unsigned long long pm = __ballot(plain);
+                bool run = false;
+                if (live && S.st == ST_STEP) {
+                    int t = jn;
+                    while (t < Jtot && ((pm >> ((g * J + t / JL) * G + (t % JL))) & 1ull)) ++t;
+                    run = t > jn;
+                    if (run) {
+                        const int src = (g * J + (t - 1) / JL) * G + ((t - 1) % JL);
+                        const double cl = __shfl(cev, src), dl = __shfl(del, src);
+                        S.c1 = cl;
+                        S.del1 = dl;
+                        S.del2 = dl;
+                        S.c2 = (S.idir > 0) ? cl + S.dc : cl - S.dc;
+                        S.ceval = S.c2;
+                        S.evals += (unsigned)(t - jn);
+                        jn = t;
+                    }
+                }
+                if (live && !run) {
+                    S.advance(dj);
+                    ++jn;
+                }
+                live = live && S.active && jn < Jtot;
+            }
+        } else {
             bool live = S.active;
             const int Jtot = J * JL;
             for (int j = 0; j < Jtot; ++j) {
