@@ -258,60 +258,91 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(int B, int Lmax, const
         nmax = 0;
     }
     __syncthreads();
-    // predicted cost (non-negative binary32: its bit pattern orders like the value) and the depth range of the batch
-    for (int b = tid; b < B; b += 1024) {
-        int n = nlay[b];
-        n = n < 1 ? 1 : (n > Lmax ? Lmax : n);
-        float lo = 1e30f, hi = -1e30f;
-        for (int l = 0; l < n; ++l) {
-            const float v = (float)vs[(ptrdiff_t)b * sb + (ptrdiff_t)l * sl];
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
+    // predicted cost (non-negative binary32: its bit pattern orders like the value) and the depth range of the batch;
+    // reduced per thread and per wavefront first (1024 threads x 4 atomics on four LDS words serialise)
+    constexpr int PER_THREAD = PAIR_MAX_B / 1024;
+    float cost[PER_THREAD]; // of this thread's models b = tid + 1024 i (kept for the two bucket passes below)
+    int depth[PER_THREAD];
+    {
+        unsigned tcmin = 0x7f800000u, tcmax = 0u;
+        int tnmin = BH_MAX_LAYERS + 1, tnmax = 0;
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int b = tid + 1024 * i;
+            cost[i] = 0.0f;
+            depth[i] = 1;
+            if (b >= B) continue;
+            int n = nlay[b];
+            n = n < 1 ? 1 : (n > Lmax ? Lmax : n);
+            float lo = 1e30f, hi = -1e30f;
+            for (int l = 0; l < n; ++l) {
+                const float v = (float)vs[(ptrdiff_t)b * sb + (ptrdiff_t)l * sl];
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+            float c = hi - lo;
+            c = (c >= 0.0f && c < 1e30f) ? c : 0.0f; // (NaN / absurd models: anywhere)
+            cost[i] = c;
+            depth[i] = n;
+            const unsigned cb = __float_as_uint(c);
+            tcmin = cb < tcmin ? cb : tcmin;
+            tcmax = cb > tcmax ? cb : tcmax;
+            tnmin = n < tnmin ? n : tnmin;
+            tnmax = n > tnmax ? n : tnmax;
         }
-        float c = hi - lo;
-        c = (c >= 0.0f && c < 1e30f) ? c : 0.0f; // (NaN / absurd models: anywhere)
-        atomicMin(&cmin_bits, __float_as_uint(c));
-        atomicMax(&cmax_bits, __float_as_uint(c));
-        atomicMin(&nmin, n);
-        atomicMax(&nmax, n);
+        for (int off = 32; off > 0; off >>= 1) {
+            tcmin = min(tcmin, (unsigned)__shfl_xor((int)tcmin, off));
+            tcmax = max(tcmax, (unsigned)__shfl_xor((int)tcmax, off));
+            tnmin = min(tnmin, __shfl_xor(tnmin, off));
+            tnmax = max(tnmax, __shfl_xor(tnmax, off));
+        }
+        if ((tid & (BH_WAVE - 1)) == 0) {
+            atomicMin(&cmin_bits, tcmin);
+            atomicMax(&cmax_bits, tcmax);
+            atomicMin(&nmin, tnmin);
+            atomicMax(&nmax, tnmax);
+        }
     }
     __syncthreads();
     const bool ragged = nmin != nmax;
     const float cmin = __uint_as_float(cmin_bits), cmax = __uint_as_float(cmax_bits);
     const float scale = (cmax > cmin) ? (float)(PAIR_BUCKETS - 1) / (cmax - cmin) : 0.0f;
-    auto bucket = [&](int b) {
-        int n = nlay[b];
-        n = n < 1 ? 1 : (n > Lmax ? Lmax : n);
-        if (ragged) return (nmax - n) < PAIR_BUCKETS ? (nmax - n) : PAIR_BUCKETS - 1; // deepest first
-        float lo = 1e30f, hi = -1e30f;
-        for (int l = 0; l < n; ++l) {
-            const float v = (float)vs[(ptrdiff_t)b * sb + (ptrdiff_t)l * sl];
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
-        }
-        float c = hi - lo;
-        c = (c >= 0.0f && c < 1e30f) ? c : 0.0f;
-        int k = (int)((cmax - c) * scale); // longest first
+    auto bucket = [&](int i) { // of this thread's i-th model
+        if (ragged) return (nmax - depth[i]) < PAIR_BUCKETS ? (nmax - depth[i]) : PAIR_BUCKETS - 1; // deepest first
+        int k = (int)((cmax - cost[i]) * scale); // longest first
         return k < 0 ? 0 : (k > PAIR_BUCKETS - 1 ? PAIR_BUCKETS - 1 : k);
     };
-    for (int b = tid; b < B; b += 1024) atomicAdd(&bin[bucket(b)], 1);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i)
+        if (tid + 1024 * i < B) atomicAdd(&bin[bucket(i)], 1);
     __syncthreads();
-    // exclusive scan of the 1024 buckets: one per thread, Hillis-Steele in place
+    // exclusive scan of the 1024 buckets, one per thread: inside the wavefronts by shuffles, then over the 16 wavefront sums
     {
+        __shared__ int wsum[1024 / BH_WAVE];
+        const int lane = tid & (BH_WAVE - 1), wv = tid / BH_WAVE;
         const int mine = bin[tid];
         int acc = mine;
-        for (int off = 1; off < PAIR_BUCKETS; off <<= 1) {
-            __syncthreads();
-            const int other = tid >= off ? bin[tid - off] : 0;
-            __syncthreads();
-            acc = bin[tid] + other;
-            bin[tid] = acc;
+        for (int off = 1; off < BH_WAVE; off <<= 1) {
+            const int o = __shfl_up(acc, off);
+            if (lane >= off) acc += o;
+        }
+        if (lane == BH_WAVE - 1) wsum[wv] = acc;
+        __syncthreads();
+        if (tid < 1024 / BH_WAVE) {
+            int w = wsum[tid];
+            for (int off = 1; off < 1024 / BH_WAVE; off <<= 1) {
+                const int o = __shfl_up(w, off);
+                if (tid >= off) w += o;
+            }
+            wsum[tid] = w;
         }
         __syncthreads();
-        bin[tid] = acc - mine; // start offset of the bucket
+        bin[tid] = (wv > 0 ? wsum[wv - 1] : 0) + acc - mine; // start offset of the bucket
         __syncthreads();
     }
-    for (int b = tid; b < B; b += 1024) sorted[atomicAdd(&bin[bucket(b)], 1)] = b; // (order inside a bucket is arbitrary)
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i)
+        if (tid + 1024 * i < B) sorted[atomicAdd(&bin[bucket(i)], 1)] = tid + 1024 * i; // (order inside a bucket is arbitrary)
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const PairOrderTarget T = t == 0 ? t0 : t1;

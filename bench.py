@@ -476,7 +476,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
     swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
     achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
-    pmc = pmc_summary(workload, B)
+    pmc = pmc_summary(workload + ("fast" if eng.swd_search() == "fast" else ""), B)
     # measured HBM bytes per launch (PMC pass of tools/profile_round.sh, committed summary); null without one
     traffic = pmc.get("hbm_bytes_per_launch")
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -30,6 +30,9 @@ python $R/bench.py --workload c2 --batch 512 --steps 20 --warmup 3 --no-cpu-base
 python $R/bench.py --workload c4 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c4_depth1.json" 2> "$OUT/bench_c4_depth1.err"
 python $R/bench.py --workload c5 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c5_depth1.json" 2> "$OUT/bench_c5_depth1.err"
 python $R/tools/gpu_latency.py > "$OUT/latency.txt" 2>&1
+# the optional short root refinement (bh_engine_set_swd_search): c2 line and single-model latency
+python $R/bench.py --workload c2 --search fast --no-cpu-baseline > "$OUT/bench_c2_fast.json" 2> "$OUT/bench_c2_fast.err"
+BH_SWD_SEARCH=fast python $R/tools/gpu_latency.py > "$OUT/latency_fast.txt" 2>&1
 for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
 for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
 fi
@@ -41,6 +44,7 @@ $TR -d "$OUT/trace_c2" -o t -- python $R/bench.py --workload c2 --steps 10 --war
 $TR -d "$OUT/trace_c3" -o t -- python $R/bench.py --workload c3 --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3.log" 2>&1
 $TR -d "$OUT/trace_c3g" -o t -- python $R/bench.py --workload c3g --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3g.log" 2>&1
 $TR -d "$OUT/trace_c2_b65536" -o t -- python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 $NB > "$OUT/trace_c2_b65536.log" 2>&1
+$TR -d "$OUT/trace_c2fast" -o t -- python $R/bench.py --workload c2 --search fast --steps 10 --warmup 2 $NB > "$OUT/trace_c2fast.log" 2>&1
 $TR -d "$OUT/trace_c4" -o t -- python $R/bench.py --workload c4 --steps 700 --warmup 300 > "$OUT/trace_c4.log" 2>&1
 $TR -d "$OUT/trace_c5" -o t -- python $R/bench.py --workload c5 --steps 600 --warmup 300 > "$OUT/trace_c5.log" 2>&1
 for sh in c3 tut t512u t512r n16384; do
@@ -61,6 +65,7 @@ for WL in c2 c3; do
   $PM --pmc $SQ -d "$OUT/pmc_${WL}_SQ" -o pmc -- $CMD > "$OUT/pmc_${WL}_SQ.log" 2>&1
   $PM --pmc $SQ2 -d "$OUT/pmc_${WL}_SQ2" -o pmc -- $CMD > "$OUT/pmc_${WL}_SQ2.log" 2>&1
 done
+$PM --pmc $SQ -d "$OUT/pmc_c2fast_SQ" -o pmc -- python $R/bench.py --workload c2 --search fast --steps 4 --warmup 1 $NB > "$OUT/pmc_c2fast_SQ.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do   # the progress board's share of the c2 traffic: the same passes with the board off
   BH_SWD_NO_BOARD=1 $PM --pmc $C -d "$OUT/pmc_c2noboard_$C" -o pmc -- python $R/bench.py --workload c2 --steps 4 --warmup 1 $NB > "$OUT/pmc_c2noboard_$C.log" 2>&1
 done
