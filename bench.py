@@ -671,7 +671,7 @@ def main():
                         "kernel_ms_per_launch", "failed_models_last_step", "error")
                 out["fast_search"] = {"note": "bh_engine_set_swd_search(BH_SEARCH_FAST): same bracket scan as the reference, ~3 evaluations "
                                               "inside a bracket instead of nevill's 10-12; phase velocities within 1.2e-6 relative of the "
-                                              "reference's (north_star: 1e-5), failure flags identical (tests/test_gpu_swd_fast.py); "
+                                              "reference's (north_star: 1e-5; tests/test_gpu_swd_fast.py, DESIGN.md 3.1b); "
                                               "parity_check below is against the oracle's REFERENCE sequence",
                                       **{w: ({k: b[k] for k in keep if k in b} if isinstance(b, dict) else b) for w, b in fast.items()}}
                 if "value" in fast.get("c2", {}):
