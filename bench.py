@@ -389,7 +389,7 @@ def rf_roofline(eng, spec, d_batch, B, L, dev, reps=20):
             "rf_per_s": B / (ms * 1e-3)}
 
 
-def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True, light_cpu=False):
+def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True, light_cpu=False, rf_roof=True):
     """One evaluate workload (c2 / c3 / c2g / c3g): untimed clock warm-up, `--warmup` steps, then EXACTLY `--steps`
     steps between barrier + synchronize on both sides, max over ranks.  Returns the result block on rank 0."""
     import torch
@@ -527,7 +527,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
             out["parity_check"] = parity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_logL, d_misf, d_err)
         except Exception as ex:
             out["parity_check"] = {"n": 0, "error": repr(ex)}
-    if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline:
+    if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline and rf_roof:
         try:
             out["rf_roofline"] = rf_roofline(eng, spec, d_batches[0], B, L, dev)
         except Exception as ex:
@@ -653,6 +653,7 @@ def main():
             eng.set_swd_search("fast")
             try:
                 fast["c2"] = run_eval(args, eng, rank, world, dist, dev, "c2", dryrun, with_cpu=False)
+                fast["c3"] = run_eval(args, eng, rank, world, dist, dev, "c3", dryrun, with_cpu=False, rf_roof=False)
                 for w in ("c4", "c5"):
                     try:
                         fast[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
