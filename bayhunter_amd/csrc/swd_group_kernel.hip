@@ -572,7 +572,24 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                     if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
                 }
                 if (__ballot(live) == 0ull) break;
-                if (live) S.advance(dj);
+                if (FAST) {
+                    // a plain bracket step (three in four of this build's transitions): the value has del1's sign, the
+                    // velocity is inside the scan's bounds and the next request is the next grid point -- what advance()
+                    // does then, without its way through the continuation tags
+                    const double nx = (S.idir > 0) ? S.c2 + S.dc : S.c2 - S.dc;
+                    const bool plain = live && S.st == ST_STEP && !signs_differ(S.del1, dj) &&
+                                       !(S.c2 < S.cm || S.c2 >= S.betmxd + S.dc) && nx > S.clow;
+                    if (plain) {
+                        S.del2 = dj;
+                        S.c1 = S.c2;
+                        S.del1 = dj;
+                        S.c2 = nx;
+                        S.ceval = nx;
+                        ++S.evals;
+                    } else if (live) {
+                        S.advance(dj);
+                    }
+                } else if (live) S.advance(dj);
             }
         }
         if (prof) {
