@@ -152,6 +152,55 @@ def test_earth_flattening_and_deep_models(fast, oracle):
             assert np.array_equal(v, fv) and np.array_equal(e, fe)
 
 
+def test_broken_models_are_failed_in_band(fast, oracle):
+    """NaN / infinite / negative / absurd parameters are reported as failed without being searched, the healthy models
+    of the batch are unaffected (test_gpu_swd.py has the same for the reference sequence)."""
+    rs = np.random.RandomState(8)
+    nlay, h, vp, vs, rho = synth_models(rs, 24, 6)
+    vs[2, 0] = np.nan; vp[1, 1] = np.inf; h[0, 2] = np.nan; rho[3, 3] = -1.0; vs[:, 4] = -1.0; h[1, 5] = -5.0
+    vp[:, 6] = 1e-60; vs[:, 7] = 1e30
+    per = np.linspace(2, 40, 12)
+    good = np.arange(8, 24)
+    try:
+        for G, J in ((0, 0), (1, 4), (9, 2), (9, 7)):
+            fast.set_swd_group(G)
+            fast.set_swd_lookahead(J)
+            for iwave in (2, 1):
+                v, e = fast.swd_batch(nlay, h, vp, vs, rho, per, iwave, 0)
+                assert (e[:8] == 1).all() and (v[:8] == 0).all()
+                with oracle.swd_search(True):
+                    ov, oe, _ = oracle.swd_batch(nlay[good], h.T[good], vp.T[good], vs.T[good], rho.T[good], per, iwave, 0)
+                assert np.array_equal(v[good], ov) and np.array_equal(e[good], oe)
+    finally:
+        fast.set_swd_group(0)
+        fast.set_swd_lookahead(0)
+
+
+def test_speculative_chain_windows_stay_exact_with_the_short_refinement(fast):
+    """The short sequence is a function of the model alone, so the device-resident chains' speculative windows (many
+    proposals per launch, batch composition changing with the depth) still walk the one-iteration-per-launch trajectory
+    bit for bit -- and it is a different trajectory from the reference sequence's (1e-6 in a velocity flips a decision
+    sooner or later)."""
+    from test_gpu_device_chains import SETUPS, make_targets
+    from bayhunter_amd.device_chains import DeviceChains
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+    init = dict(su["init"], iter_burnin=420, iter_main=80, maxmodels=10)
+    keys = ("n", "vs", "z", "like", "noise", "vpvs", "misfits", "propdist", "accepted")
+
+    def run(depth):
+        return DeviceChains(make_targets(g), 8, init, su["priors"], seed=11, spec_depth=depth).run().state_host()
+
+    s1, s5 = run(1), run(5)
+    for k in keys:
+        assert np.array_equal(s1[k], s5[k]), k
+    fast.set_swd_search("reference")
+    r1 = run(1)
+    fast.set_swd_search("fast")
+    assert not np.array_equal(r1["like"], s1["like"])
+    assert abs(np.median(r1["like"]) - np.median(s1["like"])) < 0.2 * abs(np.median(r1["like"])) + 50.0
+
+
 def test_the_switch_is_per_engine_and_validated(engine):
     from bayhunter_amd.engine import EngineError
     assert engine.swd_search() == "reference"          # the default: the reference's bits
