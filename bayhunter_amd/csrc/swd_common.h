@@ -465,8 +465,11 @@ enum : int {
 // (measured: tests/test_gpu_swd.py), against north_star's 1e-5; NOT bit-identical, hence off by default.  The sequence
 // of evaluations is a function of the model alone (not of the launch plan): results do not depend on the batch.
 // oracle/swd_oracle.c (refine_root_fast) restates it for the bit-level check of the device.
-template <int XSC, int NLO = NEV_MAX, bool FAST = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+// FASTM: 0 = the reference sequence only; 1 = FAST as described (group-velocity targets fall through to the reference
+// sequence); 2 = FAST for launches WITHOUT group-velocity targets: nevill and the second-root logic are not compiled in.
+template <int XSC, int NLO = NEV_MAX, int FASTM = 0> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
+    static constexpr bool FAST = FASTM != 0, PHASE_ONLY = FASTM == 2;
     int XS = XSC;
     // constants of the reference's driver (compile-time: they cost no registers)
     static constexpr double one = 1.0e-2;
@@ -575,7 +578,7 @@ struct SearchT {
         const double cc = (double)cc1;
         cm = cc;
         betmxd = (double)betmx;
-        group = igr > 0;
+        group = !PHASE_ONLY && igr > 0;
         K = K_;
         per = per_;
         xl = xl_;
@@ -747,7 +750,7 @@ struct SearchT {
                 }
             }
         } else
-        switch (st) {
+        switch (PHASE_ONLY ? (st == ST_FIRST ? ST_FIRST : ST_STEP) : st) { // (PHASE_ONLY: nevill's states are never entered)
         case ST_FIRST:
             del1 = del;
             if (ifirst == 1) del1st = del1;
@@ -757,7 +760,7 @@ struct SearchT {
         case ST_STEP:
             del2 = del;
             if (signs_differ(del1, del2)) { // bracketed: enter nevill with (c1,c2,del1,del2)
-                if (FAST && !group) {
+                if (FAST && (PHASE_ONLY || !group)) {
                     have_p = false;
                     fit = 0;
                     // A bracket that reaches beyond the fastest S velocity (a root up there is rejected, :468-471, and the
@@ -972,5 +975,5 @@ struct SearchT {
     }
 };
 using SearchRt = SearchT<0>;
-using SearchRtFast = SearchT<0, NEV_MAX, true>;
+using SearchRtFast = SearchT<0, NEV_MAX, 1>;
 

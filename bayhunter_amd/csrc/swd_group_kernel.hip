@@ -169,7 +169,7 @@ __device__ __forceinline__ void wave_sync()
 // are to run beside the kernel -- a CU's eight wavefronts then hold two copies of the tables instead of four, which is
 // what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
 // FAST: the build with the optional short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
-template <int WPB, bool FAST>
+template <int WPB, int FASTM>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -276,8 +276,9 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const bool ragged = __ballot(mmax != mtop || llw != 1) != 0ull;
     const int col = li % 5;                          // the 5-vector component this lane owns
 
+    constexpr bool FAST = FASTM != 0;
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
-    SearchT<0, NEV_MAX, FAST> S;
+    SearchT<0, NEV_MAX, FASTM> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
            T.mode, cpl + g, cpl + (size_t)K * MPW + g);
@@ -867,25 +868,32 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         info->waves = (a.wg_n1 > 0) ? (long)a.wg_n0 + a.wg_n1 : (long)nwaves * a.ntargets;
         info->lds = lds;
     }
-    // (group-velocity targets keep the reference sequence: a launch of those alone takes the reference build, 10 % faster)
-    bool any_phase = false;
-    for (int t = 0; t < a.ntargets; ++t) any_phase = any_phase || a.t[t].igr == 0;
-    a.fast = (a.fast && any_phase) ? 1 : 0;
+    // build: 0 = reference sequence; with the short refinement asked for: 2 = no group-velocity target in the launch (nevill
+    // not compiled in), 1 = mixed (group-velocity targets keep the reference sequence), 0 = group-velocity targets only
+    bool any_phase = false, any_group = false;
+    for (int t = 0; t < a.ntargets; ++t) {
+        any_phase = any_phase || a.t[t].igr == 0;
+        any_group = any_group || a.t[t].igr != 0;
+    }
+    const int build = (a.fast && any_phase) ? (any_group ? 1 : 2) : 0;
+    a.fast = build;
+    const dim3 block(BH_WAVE * wpb);
     if (wpb == 4) {
         static bool big_lds = false;
         if (lds > WG_LDS_CAP && !big_lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(swd_group_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return -1;
+            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0>), reinterpret_cast<const void *>(swd_group_kernel<4, 1>),
+                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2>)};
+            for (const void *k : k4)
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
             big_lds = true;
         }
-        if (a.fast) hipLaunchKernelGGL((swd_group_kernel<4, true>), grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
-        else hipLaunchKernelGGL((swd_group_kernel<4, false>), grid, dim3(BH_WAVE * 4), lds, stream, a, redundant, (int)wave_lds);
+        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<4, 2>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<4, 1>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else hipLaunchKernelGGL((swd_group_kernel<4, 0>), grid, block, lds, stream, a, redundant, (int)wave_lds);
     } else {
-        if (a.fast) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, true>), grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
-        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, false>), grid, dim3(BH_WAVE * GROUP_WPB), lds, stream, a, redundant, (int)wave_lds);
+        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0>), grid, block, lds, stream, a, redundant, (int)wave_lds);
     }
     return 0;
 }

@@ -72,7 +72,7 @@ __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 // work array) and a workgroup is WPB wavefronts sharing ONE copy of the libm tables: WPB = 1 gives 7 wavefronts per
 // CU at 10 layers (10.2 + 5.1 + 0.25 + 5.5 KB; it was 5 with all 11 orders in LDS), WPB = 2 gives 8 -- 5-9 % faster
 // from 100 000 models on, 2.5 % slower below (the launcher picks).
-template <int IFUNC, bool LOOK, int LANE_WPB, bool FAST> // FAST: the build with the optional short refinement (SearchT, swd_common.h)
+template <int IFUNC, bool LOOK, int LANE_WPB, int FAST> // FAST: 0 the reference sequence, 2 the short refinement (a launch is one target: SearchT, swd_common.h)
 __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem_all[];
@@ -496,7 +496,7 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     const dim3 grid(two ? (waves + 1) / 2 : waves), block((two ? 2 : 1) * BH_WAVE);
     // (wave type, look-ahead, wavefronts per workgroup, refinement) -> instantiation
 #define BH_LANE_LAUNCH(IF, LK, WP, FS) hipLaunchKernelGGL((swd_kernel<IF, LK, WP, FS>), grid, block, lds, stream, b)
-#define BH_LANE_PICK_FS(IF, LK, WP) do { if (a.fast && a.igr == 0) BH_LANE_LAUNCH(IF, LK, WP, true); else BH_LANE_LAUNCH(IF, LK, WP, false); } while (0)
+#define BH_LANE_PICK_FS(IF, LK, WP) do { if (a.fast && a.igr == 0) BH_LANE_LAUNCH(IF, LK, WP, 2); else BH_LANE_LAUNCH(IF, LK, WP, 0); } while (0)
 #define BH_LANE_PICK_WP(IF, LK) do { if (two) BH_LANE_PICK_FS(IF, LK, 2); else BH_LANE_PICK_FS(IF, LK, 1); } while (0)
 #define BH_LANE_PICK_LK(IF) do { if (J > 1) BH_LANE_PICK_WP(IF, true); else BH_LANE_PICK_WP(IF, false); } while (0)
     if (iwave == 1) BH_LANE_PICK_LK(1);
