@@ -467,9 +467,11 @@ enum : int {
 // oracle/swd_oracle.c (refine_root_fast) restates it for the bit-level check of the device.
 // FASTM: 0 = the reference sequence only; 1 = FAST as described (group-velocity targets fall through to the reference
 // sequence); 2 = FAST for launches WITHOUT group-velocity targets: nevill and the second-root logic are not compiled in.
-template <int XSC, int NLO = NEV_MAX, int FASTM = 0> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+// SIMPLE: the launch holds fundamental-mode phase-velocity targets only (the usual inversion set-up): the second root of a
+// group velocity and the mode loop are not compiled in (fewer live registers in the round loop).
+template <int XSC, int NLO = NEV_MAX, int FASTM = 0, bool SIMPLE = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
-    static constexpr bool FAST = FASTM != 0, PHASE_ONLY = FASTM == 2;
+    static constexpr bool FAST = FASTM != 0, PHASE_ONLY = FASTM == 2, NOGROUP = PHASE_ONLY || SIMPLE;
     int XS = XSC;
     // constants of the reference's driver (compile-time: they cost no registers)
     static constexpr double one = 1.0e-2;
@@ -578,14 +580,14 @@ struct SearchT {
         const double cc = (double)cc1;
         cm = cc;
         betmxd = (double)betmx;
-        group = !PHASE_ONLY && igr > 0;
+        group = !NOGROUP && igr > 0;
         K = K_;
         per = per_;
         xl = xl_;
         yl = yl_;
         vel = vel_;
         writer = writer_;
-        mode = mode_;
+        mode = SIMPLE ? 1 : mode_;
         cper = cper_;
         cbper = cbper_;
         if (mode > 1)

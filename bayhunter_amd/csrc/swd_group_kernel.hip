@@ -169,7 +169,8 @@ __device__ __forceinline__ void wave_sync()
 // are to run beside the kernel -- a CU's eight wavefronts then hold two copies of the tables instead of four, which is
 // what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
 // FAST: the build with the optional short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
-template <int WPB, int FASTM>
+// PROF: the build with the evaluation counters, phase clocks and wavefront trace (launches with A.neval set).
+template <int WPB, int FASTM, bool SIMPLE, bool PROF>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
 
     constexpr bool FAST = FASTM != 0;
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
-    SearchT<0, NEV_MAX, FASTM> S;
+    SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
            T.mode, cpl + g, cpl + (size_t)K * MPW + g);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
     double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
-    const bool prof = (A.neval != nullptr);
+    const bool prof = PROF && (A.neval != nullptr);
     long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
     const unsigned long long w_start = prof ? wall_clock64() : 0ull, c_start = prof ? clock64() : 0ull;
     unsigned int nrounds = 0;
@@ -869,32 +870,49 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         info->lds = lds;
     }
     // build: 0 = reference sequence; with the short refinement asked for: 2 = no group-velocity target in the launch (nevill
-    // not compiled in), 1 = mixed (group-velocity targets keep the reference sequence), 0 = group-velocity targets only
-    bool any_phase = false, any_group = false;
+    // not compiled in), 1 = mixed (group-velocity targets keep the reference sequence), 0 = group-velocity targets only.
+    // simple: fundamental-mode phase velocities only (builds 0 and 2; no second root, no mode loop in the kernel).
+    bool any_phase = false, any_group = false, any_modes = false;
     for (int t = 0; t < a.ntargets; ++t) {
         any_phase = any_phase || a.t[t].igr == 0;
         any_group = any_group || a.t[t].igr != 0;
+        any_modes = any_modes || a.t[t].mode > 1;
     }
     const int build = (a.fast && any_phase) ? (any_group ? 1 : 2) : 0;
+    static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
+    const bool simple = !any_group && !any_modes && !no_simple;
     a.fast = build;
     const dim3 block(BH_WAVE * wpb);
-    if (wpb == 4) {
+    const bool counted = a.neval != nullptr;
+#define BH_GROUP_LAUNCH(WP, FM, SI, PR) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR>), grid, block, lds, stream, a, redundant, (int)wave_lds)
+    // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
+    // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
+    if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only)
         static bool big_lds = false;
         if (lds > WG_LDS_CAP && !big_lds) {
-            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0>), reinterpret_cast<const void *>(swd_group_kernel<4, 1>),
-                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2>)};
+            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true>),
+                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true>)};
             for (const void *k : k4)
                 if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
             big_lds = true;
         }
-        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<4, 2>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<4, 1>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else hipLaunchKernelGGL((swd_group_kernel<4, 0>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        if (build == 2) BH_GROUP_LAUNCH(4, 2, false, true);
+        else if (build == 1) BH_GROUP_LAUNCH(4, 1, false, true);
+        else BH_GROUP_LAUNCH(4, 0, false, true);
+    } else if (build == 2 && simple) {
+        if (counted) BH_GROUP_LAUNCH(GROUP_WPB, 2, true, true);
+        else BH_GROUP_LAUNCH(GROUP_WPB, 2, true, false);
+    } else if (build == 2) {
+        BH_GROUP_LAUNCH(GROUP_WPB, 2, false, true);
+    } else if (build == 1) {
+        BH_GROUP_LAUNCH(GROUP_WPB, 1, false, true);
+    } else if (simple) {
+        if (counted) BH_GROUP_LAUNCH(GROUP_WPB, 0, true, true);
+        else BH_GROUP_LAUNCH(GROUP_WPB, 0, true, false);
     } else {
-        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        BH_GROUP_LAUNCH(GROUP_WPB, 0, false, true);
     }
+#undef BH_GROUP_LAUNCH
     return 0;
 }
 
