@@ -95,6 +95,16 @@ __device__ Draws get_draws(const bh_chain_config &cfg, const bh_chain_state &S, 
     return d;
 }
 
+// the accept step's draw alone (the same bits as get_draws(...).u_accept, without the other five)
+__device__ double get_accept_draw(const bh_chain_config &cfg, const bh_chain_state &S, int c, int C, int iiter, int k)
+{
+    if (S.inject != nullptr) return S.inject[(size_t)k * 6 * C + 3 * (size_t)C + c];
+    Philox ph;
+    uint32_t q[4];
+    ph.gen(cfg.seed, (uint32_t)(cfg.chain_offset + (int64_t)c), (uint32_t)iiter, 1u, q);
+    return u01(q[2], q[3]);
+}
+
 enum { MV_VS = 0, MV_Z = 1, MV_BIRTH = 2, MV_DEATH = 3, MV_NOISE = 4, MV_VPVS = 5 };
 __device__ __forceinline__ int par_index(int mv) { return mv <= 1 ? mv : (mv <= 3 ? 2 : mv - 1); } // PAR_MAP
 
@@ -116,13 +126,19 @@ __device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, in
                           const double *lds_from = nullptr)
 {
     if (from_node >= 0 && lds_from != nullptr) {
-        P.n = (int)lds_from[0];
-        P.vpvs = lds_from[2];
-        for (int i = 0; i < 2 * nt; ++i) P.noise[i] = lds_from[3 + i];
-        const double *fv = lds_from + 3 + 2 * nt, *fz = fv + (ML + 1);
-        for (int i = 0; i < P.n; ++i) {
-            P.vs[i] = fv[i];
-            P.z[i] = fz[i];
+        // (source and destination records never overlap: told to the compiler so that the LDS reads of several
+        // elements are in flight together -- one wavefront per chain, every dependent LDS round trip is ~100 cycles)
+        const double *__restrict__ src = lds_from;
+        double *__restrict__ pn = P.noise, *__restrict__ pv = P.vs, *__restrict__ pz = P.z;
+        P.n = (int)src[0];
+        P.vpvs = src[2];
+        for (int i = 0; i < 2 * nt; ++i) pn[i] = src[3 + i];
+        const double *__restrict__ fv = src + 3 + 2 * nt, *__restrict__ fz = fv + (ML + 1);
+        const int n = P.n;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            pv[i] = fv[i];
+            pz[i] = fz[i];
         }
         return;
     }
@@ -146,15 +162,21 @@ __device__ void load_base(const bh_chain_state &S, int C, size_t ldp, int nt, in
     }
 }
 
-__device__ __forceinline__ void layer_thicknesses(const Params &P, double *h)
+__device__ __forceinline__ void layer_thicknesses(const Params &P, double *h_)
 {
-    double prev = 0.0;
-    for (int i = 0; i + 1 < P.n; ++i) {
-        const double zd = (P.z[i] + P.z[i + 1]) / 2.;
+    const double *__restrict__ z = P.z;
+    double *__restrict__ h = h_;
+    const int n = P.n;
+    double prev = 0.0, zi = n >= 1 ? z[0] : 0.0;
+#pragma unroll 4
+    for (int i = 0; i + 1 < n; ++i) {
+        const double zn = z[i + 1];
+        const double zd = (zi + zn) / 2.;
         h[i] = zd - prev;
         prev = zd;
+        zi = zn;
     }
-    if (P.n >= 1) h[P.n - 1] = 0.0;
+    if (n >= 1) h[n - 1] = 0.0;
 }
 
 // One proposal (SingleChain.py:246-420, :511-556; Models.py:26-52): from the state of `from_node`, with the draws of
@@ -252,8 +274,14 @@ __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const b
         if (vpvs < cfg.vpvsmin || vpvs > cfg.vpvsmax) valid = false;
     }
     // nuclei sorted by depth (:315-328); insertion sort is stable like the reference's argsort use
+    double ztop = n > 0 ? z[0] : 0.0; // largest depth so far = z[i - 1] once the first i nuclei are in order
     for (int i = 1; i < n; ++i) {
-        const double zi = z[i], vi = vs[i];
+        const double zi = z[i];
+        if (!(ztop > zi)) { // already in place (the usual case: one nucleus moved at most)
+            ztop = zi;
+            continue;
+        }
+        const double vi = vs[i];
         int j = i - 1;
         while (j >= 0 && z[j] > zi) {
             z[j + 1] = z[j];
@@ -271,17 +299,25 @@ __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const b
     if (valid && (mv <= MV_DEATH)) {
         const int layermodel = n - 1;
         if (!(layermodel >= cfg.layermin && layermodel <= cfg.layermax)) valid = false;
-        double zc = 0.0;
-        for (int i = 0; i < n && valid; ++i) {
-            if (i < n - 1 && h[i] < cfg.thickmin) valid = false;
-            if (vs[i] < cfg.vsmin || vs[i] > cfg.vsmax) valid = false;
-            zc += h[i];
-            if (zc < cfg.zmin || zc > cfg.zmax) valid = false;
+        // (every layer is looked at, no early exit: the tests have no side effects and the reads can be in flight together)
+        const double *__restrict__ rh = h, *__restrict__ rv = vs;
+        double zc = 0.0, vi = n > 0 ? rv[0] : 0.0;
+        bool ok = true;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            const double hi = rh[i];
+            const double vn = (i + 1 < n) ? rv[i + 1] : 0.0;
+            if (i < n - 1 && hi < cfg.thickmin) ok = false;
+            if (vi < cfg.vsmin || vi > cfg.vsmax) ok = false;
+            zc += hi;
+            if (zc < cfg.zmin || zc > cfg.zmax) ok = false;
             if (i + 1 < n) {
-                if (cfg.lvz >= 0.0 && !(vs[i + 1] - vs[i] * (1 - cfg.lvz) > 0)) valid = false;
-                if (cfg.hvz >= 0.0 && !(vs[i] * (1 + cfg.hvz) - vs[i + 1] > 0)) valid = false;
+                if (cfg.lvz >= 0.0 && !(vn - vi * (1 - cfg.lvz) > 0)) ok = false;
+                if (cfg.hvz >= 0.0 && !(vi * (1 + cfg.hvz) - vn > 0)) ok = false;
             }
+            vi = vn;
         }
+        valid = valid && ok;
     }
     // ---- write the proposal and the layered model (invalid: re-evaluate the model it started from) ---------
     const size_t col = (size_t)node * C + c;
@@ -299,20 +335,24 @@ __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const b
     *valid_out = valid;
     S.pn[col] = n;
     S.pvpvs[col] = vpvs;
-    for (int i = 0; i < n; ++i) {
-        S.pvs[(size_t)i * ldp + col] = vs[i];
-        S.pz[(size_t)i * ldp + col] = z[i];
-    }
     for (int i = 0; i < 2 * nt; ++i) S.pnoise[col * 2 * nt + i] = noise[i]; // [columns][2nt]: evaluate's layout
     // vp: crustal vp/vs down to the first layer with vs >= mantle[0], mantle[1] below (Models.py:26-37)
-    bool deep = false;
-    for (int i = 0; i < n; ++i) {
-        if (cfg.mantle_vs > 0.0 && vs[i] >= cfg.mantle_vs) deep = true;
-        S.lay_h[(size_t)i * ldp + col] = h[i];
-        S.lay_vs[(size_t)i * ldp + col] = vs[i];
-        const double vpi = vs[i] * (deep ? cfg.mantle_vpvs : vpvs);
-        S.lay_vp[(size_t)i * ldp + col] = vpi;
-        if (S.lay_rho != nullptr) S.lay_rho[(size_t)i * ldp + col] = vpi * 0.32 + 0.77; // as rho_from_vp_kernel (Targets.py:319)
+    {
+        // (one pass over the node's arrays; they are only read here and the global arrays only written)
+        const double *__restrict__ rv = vs, *__restrict__ rz = z, *__restrict__ rh = h;
+        bool deep = false;
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) {
+            const double vi = rv[i], zi = rz[i], hi = rh[i];
+            if (cfg.mantle_vs > 0.0 && vi >= cfg.mantle_vs) deep = true;
+            S.pvs[(size_t)i * ldp + col] = vi;
+            S.pz[(size_t)i * ldp + col] = zi;
+            S.lay_h[(size_t)i * ldp + col] = hi;
+            S.lay_vs[(size_t)i * ldp + col] = vi;
+            const double vpi = vi * (deep ? cfg.mantle_vpvs : vpvs);
+            S.lay_vp[(size_t)i * ldp + col] = vpi;
+            if (S.lay_rho != nullptr) S.lay_rho[(size_t)i * ldp + col] = vpi * 0.32 + 0.77; // as rho_from_vp_kernel (Targets.py:319)
+        }
     }
     S.lay_n[col] = n;
 }
@@ -392,7 +432,7 @@ __global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C
         const size_t col = (size_t)node * C + c;
         bool accepted = false;
         if (S.valid[col]) {
-            const Draws d = get_draws(cfg, S, c, C, iiter + k, k);
+            const double u_accept = get_accept_draw(cfg, S, c, C, iiter + k, k);
             const int mv = S.move[col];
             const int pi = par_index(mv);
             S.proposed[pi * (size_t)C + c] += 1.0;
@@ -408,7 +448,7 @@ __global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C
             } else {
                 alpha = dl;
             }
-            if (log(d.u_accept) < alpha) {
+            if (log(u_accept) < alpha) {
                 accepted = true;
                 last = node;
                 cur = like;
