@@ -72,7 +72,9 @@ __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 // work array) and a workgroup is WPB wavefronts sharing ONE copy of the libm tables: WPB = 1 gives 7 wavefronts per
 // CU at 10 layers (10.2 + 5.1 + 0.25 + 5.5 KB; it was 5 with all 11 orders in LDS), WPB = 2 gives 8 -- 5-9 % faster
 // from 100 000 models on, 2.5 % slower below (the launcher picks).
-template <int IFUNC, bool LOOK, int LANE_WPB, int FAST> // FAST: 0 the reference sequence, 2 the short refinement (a launch is one target: SearchT, swd_common.h)
+// FAST: 0 the reference sequence, 2 the short refinement (a launch is one target); SIMPLE: a fundamental-mode phase-velocity
+// launch (SearchT, swd_common.h: no second root, no mode loop)
+template <int IFUNC, bool LOOK, int LANE_WPB, int FAST, bool SIMPLE>
 __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem_all[];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
     md.rho = mdl + 3 * Lmax * BH_WAVE + lane;
     const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
 
-    SearchT<BH_WAVE, NEV_LO, FAST> S;
+    SearchT<BH_WAVE, NEV_LO, FAST, SIMPLE> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
            cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
     {
@@ -495,8 +497,20 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     const size_t lds = LANE_TAB_PAD + (two ? 2 : 1) * wb;
     const dim3 grid(two ? (waves + 1) / 2 : waves), block((two ? 2 : 1) * BH_WAVE);
     // (wave type, look-ahead, wavefronts per workgroup, refinement) -> instantiation
-#define BH_LANE_LAUNCH(IF, LK, WP, FS) hipLaunchKernelGGL((swd_kernel<IF, LK, WP, FS>), grid, block, lds, stream, b)
-#define BH_LANE_PICK_FS(IF, LK, WP) do { if (a.fast && a.igr == 0) BH_LANE_LAUNCH(IF, LK, WP, 2); else BH_LANE_LAUNCH(IF, LK, WP, 0); } while (0)
+    static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
+    // Measured (c2 batches, with / without): reference sequence -3 % at B = 16 384 (4 trial lanes per model) but +4 % at
+    // 65 536 and +6 % at 131 072 (one lane per model: the Love build drops to 165 registers there, a third wavefront per SIMD
+    // upsets the Rayleigh / Love pairs the time-sliced priorities are tuned for); short refinement -3 % at 65 536.
+    const bool simple = a.igr == 0 && a.mode <= 1 && !no_simple && (J > 1 || a.fast);
+#define BH_LANE_LAUNCH(IF, LK, WP, FS, SI) hipLaunchKernelGGL((swd_kernel<IF, LK, WP, FS, SI>), grid, block, lds, stream, b)
+#define BH_LANE_PICK_FS(IF, LK, WP)                                                  \
+    do {                                                                             \
+        if (a.fast && a.igr == 0) {                                                  \
+            if (simple) BH_LANE_LAUNCH(IF, LK, WP, 2, true);                         \
+            else BH_LANE_LAUNCH(IF, LK, WP, 2, false);                               \
+        } else if (simple) BH_LANE_LAUNCH(IF, LK, WP, 0, true);                      \
+        else BH_LANE_LAUNCH(IF, LK, WP, 0, false);                                   \
+    } while (0)
 #define BH_LANE_PICK_WP(IF, LK) do { if (two) BH_LANE_PICK_FS(IF, LK, 2); else BH_LANE_PICK_FS(IF, LK, 1); } while (0)
 #define BH_LANE_PICK_LK(IF) do { if (J > 1) BH_LANE_PICK_WP(IF, true); else BH_LANE_PICK_WP(IF, false); } while (0)
     if (iwave == 1) BH_LANE_PICK_LK(1);
