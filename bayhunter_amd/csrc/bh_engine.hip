@@ -300,6 +300,13 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                          base + 3 * ne, base + 4 * ne, st);
         sh = base; svp = base + ne; svs = base + 2 * ne; srl = base + 3 * ne; srr = base + 4 * ne;
     }
+    // Typical depth of the batch (0 = unknown: the array capacity is planned for).  Ignored where every (model, target) gets a
+    // wavefront of its own anyway (at most 2048 of them: the chip's two per SIMD) -- the regime of the chains' speculative
+    // windows.  There a depth class of its own for the shallow bulk buys nothing (the models per wavefront cannot grow), the
+    // narrower lane groups cost a second pass over the layers and seven instead of four trials per round more transitions:
+    // measured on windows of 1016 models of 3-9 layers in arrays of 21 (c4): 1.50 ms without the hint, 1.70-1.83 ms with it.
+    const int typ_given = m.typ_layers > 0 ? m.typ_layers : e->hint_layers;
+    const int typ_layers = ((long)nlive * B <= 2048) ? 0 : typ_given;
     int iw[BH_MAX_TARGETS], look[BH_MAX_TARGETS], G = 1;
     {
         int n = 0;
@@ -307,7 +314,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             if (jobs[j].K != 0) iw[n++] = jobs[j].iwave;
         // lanes per model follow the TYPICAL depth of the batch (deeper models take further passes over
         // their layers): known for host batches, a caller's hint for device-resident ones, else Lmax
-        int Lplan = m.typ_layers > 0 ? m.typ_layers : (e->hint_layers > 0 ? e->hint_layers : Lmax);
+        int Lplan = typ_layers > 0 ? typ_layers : Lmax;
         if (Lplan > Lmax) Lplan = Lmax;
         bh_swd_plan(B, Lplan, n, iw, e->force_group, &G, look);
         if (e->force_look > 0)
@@ -341,12 +348,12 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     static const int pair_min = std::getenv("BH_SWD_PAIR_MINWAVES") ? std::atoi(std::getenv("BH_SWD_PAIR_MINWAVES")) : -1;
     const bool use_pair = B > 1 && !e->no_order && !e->as_given && !e->no_pair && G > 1 && nlive == 2 && bh_pair_order_fits(B) &&
                           plan_waves >= (pair_min >= 0 ? pair_min : 7 * (long)e->pairwork.ncu) && (pair_min >= 0 || 2 * wmax >= 3 * wmin) &&
-                          !(((m.typ_layers > 0 ? m.typ_layers : e->hint_layers) > 0) && (m.typ_layers > 0 ? m.typ_layers : e->hint_layers) + 2 < Lmax);
+                          !(typ_layers > 0 && typ_layers + 2 < Lmax);
     if (B > 1 && !e->no_order && !e->as_given && !use_pair) {
         if ((rc = ensure(e, e->perm, ((size_t)B + 4) * sizeof(int32_t)))) return rc;
         int32_t *p = (int32_t *)e->perm.p;
         // LDS rows for the bulk of the batch: its typical depth plus a margin; deeper models get their own launch
-        const int typ = m.typ_layers > 0 ? m.typ_layers : e->hint_layers;
+        const int typ = typ_layers;
         if (typ > 0 && typ + 2 < Lmax) Lcut = typ + 2;
         bh_launch_order(B, m.nlay, p + 4, Lcut, p, st);
         perm = p + 4;
@@ -432,6 +439,15 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     a.started = e->started;
     a.prio_low = e->swd_prio_low_now;
     a.fast = e->swd_search;
+    {
+        static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
+        if (dbg) {
+            std::fprintf(stderr, "[bh] dispersion plan B=%d Lmax=%d: lanes per model %d, typical layers %d (hint %d), Lcut %d%s, pairing %d; trials per round:",
+                         B, Lmax, G, m.typ_layers, e->hint_layers, Lcut, split ? " (two depth classes)" : "", (int)use_pair);
+            for (int t = 0; t < a.ntargets; ++t) std::fprintf(stderr, " %s %d/%d", a.t[t].iwave == BH_WAVE_LOVE ? "L" : "R", a.t[t].look, a.t[t].inlook);
+            std::fprintf(stderr, "\n");
+        }
+    }
     ev_begin(e, 0, st);
     const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
     ev_end(e, 0, st);

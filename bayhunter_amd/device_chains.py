@@ -220,9 +220,17 @@ class DeviceChains(object):
         return max(1, w)
 
     # ---- one lock-step window of all chains: three enqueues, no synchronisation ---------------------
+    HINT_EVERY = 64
+
     def iterate(self):
         """Advance every chain by `window()` iterations (1 with spec_depth = 1); returns that number."""
         e, t, Cn = self.engine, self.t, self.C
+        # transdimensional chains: the dispersion kernel's lane groups and LDS rows are sized for the models the chains
+        # hold NOW (typically 5-7 layers in arrays of 21), refreshed every HINT_EVERY launches (one small read-back; run()
+        # also does it at every snapshot).  The engine uses it for batches of more than a wavefront's worth of models per
+        # SIMD pair (many chains); a window of ~1000 models gets one wavefront per model whatever its depth.
+        if self.launches % self.HINT_EVERY == 0:
+            e.set_typical_layers(int(self.torch.ceil(t["n"].double().mean()).item()))
         w = self.window()
         B = Cn * ((1 << w) - 1)
         e.chain_propose_window(self.cfg, self.state, Cn, self.iiter, w, self.ld)
