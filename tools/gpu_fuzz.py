@@ -25,7 +25,7 @@ if FAST:
 worst, flagdiff, zerodiff, nmodels = 0.0, 0, 0, 0
 t0 = time.time()
 for it in range(ncfg):
-    B = int(rs.choice([1, 2, 7, 33, 64, 65, 200, 700, 1500]))
+    B = int(rs.choice([1, 2, 7, 33, 64, 65, 200, 700, 1500, 2600]))   # (2600: above the batch size below which the depth hint is ignored)
     L = int(rs.choice([2, 3, 5, 8, 10, 13, 17, 21, 30]))
     ragged = bool(rs.rand() < 0.6) and L > 2
     nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=float(rs.choice([0.0, 0.2, 0.5])), ragged=ragged)
