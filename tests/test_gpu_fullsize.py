@@ -81,7 +81,7 @@ def test_ragged_device_batch_any_depth_hint(engine, oracle, hint):
     order by depth, two depth classes in one launch) -- velocities and flags are those of the oracle."""
     import torch
     rs = np.random.RandomState(17)
-    Bn, L = 1500, 21
+    Bn, L = 2600, 21   # (above 2048 models per call: below, every model has a wavefront of its own and the engine ignores the hint)
     nlay, h, vp, vs, rho = synth_models(rs, Bn, L, lvz_frac=0.2, ragged=True)
     shallow = rs.rand(Bn) < 0.8                           # 80 % of the models keep at most 7 layers
     for b in np.flatnonzero(shallow):
