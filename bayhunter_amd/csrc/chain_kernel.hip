@@ -497,6 +497,104 @@ __global__ void chain_accept_kernel(bh_chain_config cfg, bh_chain_state S, int C
     }
 }
 
+// A wavefront per chain: walk the realised path through the window's tree (depth > 1).  Same decisions and the same bits as
+// `depth` rounds of chain_accept_kernel; what differs is where the operands wait: the tree's per-node values (valid, move,
+// logL, birth/death term) are fetched by all lanes at once -- node j in lane j mod 64 -- and the window's accept draws by
+// the first `depth` lanes, so that the walk itself is shuffles instead of three dependent global loads and a Philox
+// evaluation per level (24 -> 9 us at depth 7); the counters of the five proposal types sit in lanes 0..4 and are written
+// back once; the committed model is copied one layer per lane.
+__global__ __launch_bounds__(64) void chain_accept_window_kernel(bh_chain_config cfg, bh_chain_state S, int C, size_t ldp, int iiter, int depth,
+                                                                  const double *logL, const double *misfits)
+{
+    const int c = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (c >= C) return;
+    const int nt = cfg.nt, N = (1 << depth) - 1;
+    int valid0 = 0, valid1 = 0, mv0 = 0, mv1 = 0;
+    double like0 = 0.0, like1 = 0.0, dv0 = 0.0, dv1 = 0.0;
+    if (lane < N) {
+        const size_t col = (size_t)lane * C + c;
+        valid0 = S.valid[col]; mv0 = S.move[col]; like0 = logL[col]; dv0 = S.dvs2[col];
+    }
+    if (lane + 64 < N) {
+        const size_t col = (size_t)(lane + 64) * C + c;
+        valid1 = S.valid[col]; mv1 = S.move[col]; like1 = logL[col]; dv1 = S.dvs2[col];
+    }
+    const double udraw = (lane < depth) ? get_accept_draw(cfg, S, c, C, iiter + lane, lane) : 0.5;
+    double cur = S.like[c];
+    const double beta = S.beta ? S.beta[c] : 1.0;
+    const double theta = S.propdist[2 * (size_t)C + c]; // (changes only in the adaptation, after the window's last decision)
+    double prop = lane < 5 ? S.proposed[lane * (size_t)C + c] : 0.0, acc = lane < 5 ? S.accepted[lane * (size_t)C + c] : 0.0;
+    long long nacc = (long long)S.naccepted[c];
+    int node = 0, last = -1;
+    for (int k = 0; k < depth; ++k) {
+        const int src = node & 63;
+        const bool hi = node >= 64;
+        const int va = __shfl(valid0, src), vb = __shfl(valid1, src), ma = __shfl(mv0, src), mb = __shfl(mv1, src);
+        const double la = __shfl(like0, src), lb = __shfl(like1, src), da = __shfl(dv0, src), db = __shfl(dv1, src);
+        const double u_accept = __shfl(udraw, k);
+        bool accepted = false;
+        if (hi ? vb : va) {
+            const int mv = hi ? mb : ma;
+            const int pi = par_index(mv);
+            if (lane == pi) prop += 1.0;
+            const double like = hi ? lb : la;
+            const double dl = (S.beta ? beta * (like - cur) : like - cur);
+            double alpha;
+            if (mv == MV_BIRTH || mv == MV_DEATH) { // Bodin et al. (2012), SingleChain.py:468-485
+                const double dv = cfg.vsmax - cfg.vsmin;
+                const double Bt = (hi ? db : da) / (2. * (theta * theta));
+                if (mv == MV_BIRTH) alpha = log((theta * sqrt(2 * M_PI)) / dv) + Bt + dl;
+                else alpha = log(dv / (theta * sqrt(2 * M_PI))) - Bt + dl;
+            } else {
+                alpha = dl;
+            }
+            if (log(u_accept) < alpha) {
+                accepted = true;
+                last = node;
+                cur = like;
+                if (lane == pi) acc += 1.0;
+                nacc += 1;
+            }
+            // proposal-width adaptation (SingleChain.py:425-450): the last decision of a window only (the host sees to it)
+            if ((iiter + k) % 1000 == 0) {
+                const bool all = (__ballot(lane < 5 && prop != 0.0) & 0x1full) == 0x1full;
+                if (all && lane < 5) {
+                    const double rate = acc / prop * 100;
+                    double pd = S.propdist[lane * (size_t)C + c];
+                    if (rate < cfg.acc_lo) {
+                        pd = pd * 0.95;
+                        if (pd < 0.001) pd = 0.001;
+                    } else if (rate > cfg.acc_hi) {
+                        pd = pd * 1.05;
+                    }
+                    S.propdist[lane * (size_t)C + c] = pd;
+                }
+            }
+        }
+        node = 2 * node + (accepted ? 2 : 1);
+    }
+    if (lane < 5) {
+        S.proposed[lane * (size_t)C + c] = prop;
+        S.accepted[lane * (size_t)C + c] = acc;
+    }
+    if (lane == 0) S.naccepted[c] = nacc;
+    if (last >= 0) { // the last accepted proposal of the window becomes the chain's state
+        const size_t col = (size_t)last * C + c;
+        const int n = S.pn[col];
+        for (int i = lane; i < cfg.maxlayers; i += 64) { // (rows beyond n are kept at zero, see chain_accept_kernel)
+            S.vs[(size_t)i * C + c] = i < n ? S.pvs[(size_t)i * ldp + col] : 0.0;
+            S.z[(size_t)i * C + c] = i < n ? S.pz[(size_t)i * ldp + col] : 0.0;
+        }
+        for (int i = lane; i < 2 * nt; i += 64) S.noise[(size_t)i * C + c] = S.pnoise[col * 2 * nt + i];
+        for (int i = lane; i <= nt; i += 64) S.misfits[(size_t)i * C + c] = misfits[col * (nt + 1) + i];
+        if (lane == 0) {
+            S.n[c] = n;
+            S.vpvs[c] = S.pvpvs[col];
+            S.like[c] = cur;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -536,8 +634,12 @@ int bh_chain_accept_window(void *stream, const bh_chain_config *cfg, const bh_ch
     for (int k = 0; k + 1 < depth; ++k)
         if ((iiter + k) % 1000 == 0) return BH_EINVAL;
     if (C == 0) return BH_OK;
-    hipLaunchKernelGGL(chain_accept_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, (size_t)ld,
-                       iiter, depth, logL, misfits);
+    if (depth > 1) // a wavefront per chain
+        hipLaunchKernelGGL(chain_accept_window_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, (size_t)ld, iiter, depth,
+                           logL, misfits);
+    else
+        hipLaunchKernelGGL(chain_accept_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, *cfg, *state, C, (size_t)ld,
+                           iiter, depth, logL, misfits);
     return hipGetLastError() == hipSuccess ? BH_OK : BH_EHIP;
 }
 
