@@ -183,10 +183,9 @@ __device__ __forceinline__ void layer_thicknesses(const Params &P, double *h_)
 // iteration `iiter`, into column node*C + c of the proposal arrays (leading dimension ldp).
 // `P` brings the storage; `lds_from` as in load_base.
 __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const bh_chain_state &S, int C, size_t ldp, int c, int iiter,
-                                             int k, int from_node, int node, Params &P, const double *lds_from, bool *valid_out)
+                                             int from_node, int node, Params &P, const double *lds_from, bool *valid_out, const Draws &d)
 {
     const int ML = cfg.maxlayers, nt = cfg.nt;
-    const Draws d = get_draws(cfg, S, c, C, iiter, k);
     // ---- which modification (SingleChain.py:512-517, :596-599) ---------------------------------
     int nnoise = 0;
     for (int i = 0; i < 2 * nt; ++i) nnoise += (cfg.noise_lo[i] != cfg.noise_hi[i]);
@@ -366,7 +365,7 @@ __global__ void chain_propose_kernel(bh_chain_config cfg, bh_chain_state S, int 
     Params P;
     P.vs = vs; P.z = z; P.h = h; P.noise = noise;
     bool valid;
-    propose_node(cfg, S, C, (size_t)C, c, iiter, 0, -1, 0, P, nullptr, &valid);
+    propose_node(cfg, S, C, (size_t)C, c, iiter, -1, 0, P, nullptr, &valid, get_draws(cfg, S, c, C, iiter, 0));
 }
 
 // Speculative window: T = 2^(depth-1) lanes per chain (64 / T chains per single-wavefront workgroup); level k of the
@@ -388,7 +387,17 @@ __global__ __launch_bounds__(64) void chain_propose_window_kernel(bh_chain_confi
     const int nt = cfg.nt, ML = cfg.maxlayers;
     const int RS = node_rec_doubles(nt, ML) | 1; // odd stride: neighbouring nodes start in different banks
     double *mine = tree + (size_t)slot * N * RS;  // this chain's records
+    // The draws of iteration iiter + k are the same for every node of level k: lane k of the chain computes them (four Philox
+    // blocks, a logarithm, a square root and a cosine: 3 us when every level did it for itself, 21 of the kernel's 70 us at
+    // depth 7), the level's lanes fetch them.  (2^(depth-1) >= depth: the chain has a lane for every level.)
+    Draws mydraws = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < C && p < depth) mydraws = get_draws(cfg, S, c, C, iiter + p, p);
     for (int k = 0; k < depth; ++k) {
+        const int srcl = slot * T + k;
+        Draws d;
+        d.u_move = __shfl(mydraws.u_move, srcl); d.u_index = __shfl(mydraws.u_index, srcl);
+        d.u_z = __shfl(mydraws.u_z, srcl); d.u_accept = __shfl(mydraws.u_accept, srcl);
+        d.u_noise = __shfl(mydraws.u_noise, srcl); d.normal = __shfl(mydraws.normal, srcl);
         if (c < C && p < (1 << k)) {
             const int node = (1 << k) - 1 + p;
             // nearest ancestor entered through its "accepted" edge whose proposal was valid
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(64) void chain_propose_window_kernel(bh_chain_confi
             P.z = P.vs + (ML + 1);
             P.h = P.z + (ML + 1);
             bool valid;
-            propose_node(cfg, S, C, ldp, c, iiter + k, k, from, node, P, from >= 0 ? mine + (size_t)from * RS : nullptr, &valid);
+            propose_node(cfg, S, C, ldp, c, iiter + k, from, node, P, from >= 0 ? mine + (size_t)from * RS : nullptr, &valid, d);
             rec[0] = (double)P.n;
             rec[1] = valid ? 1.0 : 0.0;
             rec[2] = P.vpvs;
