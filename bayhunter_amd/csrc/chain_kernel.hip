@@ -179,6 +179,22 @@ __device__ __forceinline__ void layer_thicknesses(const Params &P, double *h_)
     if (n >= 1) h[n - 1] = 0.0;
 }
 
+// index of the nucleus nearest in depth to zb (first one on ties, like the reference's argmin); reads only
+__device__ __forceinline__ int nearest_nucleus(const double *__restrict__ z, int n, double zb)
+{
+    int near = 0;
+    double best = fabs(z[0] - zb);
+#pragma unroll 4
+    for (int i = 1; i < n; ++i) {
+        const double di = fabs(z[i] - zb);
+        if (di < best) {
+            best = di;
+            near = i;
+        }
+    }
+    return near;
+}
+
 // One proposal (SingleChain.py:246-420, :511-556; Models.py:26-52): from the state of `from_node`, with the draws of
 // iteration `iiter`, into column node*C + c of the proposal arrays (leading dimension ldp).
 // `P` brings the storage; `lds_from` as in load_base.
@@ -221,13 +237,7 @@ __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const b
         z[ind] = z[ind] + d.normal * S.propdist[1 * (size_t)C + c];
     } else if (mv == MV_BIRTH) {
         const double zb = cfg.zmin + d.u_z * (cfg.zmax - cfg.zmin);
-        int near = 0;
-        double best = fabs(z[0] - zb);
-        for (int i = 1; i < n; ++i)
-            if (fabs(z[i] - zb) < best) {
-                best = fabs(z[i] - zb);
-                near = i;
-            }
+        const int near = nearest_nucleus(z, n, zb);
         const double vb = vs[near] + d.normal * S.propdist[2 * (size_t)C + c];
         dvs2 = (vb - vs[near]) * (vb - vs[near]);
         if (n >= ML) valid = false; // would exceed the layer prior anyway
@@ -247,13 +257,7 @@ __device__ __forceinline__ void propose_node(const bh_chain_config &cfg, const b
         n -= 1;
         if (n < 1) valid = false;
         else {
-            int near = 0;
-            double best = fabs(z[0] - zb);
-            for (int i = 1; i < n; ++i)
-                if (fabs(z[i] - zb) < best) {
-                    best = fabs(z[i] - zb);
-                    near = i;
-                }
+            const int near = nearest_nucleus(z, n, zb);
             dvs2 = (vs[near] - vb) * (vs[near] - vb);
         }
     } else if (mv == MV_NOISE) {
