@@ -109,6 +109,7 @@ class DeviceChains(object):
         self.ld = self.C * ((1 << self.depth) - 1)        # columns of the proposal arrays: all nodes of all chains
         self.snap_in_run = False                          # run(): windows also end at snapshot iterations
         self.launches = 0
+        self._hint = 0
         self._dev_exchange = None
         from .parallel import chain_layout, chain_seeds, rank_chain_counts
         self.rank_counts = rank_chain_counts(self.C, dist, int(device))       # collective buffers on THIS rank's GPU
@@ -230,13 +231,17 @@ class DeviceChains(object):
         # also does it at every snapshot).  The engine uses it for batches of more than a wavefront's worth of models per
         # SIMD pair (many chains); a window of ~1000 models gets one wavefront per model whatever its depth.
         if self.launches % self.HINT_EVERY == 0:
-            e.set_typical_layers(int(self.torch.ceil(t["n"].double().mean()).item()))
+            self._hint = int(self.torch.ceil(t["n"].double().mean()).item())
         w = self.window()
         B = Cn * ((1 << w) - 1)
         e.chain_propose_window(self.cfg, self.state, Cn, self.iiter, w, self.ld)
-        e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
-                             t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
-                             self.mis.data_ptr(), self.err.data_ptr())
+        e.set_typical_layers(self._hint)       # (for this call only: the engine is shared with other callers)
+        try:
+            e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
+                                 t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
+                                 self.mis.data_ptr(), self.err.data_ptr())
+        finally:
+            e.set_typical_layers(0)
         e.chain_accept_window(self.cfg, self.state, Cn, self.iiter, w, self.ld, self.logL.data_ptr(), self.mis.data_ptr())
         self.iiter += w
         self.launches += 1
@@ -276,7 +281,7 @@ class DeviceChains(object):
                    beta=None if t["beta"] is None else t["beta"].cpu().numpy())
         self.snap["p1" if self.iiter < 0 else "p2"].append(row)
         # transdimensional chains: size the dispersion kernel's lane groups for the models the chains hold now
-        self.engine.set_typical_layers(int(np.ceil(row["n"].mean())))
+        self._hint = int(np.ceil(row["n"].mean()))
 
     def run(self, progress=None):
         self.snap_in_run = True
@@ -291,7 +296,6 @@ class DeviceChains(object):
         finally:
             self.snap_in_run = False
         self.engine.synchronize()
-        self.engine.set_typical_layers(0)
         return self
 
     # ---- results -------------------------------------------------------------------------------------

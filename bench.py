@@ -265,6 +265,7 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
     elapsed = time.perf_counter() - t0
     ncalls, tot_ms, fam_ms = eng.timing_collect()
     eng.set_instrumentation(timing=False, counting=False)
+    eng.set_typical_layers(0)      # (the engine is shared with the evaluate workloads that follow)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
