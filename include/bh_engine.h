@@ -93,7 +93,7 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  *     the reference sequence: a group velocity is a difference quotient of two roots and amplifies their scatter a
  *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5); the failure
  *     flag agrees except where the reference's own outcome hinges on a 1e-6 shift of its scan grid (a Love root within
- *     ~1.3e-3 km/s of the half-space velocity at the LAST period: 112 of 7.3 million random models);
+ *     ~1.3e-3 km/s of the half-space velocity at the LAST period: 145 of 9.4 million random models);
  *     a deterministic function of the model (independent of batch and launch plan), but NOT the
  *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
  * Also BH_SWD_SEARCH=fast in the environment at engine creation. */
