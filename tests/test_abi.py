@@ -27,6 +27,16 @@ def test_library_built_and_exports_every_declared_symbol():
     assert lib.bh_abi_version() == 5
 
 
+def test_python_constants_mirror_the_header():
+    """Enumerations the ctypes layer restates (error codes, target kinds, laws, search modes, ABI version)."""
+    from bayhunter_amd import engine as E
+    txt = open(os.path.join(REPO, "include", "bh_engine.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"^#define\s+(BH_[A-Z0-9_]+)\s+(-?\d+)\b", txt, flags=re.M)}
+    assert defs["BH_ABI_VERSION"] == 5
+    assert (defs["BH_SEARCH_REFERENCE"], defs["BH_SEARCH_FAST"]) == (E.SEARCH_REFERENCE, E.SEARCH_FAST) == (0, 1)
+    assert defs["BH_CHAIN_MAXDEPTH"] == E.BH_CHAIN_MAXDEPTH
+
+
 def test_library_contains_gfx950_code_object():
     from bayhunter_amd import engine as E
     blob = open(E.LIB_PATH, "rb").read()
