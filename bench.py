@@ -650,7 +650,7 @@ def main():
         # the same workloads with the engine's OPTIONAL short root refinement (not the reference's sequence of evaluations:
         # velocities within 1.2e-6 relative instead of bit-identical, include/bh_engine.h) -- reported beside, never as `value`
         fast = {}
-        if args.search == "reference":
+        if args.search == "reference" and (world == 1 or os.environ.get("BH_BENCH_FAST_BLOCK", "0") == "1"):   # (a supplement: at N = 1 only)
             eng.set_swd_search("fast")
             try:
                 fast["c2"] = run_eval(args, eng, rank, world, dist, dev, "c2", dryrun, with_cpu=False)
