@@ -306,7 +306,8 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     // narrower lane groups cost a second pass over the layers and seven instead of four trials per round more transitions:
     // measured on windows of 1016 models of 3-9 layers in arrays of 21 (c4): 1.50 ms without the hint, 1.70-1.83 ms with it.
     const int typ_given = m.typ_layers > 0 ? m.typ_layers : e->hint_layers;
-    const int typ_layers = ((long)nlive * B <= 2048) ? 0 : typ_given;
+    static const bool hint_always = std::getenv("BH_SWD_HINT_ALWAYS") != nullptr; // experiment switch
+    const int typ_layers = ((long)nlive * B <= 2048 && !hint_always) ? 0 : typ_given;
     int iw[BH_MAX_TARGETS], look[BH_MAX_TARGETS], G = 1;
     {
         int n = 0;
