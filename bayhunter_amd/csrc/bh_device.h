@@ -105,6 +105,8 @@ struct SwdMultiArgs {
                        // for "all workgroups of this launch are resident" before it dispatches work beside them
     int prio_low;      // s_setprio level of a wavefront's unfavoured phase (0; 1 when receiver-function wavefronts at 0 run beside it)
     int fast;          // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
+    int adapt_ok;      // 1: a launch of one model per wavefront may let every wavefront size its lane groups and trials for its
+                       // own model (swd_group_kernel<.., ADAPT>); 0: the caller fixed lanes or trials (experiments)
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);

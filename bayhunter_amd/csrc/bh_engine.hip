@@ -440,6 +440,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     a.started = e->started;
     a.prio_low = e->swd_prio_low_now;
     a.fast = e->swd_search;
+    a.adapt_ok = (e->force_group == 0 && e->force_look == 0 && e->look_r == 0 && e->look_l == 0) ? 1 : 0;
     {
         static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
         if (dbg) {

@@ -170,7 +170,14 @@ __device__ __forceinline__ void wave_sync()
 // what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
 // FAST: the build with the optional short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
 // PROF: the build with the evaluation counters, phase clocks and wavefront trace (launches with A.neval set).
-template <int WPB, int FASTM, bool SIMPLE, bool PROF>
+// ADAPT: a launch of ONE model per wavefront (a chain window, a single model): every wavefront sizes its lane groups and its
+// trials per round for its OWN model -- a lane per finite layer (8 ... 16), as many trials as lanes and the wavefront's LDS
+// region admit (at most ADAPT_MAX_TRIALS), LDS rows for the model's own layers instead of the arrays' capacity.  With the
+// capacity's rows (21 for the chains) four trials fit; a window's dispersion time falls with every further trial
+// (4 / 6 / 8 trials: 1.82 / 1.53 / 1.42 ms for 1016 models of 3-9 layers), so the shallow models of a window get eight,
+// its deep ones keep four.  Scheduling only: which values the search consumes does not depend on it.
+constexpr int ADAPT_MAX_TRIALS = 8;
+template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -191,15 +198,32 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
         ty = (l1 > l0) ? 1 : 0;
         wid = (l1 > l0) ? l0 : wid - l0;
     }
-    const int G = A.lanes[cls];
+    int G = A.lanes[cls];
     const SwdTarget T = A.t[ty];
     int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
+    int rows_own = 0;
+    if (ADAPT) { // (one class, one model per wavefront: wavefront `wid` has model `wid` of the processing order)
+        const int32_t *perm0 = T.perm != nullptr ? T.perm : A.perm;
+        const bool v0 = !beyond && wid < A.B;
+        int m0 = v0 ? A.nlay[perm0 ? perm0[wid] : wid] : 2;
+        m0 = __builtin_amdgcn_readfirstlane(m0);
+        m0 = m0 < 2 ? 2 : (m0 > A.rows[1] ? A.rows[1] : m0);
+        const int fin = m0 - 1;
+        G = fin < 8 ? 8 : (fin > 16 ? 16 : fin);
+        const int fixed = (2 * NEV_MAX + ((T.K + 1) & ~1)) * (int)sizeof(double) + ((4 * m0 * (int)sizeof(float) + 15) & ~15) + 64;
+        const int jl = (wave_lds - fixed) / (fin * CA_STRIDE * (int)sizeof(double));
+        J = BH_WAVE / G;
+        J = J > jl ? jl : J;
+        J = J > ADAPT_MAX_TRIALS ? ADAPT_MAX_TRIALS : J;
+        J = J < 1 ? 1 : J;
+        rows_own = m0;
+    }
     while (J > 1 && G * J > BH_WAVE) --J;
     // Love only: further trials INSIDE a lane group.  Its recursion is scalar (every lane of the group
     // would repeat it), so lane l runs trial l mod JL instead; only the layer terms cost JL passes.
     const int JL = (T.iwave == 1 && T.inlook > 1) ? T.inlook : 1;
     const int LPM = G * J;         // lanes per model: J groups of G lanes, group r evaluates candidate r
-    const int MPW = BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
+    const int MPW = ADAPT ? 1 : BH_WAVE / LPM; // models per wavefront (lanes >= MPW*LPM idle along as clones of lane 0)
     extern __shared__ __align__(16) unsigned char smem_all[];
     const int lane = threadIdx.x & (BH_WAVE - 1);
     // the workgroup's shared copy of the libm tables, then one private region per wavefront
@@ -224,7 +248,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const bool valid = sidx < hi;
     const int32_t *perm = T.perm != nullptr ? T.perm : A.perm; // processing order: the target's own (SIMD pairing) or the batch's
     const int ib = valid ? (perm ? perm[sidx] : sidx) : 0;
-    const int Lmax = A.rows[cls]; // LDS rows per model of this class (>= every layer count it meets)
+    const int Lmax = ADAPT ? rows_own : A.rows[cls]; // LDS rows per model of this class (>= every layer count it meets)
     const int K = T.K;
     const int ifunc = T.iwave; // 1 Love, 2 Rayleigh: uniform per wavefront
 
@@ -863,6 +887,24 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         }
         (void)hipGetLastError();
     }
+    // One model per wavefront for every target (a chain window, a single model), one class, the usual targets: every wavefront
+    // sizes its lane groups and trials for its own model (ADAPT, see the kernel) within the region all wavefronts can be
+    // resident with.
+    static const bool no_adapt = std::getenv("BH_SWD_NO_ADAPT") != nullptr; // experiment switch
+    // (capacity up to 32 rows: at least two trials fit the region; deeper arrays keep the launcher's own choice of fewer, wider
+    // lane groups in a larger region)
+    bool adapt = a.adapt_ok && !no_adapt && !two && wpb == GROUP_WPB && a.Lmax <= 32 && a.Lmax >= 2;
+    {
+        bool plain = true;
+        for (int t = 0; t < a.ntargets; ++t) {
+            int J = a.t[t].look > 1 ? a.t[t].look : 1;
+            while (J > 1 && a.lanes[1] * J > BH_WAVE) --J;
+            adapt = adapt && BH_WAVE / (a.lanes[1] * J) == 1;
+            plain = plain && a.t[t].igr == 0 && a.t[t].mode <= 1 && a.t[t].K <= 64;
+        }
+        adapt = adapt && plain;
+        if (adapt) wave_lds = WAVE_LDS_TARGET & ~(size_t)15;
+    }
     const size_t lds = LIBM_TAB_PAD + wpb * wave_lds;
     if (info != nullptr) {
         info->workgroups = grid.x * grid.y * grid.z;
@@ -884,14 +926,15 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     a.fast = build;
     const dim3 block(BH_WAVE * wpb);
     const bool counted = a.neval != nullptr;
-#define BH_GROUP_LAUNCH(WP, FM, SI, PR) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR>), grid, block, lds, stream, a, redundant, (int)wave_lds)
+#define BH_GROUP_LAUNCH(WP, FM, SI, PR) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, false>), grid, block, lds, stream, a, redundant, (int)wave_lds)
+#define BH_GROUP_LAUNCH_ADAPT(FM, PR) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, FM, true, PR, true>), grid, block, lds, stream, a, redundant, (int)wave_lds)
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
     if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only)
         static bool big_lds = false;
         if (lds > WG_LDS_CAP && !big_lds) {
-            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true>),
-                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true>)};
+            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false>),
+                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true, false>)};
             for (const void *k : k4)
                 if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
             big_lds = true;
@@ -899,6 +942,12 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         if (build == 2) BH_GROUP_LAUNCH(4, 2, false, true);
         else if (build == 1) BH_GROUP_LAUNCH(4, 1, false, true);
         else BH_GROUP_LAUNCH(4, 0, false, true);
+    } else if (adapt && build == 2) {
+        if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
+        else BH_GROUP_LAUNCH_ADAPT(2, false);
+    } else if (adapt) {
+        if (counted) BH_GROUP_LAUNCH_ADAPT(0, true);
+        else BH_GROUP_LAUNCH_ADAPT(0, false);
     } else if (build == 2 && simple) {
         if (counted) BH_GROUP_LAUNCH(GROUP_WPB, 2, true, true);
         else BH_GROUP_LAUNCH(GROUP_WPB, 2, true, false);
@@ -912,6 +961,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     } else {
         BH_GROUP_LAUNCH(GROUP_WPB, 0, false, true);
     }
+#undef BH_GROUP_LAUNCH_ADAPT
 #undef BH_GROUP_LAUNCH
     return 0;
 }
