@@ -63,6 +63,8 @@ struct SwdKernelArgs {
     int fair;         // alternate the issue priority of the two wavefronts of a SIMD (scheduling only)
     double *nev_high; // work array [bh_swd_nev_high_doubles(B, look)]: Neville orders the kernel does not keep in LDS
     int fast;         // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
+    int counted;      // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
+    int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
@@ -83,6 +85,9 @@ struct SwdTarget {
     double *vel;  // [B][ldv] (+ column offset already applied)
     int32_t *err; // [B]
     const int32_t *perm; // optional: this target's own processing order (bh_launch_pair_order); else SwdMultiArgs::perm
+    const int32_t *count; // optional (device): the launch covers the first *count entries of the processing order only (the
+                          // re-run of the models the short refinement's guard fired on: perm = that list)
+    int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
 };
 struct SwdMultiArgs {
     int B, Lmax, ntargets;
@@ -107,6 +112,8 @@ struct SwdMultiArgs {
     int fast;          // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
     int adapt_ok;      // 1: a launch of one model per wavefront may let every wavefront size its lane groups and trials for its
                        // own model (swd_group_kernel<.., ADAPT>); 0: the caller fixed lanes or trials (experiments)
+    int counted;       // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
+    int rerun;         // 1: the launch re-runs listed models (SwdTarget::count): plain two-dimensional grid, no SIMD pairing
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);

@@ -77,6 +77,9 @@ struct bh_engine {
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = 0;  // bh_engine_set_swd_search / BH_SWD_SEARCH=fast: 1 = the short refinement for phase-velocity targets
+    int swd_scan = 1;    // bh_engine_set_swd_scan / BH_SWD_SCAN=plain: 1 = Love scans skip the steps a mode count proves empty (same bits)
+    DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
+    uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
     int love_inlook = 0; // BH_SWD_LOVE_INLOOK env (experiment switch): Love trials inside a lane group, 0 = automatic
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -272,6 +275,52 @@ int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
     return BH_OK;
 }
 
+// The guard of the short refinement (SearchT, swd_common.h): work space = BH_MAX_TARGETS counts (16 words) followed by one
+// list of B model indices per target.
+constexpr int GUARD_HEAD = 16;
+int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t **lists)
+{
+    int rc = ensure(e, e->guard, ((size_t)GUARD_HEAD + (size_t)BH_MAX_TARGETS * (size_t)(B + 4)) * sizeof(int32_t));
+    if (rc) return rc;
+    *counts = (int32_t *)e->guard.p;
+    *lists = (int32_t *)e->guard.p + GUARD_HEAD;
+    HIPCHK(e, hipMemsetAsync(e->guard.p, 0, GUARD_HEAD * sizeof(int32_t), st));
+    return BH_OK;
+}
+
+// Second launch of a call in BH_SEARCH_FAST: the models the guard fired on (per target: counts[t], lists + t * (B + 4)),
+// again, with the reference's sequence -- one model per wavefront, as many trials per round as its lanes admit.  The launch
+// is sized for the worst case and reads the counts on the device: workgroups beyond them leave at once (no host round trip;
+// nearly always all of them).  Rows and failure flags of the listed models are overwritten with the reference's.
+int launch_swd_rerun(bh_engine *e, hipStream_t st, const SwdMultiArgs &main, int32_t *counts, int32_t *lists)
+{
+    SwdMultiArgs a = main;
+    a.fast = 0;
+    a.rerun = 1;
+    a.perm = nullptr;
+    a.split = nullptr;
+    a.Lcut = a.Lmax;
+    a.started = nullptr;
+    a.stamp = (++e->swd_stamp) & 0xffffu;
+    if (a.stamp == 0) a.stamp = (++e->swd_stamp) & 0xffffu;
+    a.adapt_ok = 1;
+    const int G = bh_swd_pick_group(a.B, a.ntargets, a.Lmax);
+    for (int t = 0; t < a.ntargets; ++t) {
+        a.t[t].perm = lists + (size_t)t * (size_t)(a.B + 4);
+        a.t[t].count = counts + t;
+        a.t[t].gcount = nullptr;
+        a.t[t].glist = nullptr;
+        a.t[t].look = 64 / G > 1 ? 64 / G : 1; // one model per wavefront
+        a.t[t].inlook = 1;
+    }
+    SwdLaunchInfo info{};
+    const int lrc = bh_launch_swd_group(a, G, st, &info, 2, nullptr);
+    if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
+    HIPCHK(e, hipGetLastError());
+    ++e->rerun_launches;
+    return BH_OK;
+}
+
 // All dispersion targets of one call.  Small batches go to the group kernel (G lanes per model,
 // one launch for all targets); batches that fill the chip by themselves use one lane per model.
 int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
@@ -373,6 +422,20 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         if ((rc = ensure(e, e->nevhi, nev_off[nlive2] * sizeof(double)))) return rc;
         long lane_waves = 0; // wavefronts of the call
         for (int t = 0; t < nlive2; ++t) lane_waves += (long)((B + 63) / 64) * (look[t] > 1 ? look[t] : 1);
+        int32_t *gcounts = nullptr, *glists = nullptr;
+        bool any_fast = false;
+        for (int j = 0; j < njobs; ++j) any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0);
+        any_fast = any_fast && e->swd_search != 0;
+        if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
+        SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
+        ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan;
+        if (any_fast) {
+            if (!e->board.p) {
+                if ((rc = ensure(e, e->board, (size_t)BH_BOARD_WORDS * sizeof(unsigned)))) return rc;
+                HIPCHK(e, hipMemsetAsync(e->board.p, 0, (size_t)BH_BOARD_WORDS * sizeof(unsigned), st));
+            }
+            ra.board = (unsigned *)e->board.p;
+        }
         ev_begin(e, 0, st);
         if (fork2) {
             HIPCHK(e, hipEventRecord(e->ev_fork2, st));
@@ -396,15 +459,25 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             a.fair = lane_waves <= 1024 ? -1 : (lane_waves <= 2048 ? 18 : 12);
             a.nev_high = (double *)e->nevhi.p + nev_off[nth];
             a.fast = e->swd_search;
+            a.counted = e->swd_scan;
+            if (any_fast && J.igr == 0) {
+                a.gcount = gcounts + nth;
+                a.glist = glists + (size_t)nth * (size_t)(B + 4);
+            }
             bh_launch_swd(a, J.iwave, (fork2 && (nth & 1)) ? e->aux2 : st);
+            SwdTarget &t = ra.t[ra.ntargets++];
+            t.iwave = J.iwave; t.igr = J.igr; t.K = J.K; t.ldv = J.ldv; t.mode = J.mode;
+            t.h = a.h; t.vp = a.vp; t.vs = a.vs; t.rho = a.rho; t.sl = a.sl; t.sb = a.sb;
+            t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
             ++nth;
         }
         if (fork2) {
             HIPCHK(e, hipEventRecord(e->ev_join2, e->aux2));
             HIPCHK(e, hipStreamWaitEvent(st, e->ev_join2, 0));
         }
-        ev_end(e, 0, st);
         HIPCHK(e, hipGetLastError());
+        if (any_fast && (rc = launch_swd_rerun(e, st, ra, gcounts, glists))) return rc;
+        ev_end(e, 0, st);
         return BH_OK;
     }
     SwdMultiArgs a{};
@@ -433,6 +506,19 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         }
         t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
     }
+    int32_t *gcounts = nullptr, *glists = nullptr;
+    bool any_fast = false;
+    for (int t = 0; t < a.ntargets; ++t) any_fast = any_fast || a.t[t].igr == 0;
+    any_fast = any_fast && e->swd_search != 0;
+    if (any_fast) {
+        if ((rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
+        for (int t = 0; t < a.ntargets; ++t)
+            if (a.t[t].igr == 0) {
+                a.t[t].gcount = gcounts + t;
+                a.t[t].glist = glists + (size_t)t * (size_t)(B + 4);
+            }
+    }
+    a.counted = e->swd_scan;
     for (int t = 0; t < a.ntargets; ++t) {
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
         if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
@@ -452,11 +538,26 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     ev_begin(e, 0, st);
     const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
-    ev_end(e, 0, st);
     e->last_swd_wpb = e->swd_wpb_now;
-    if (lrc == 0 && e->started) e->started_expected += e->last_swd.workgroups;
-    if (lrc != 0) return fail(e, BH_EINVAL, "model too deep for LDS");
-    HIPCHK(e, hipGetLastError());
+    if (lrc != 0) {
+        ev_end(e, 0, st);
+        return fail(e, BH_EINVAL, "model too deep for LDS");
+    }
+    {
+        // (the counter a second stream waits on moves only once the launch is known to have been accepted: a failed launch
+        // never increments the device word, and every later wait for the advanced value would hang -- ADVICE r03)
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            ev_end(e, 0, st);
+            return fail(e, BH_EHIP, "dispersion kernel launch", le);
+        }
+        if (e->started) e->started_expected += e->last_swd.workgroups;
+    }
+    if (any_fast && (rc = launch_swd_rerun(e, st, a, gcounts, glists))) {
+        ev_end(e, 0, st);
+        return rc;
+    }
+    ev_end(e, 0, st);
     return BH_OK;
 }
 
@@ -585,6 +686,7 @@ int bh_engine_create(int device, bh_engine **out)
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_SEARCH")) e->swd_search = (g[0] == 'f' || g[0] == '1') ? 1 : 0;
+    if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == 'p' || g[0] == '0') ? 0 : 1;
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
         e->love_inlook = std::atoi(g);
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
@@ -623,6 +725,29 @@ int bh_engine_set_swd_search(bh_engine *e, int search)
 
 int bh_engine_get_swd_search(const bh_engine *e) { return e ? e->swd_search : 0; }
 
+int bh_engine_set_swd_scan(bh_engine *e, int scan)
+{
+    if (!e) return BH_EINVAL;
+    if (scan != BH_SCAN_STEPS && scan != BH_SCAN_COUNTED) return fail(e, BH_EINVAL, "scan must be BH_SCAN_STEPS or BH_SCAN_COUNTED");
+    e->swd_scan = scan;
+    return BH_OK;
+}
+int bh_engine_get_swd_scan(const bh_engine *e) { return e ? e->swd_scan : 0; }
+
+int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches)
+{
+    if (!e) return BH_EINVAL;
+    if (rerun_launches) *rerun_launches = e->rerun_launches;
+    if (counts) {
+        for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = 0;
+        if (e->guard.p) {
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            HIPCHK(e, hipMemcpy(counts, e->guard.p, BH_MAX_TARGETS * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+    }
+    return BH_OK;
+}
+
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round)
 {
     if (!e) return BH_EINVAL;
@@ -648,7 +773,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard})
         release(*b);
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);

@@ -122,10 +122,49 @@ __device__ __forceinline__ void love_step(double &e1, double &e2, double cosq, d
     }
 }
 
+// ---- the Love MODE COUNT (not in the reference; oracle/swd_oracle.c: bho_dltar1_count restates it) -----------------
+// The SH problem at fixed omega is a Sturm-Liouville problem in k^2.  With (e1, e2) ~ (stress, displacement) of the solution
+// that decays in the half-space (c < beta of the half-space), integrated upward as dltar1 does,
+//     N(c) = number of sign changes of dltar1(., omega) below c = Z + [e1 * e2 < 0 at the surface],
+// Z = zeros of the displacement inside the finite layers (oscillation theorem: they enter at the free surface one by one,
+// a Dirichlet eigenvalue between two Neumann ones).  Inside ONE layer the displacement is a pure sinusoid of phase advance
+// q = d * rb (or a cosh / sinh combination: at most one zero), so the layer holds floor(q / pi) zeros or one more, and which
+// of the two is the sign change of e2 across the layer -- taken from the recursion's own values.  So sign(dltar1) ==
+// (-1)^N exactly as computed, and N(c2) - N(c1) says how many sign changes the reference's function has between two trial
+// velocities WITHOUT visiting the grid points in between (SearchT: the counted scan).
+// love_zero_floor: floor(q / pi) of a propagating layer as a double, -1 where it is ambiguous by two (q / pi within 1e-9 of
+// an integer: a zero at both ends of the layer at once); 0 for an evanescent layer.
+__device__ __forceinline__ double love_zero_floor(double q)
+{
+    const double x = q * 0.31830988618379067154, xf = floor(x);
+    const bool ok = (x - xf > 1.0e-9) && (xf + 1.0 - x > 1.0e-9) && (x < 1.0e9);
+    return ok ? xf : -1.0;
+}
+struct LoveCount {
+    int n;
+    bool ok;
+    __device__ __forceinline__ void reset(bool half_space_decays)
+    {
+        n = 0;
+        ok = half_space_decays;
+    }
+    // one layer: fl from love_zero_floor, the displacement before (e2_old) and after (e2_new) the layer
+    __device__ __forceinline__ void layer(double fl, double e2_old, double e2_new)
+    {
+        const int f = (int)fl;
+        ok = ok && !(fl < 0.0);
+        n += f + ((((f & 1) != 0) != signs_differ(e2_new, e2_old)) ? 1 : 0);
+    }
+    __device__ __forceinline__ int total(double e1, double e2) const { return n + (signs_differ(e1, e2) ? 1 : 0); }
+    // packed for the exchange between lanes: count, or -1 when not valid
+    __device__ __forceinline__ int packed(double e1, double e2) const { return ok ? total(e1, e2) : -1; }
+};
+
 // ---- Love: SH Thomson-Haskell (surfdisp96.f:710-769) ----------------------------------------
+// nv (optional): the packed mode count (LoveCount::packed) of this evaluation
 template <bool EXACT>
 __device__ double love_secular(double wvno, double omega, const ModelLds &md, int mmax, int llw,
-                               int mtop, DivRange &dr, const LibmTabs &LT)
+                               int mtop, DivRange &dr, const LibmTabs &LT, int *nv = nullptr)
 {
     double beta1 = md.Bv(mmax - 1);
     double rho1 = md.R(mmax - 1);
@@ -135,6 +174,8 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
     double rb = sqrt(wvnop * wvnom);
     double e1 = rho1 * rb;
     double e2 = 1.0 / (beta1 * beta1);
+    LoveCount lc;
+    lc.reset(wvno > xkb);
     for (int m = mtop - 2; m >= 0; --m) {
         if (m <= mmax - 2 && m >= llw - 1) {
             beta1 = md.Bv(m);
@@ -146,12 +187,13 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
             wvnom = fabs(wvno - xkb);
             rb = sqrt(wvnop * wvnom);
             const double q = dm * rb;
-            double cosq, y, z;
+            double cosq, y, z, fl = 0.0;
             if (wvno < xkb) {
                 double sinq;
                 bh_sincos(q, &sinq, &cosq, LT);
                 y = sinq / rb;
                 z = -rb * sinq;
+                fl = love_zero_floor(q);
             } else if (wvno == xkb) {
                 cosq = 1.0;
                 y = dm;
@@ -164,9 +206,12 @@ __device__ double love_secular(double wvno, double omega, const ModelLds &md, in
                 y = sinq / rb;
                 z = rb * sinq;
             }
+            const double e2o = e2;
             love_step<EXACT>(e1, e2, cosq, y, z, xmu, EXACT ? 0.0 : bh_rcp_refined(xmu), dr);
+            lc.layer(fl, e2o, e2);
         }
     }
+    if (nv != nullptr) *nv = lc.packed(e1, e2);
     return e1;
 }
 
@@ -444,7 +489,15 @@ enum : int {
     ST_FX = 5,    // single point: regula falsi / bisection
     ST_FP1 = 6,   // x - tau (towards c1) of the acceptance pair around the estimate x
     ST_FP2 = 7,   // x + tau (towards c2)
-    ST_FB = 8     // the fastest S velocity, first, when the bracket reaches beyond it
+    ST_FB = 8,    // (unused since the guard takes brackets that contain betmx)
+    // the counted scan (Love; see SearchT): not the reference's sequence of scan evaluations, but the same bracket
+    ST_JUMP = 9,  // the grid point `jn` steps above c1
+    ST_BIS = 10,  // a grid point between c1 and c2 (`jn` steps above c1; c2 is `nn` steps above c1 and counts more)
+    // probes of the guard of the short refinement (FAST only; see SearchT)
+    ST_GH = 11,   // just above the accepted bracket's upper end
+    ST_GL = 12,   // just below its lower end
+    ST_GS1 = 13,  // just inside the lower end of a scan step that contains a half-space velocity and showed no sign change
+    ST_GS2 = 14   // just inside its upper end
 };
 
 // ---- the per-model search state machine -------------------------------------------------------
@@ -469,9 +522,49 @@ enum : int {
 // sequence); 2 = FAST for launches WITHOUT group-velocity targets: nevill and the second-root logic are not compiled in.
 // SIMPLE: the launch holds fundamental-mode phase-velocity targets only (the usual inversion set-up): the second root of a
 // group velocity and the mode loop are not compiled in (fewer live registers in the round loop).
+//
+// THE COUNTED SCAN (Love targets, every build; bh_engine_set_swd_scan, on by default).  getsol looks for the first step
+// [g, g + dc] of its grid g_i = g_(i-1) + dc over which the secular function changes sign.  With the Love mode count N
+// (LoveCount above: sign f == (-1)^N as computed) the grid points need not all be visited: N(g_(i+s)) == N(g_i) proves that
+// none of the s steps in between shows a sign change -- the reference would walk through them --, a larger count proves there is
+// one, and a search over the grid INDEX finds the lowest step whose upper end counts more than g_i (taken as the bracket when
+// the two ends differ in sign, walked over when they do not: two roots inside one step, invisible to the reference as
+// well).  Every grid point is formed by the reference's own repeated additions of dc, so the bracket handed to the
+// refinement -- and every bit after it -- is the reference's: same velocities, same failure flags, a third of the scan's
+// evaluations.  Upward scans below min(half-space S velocity, betmx) only; everything else (downward scans, a scan that
+// turned round at clow, an ambiguous count, Rayleigh: no such count for the P-SV problem here) takes the reference's steps.
+// The stride is a function of the search state alone: the first aims one step beyond where the last period's bracket was
+// found, later ones 4, 8, ... 64 (first period: 16, 32, 64); the index search is a regula falsi when exactly one sign
+// change lies between the ends, a bisection otherwise.  oracle/swd_oracle.c (bracket_and_refine, scan mode 1) restates it.
+//
+// THE GUARD of the short refinement (FAST, phase velocities).  The reference's scan grid is anchored at the PREVIOUS root
+// (c1 = c(k-1) - 1.5 dc), which the short sequence knows to 1.05e-6 relative only: the two grids differ by s, and the two
+// scans see different sign patterns exactly when a sign change lies within |s| of a grid point.  With a lone root that moves
+// the bracket by a step (same root); but the half-space terms contain |k - k_v|, so a root creeping up to a half-space
+// velocity v has a mirror-image sign change just above v, and with that pair it decides whether the reference sees a sign
+// change AT ALL (the only mechanism in 9.4 million random models).  The guard, eps = 3e-6 x velocity:
+//   - a scan step without a sign change that contains a half-space velocity may hide the pair: probe eps inside both ends;
+//   - an accepted bracket whose root lies within two steps of a half-space velocity / betmx: root within eps of a bracket
+//     end or of betmx, or a sign change within eps OUTSIDE a bracket end (the image right behind it).
+// A model the guard fires on (`guard`) is run again with the REFERENCE's sequence by the engine (a second, small launch):
+// failure flags and zero-from-period-k rows are then the reference's by construction.
 template <int XSC, int NLO = NEV_MAX, int FASTM = 0, bool SIMPLE = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
     static constexpr bool FAST = FASTM != 0, PHASE_ONLY = FASTM == 2, NOGROUP = PHASE_ONLY || SIMPLE;
+    // counted scan
+    static constexpr int stride_first = 16, stride_next = 4, stride_max = 64;
+    // (per-lane flags share ONE register: a `bool` member lives as a 64-bit lane mask in a scalar register pair, and this
+    //  kernel has none to spare -- six more of them cost the round loop 30 spilled SGPRs)
+    enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u };
+    unsigned flg = 0u;
+    __device__ __forceinline__ bool has(unsigned f) const { return (flg & f) != 0u; }
+    __device__ __forceinline__ void put(unsigned f, bool v) { flg = v ? (flg | f) : (flg & ~f); }
+    int n1 = 0, nhi = 0, nn = 0, jn = 0, stride = 0, isteps = 0, iprev = 0, iprevb = 0;
+    double vlim = 0.0, cnext = 0.0, cnext1 = 0.0;
+    // guard
+    static constexpr double guard_rel = 3.0e-6;
+    double cell_lo = 0.0, cell_hi = 0.0, vh0 = 0.0, vh1 = 0.0;
+    double vsafe = 0.0; // scan steps entirely below this cannot involve the guard (the kernels' shortcuts for plain steps)
     int XS = XSC;
     // constants of the reference's driver (compile-time: they cost no registers)
     static constexpr double one = 1.0e-2;
@@ -547,10 +640,11 @@ struct SearchT {
     }
 
     // driver set-up (surfdisp96.f:124-217): extremal velocities, start value
+    // ifunc (1 Love, 2 Rayleigh) and counted (the counted scan is wanted) only matter for Love targets and the guard
     template <class MD>
     __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
                          double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
-                         double *cper_ = nullptr, double *cbper_ = nullptr)
+                         double *cper_ = nullptr, double *cbper_ = nullptr, int ifunc = 2, bool counted = false)
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
@@ -611,8 +705,47 @@ struct SearchT {
         t1a = t1b = 0.f;
         t1 = 1.0; omega = 1.0;
         evals = 0;
+        put(F_CNT_ON, counted && ifunc == 1);
+        flg &= ~(F_CNT_OK | F_JUMP_READY);
+        iprev = iprevb = 0;
+        vlim = fmin(md.Bv(mmax - 1), betmxd);
+        put(F_GUARD_ON, FAST && (PHASE_ONLY || !group));
+        flg &= ~F_GUARD;
+        vh0 = md.Bv(mmax - 1);                          // half-space S velocity
+        vh1 = (ifunc == 2) ? md.A(mmax - 1) : betmxd;   // half-space P velocity (Rayleigh: it enters |k - k_alpha| there)
+        vsafe = has(F_GUARD_ON) ? fmin(vh0, vh1) : 1.0e300;
         if (active) set_period(0);
         ceval = c1;
+        plan_first_jump();
+    }
+
+    // The grid point `want` steps above `from` by the reference's repeated additions, stopping below vlim.
+    // Returns the steps taken; *below = the grid point one step before the last.
+    __device__ __forceinline__ int grid_ahead(double from, int want, double &to, double &below) const
+    {
+        int sdone = 0;
+        double cs = from, cb = from;
+        while (sdone < want) {
+            const double nx = cs + dc;
+            if (!(nx < vlim)) break;
+            cb = cs;
+            cs = nx;
+            ++sdone;
+        }
+        to = cs;
+        below = cb;
+        return sdone;
+    }
+    // the first jump of a period's scan, worked out when the period is set up (the look-ahead evaluates it beside the
+    // start value): valid if the start value's count turns out usable and the scan goes upward
+    __device__ __forceinline__ void plan_first_jump()
+    {
+        flg &= ~F_JUMP_READY;
+        if (!has(F_CNT_ON) || !active) return;
+        const int ip = (!NOGROUP && root == 1) ? iprevb : iprev;
+        stride = (ip > 0) ? ip + 1 : stride_first;
+        jn = grid_ahead(c1, stride, cnext, cnext1);
+        flg |= F_JUMP_READY;
     }
 
     // label 1700/1750: the current mode found no root at period k
@@ -641,6 +774,7 @@ struct SearchT {
             }
             iq = iq + 1;
             k = 0;
+            iprev = iprevb = 0;
         }
         set_period(k);
         root = 0;
@@ -664,6 +798,7 @@ struct SearchT {
         }
         st = ST_FIRST;
         ceval = c1;
+        plan_first_jump();
     }
 
     // Look-ahead: candidate 0 is the pending request; candidate r > 0 is the phase velocity the r-th
@@ -671,9 +806,25 @@ struct SearchT {
     // further halvings towards the side on which a straight line through the bracket ends puts the
     // root while refining (:600-660).  Purely a guess about which values will be asked for: a value
     // is only ever consumed by advance() if it was computed for exactly the (ceval, omega) requested.
+    template <bool CNT = true> // CNT = false: the caller knows the counted scan is off for this search (Rayleigh wavefronts)
     __device__ __forceinline__ double candidate(int r) const
     {
         double q = ceval;
+        if ((CNT || FAST) && st >= ST_JUMP) { // the counted scan (guard probes: nothing to foresee)
+            if (r == 1) {
+                // after the jump: the index search starts, most probably, at the step below the target (the stride aims
+                // one step beyond the last period's bracket); inside the index search: the step above (a root right
+                // behind the point), or -- the point being right below c2 -- nevill's first midpoint of that bracket
+                if (CNT && st == ST_JUMP) q = cnext1;
+                else if (CNT && st == ST_BIS) q = (!FAST && jn == nn - 1) ? 0.5 * (ceval + c2) : ceval + dc;
+            }
+            return q;
+        }
+        if (CNT && st == ST_FIRST && has(F_JUMP_READY)) { // start value of a period: the first jump of its counted scan, then the step below it
+            if (r == 1) q = cnext;
+            else if (r == 2) q = cnext1;
+            return q;
+        }
         if (FAST && st >= ST_FX) { // the only request that can be foreseen: the second point of an acceptance pair
             if (st == ST_FP1 && r == 1) {
                 const double tau = fast_tau * fabs(c3);
@@ -699,13 +850,140 @@ struct SearchT {
         return q;
     }
 
-    __device__ void advance(double del)
+    // the scan step c1 -> c2 showed no sign change (:455-460): move on; returns the next `todo` of advance()
+    template <bool CNT>
+    __device__ __forceinline__ int step_done()
+    {
+        c1 = c2;
+        del1 = del2;
+        if (CNT) isteps += 1;
+        return (c1 < cm || c1 >= betmxd + dc) ? 2 : 1;
+    }
+    // (c1, c2) is a bracket: set up its refinement; returns the next `todo` of advance()
+    template <bool CNT>
+    __device__ __forceinline__ int bracketed()
+    {
+        if (CNT) {
+            if (!NOGROUP && root == 1) iprevb = isteps;
+            else iprev = isteps;
+        }
+        if (FAST && (PHASE_ONLY || !group)) {
+            cell_lo = fmin(c1, c2);
+            cell_hi = fmax(c1, c2);
+            put(F_FLO_NEG, signs_differ((c1 < c2) ? del1 : del2, 0.0));
+            have_p = false;
+            fit = 0;
+            // A bracket that contains betmx can hold THREE sign changes (the root, its mirror image and the first of the
+            // unphysical ones above the half-space velocity); which of them nevill ends at depends on its whole
+            // sequence.  The short sequence does not try: the guard fires (the model is run again with the reference's).
+            if (cell_hi > betmxd && cell_lo < betmxd) {
+                flg |= F_GUARD;
+                return 0;
+            }
+            return 7;
+        }
+        c3 = 0.5 * (c1 + c2);
+        ceval = c3;
+        st = ST_NEV0;
+        return 0;
+    }
+
+    // nv: the packed mode count of the evaluation (LoveCount::packed; -1 = none).  CNT = false: the caller knows the counted
+    // scan is off for this search (Rayleigh wavefronts: none of its code, none of its exec-mask bookkeeping)
+    template <bool CNT = true>
+    __device__ __forceinline__ void advance(double del, int nv = -1)
     {
         ++evals;
         // `todo`: 0 nothing, 1 prepare next bracket step, 2 root search failed (iret = -1),
         // 3 refinement finished with c3, 4 nevill top-of-loop, 5 nevill post-bracket section,
-        // 6 root found
+        // 6 root found, 7 next estimate of the short refinement, 10 the counted scan's index search
         int todo = 0;
+        if ((CNT || FAST) && st >= ST_JUMP) {
+            if (CNT && st == ST_JUMP) { // the grid point jn steps above c1
+                if (nv < 0 || nv < n1) { // no usable count (the value is not used): the reference's steps from c1 on
+                    flg &= ~F_CNT_OK;
+                    todo = 1;
+                } else if (nv == n1) { // jn steps without a sign change
+                    c1 = ceval;
+                    del1 = del;
+                    isteps += jn;
+                    stride = (stride < stride_next) ? stride_next : 2 * stride;
+                    if (stride > stride_max) stride = stride_max;
+                    todo = 1;
+                } else {
+                    c2 = ceval;
+                    del2 = del;
+                    nhi = nv;
+                    nn = jn;
+                    todo = 10;
+                }
+            } else if (CNT && st == ST_BIS) { // a grid point between c1 and c2
+                if (nv < n1 || nv > nhi) { // (includes nv < 0)
+                    flg &= ~F_CNT_OK;
+                    todo = 1;
+                } else if (nv > n1) {
+                    c2 = ceval;
+                    del2 = del;
+                    nhi = nv;
+                    nn = jn;
+                    todo = 10;
+                } else {
+                    c1 = ceval;
+                    del1 = del;
+                    isteps += jn;
+                    nn -= jn;
+                    todo = 10;
+                }
+            } else if (FAST) { // guard probes
+                if (st == ST_GH) {
+                    if (signs_differ(del, 0.0) == has(F_FLO_NEG)) { // differs from the upper end's sign (the opposite of the lower end's)
+                        flg |= F_GUARD;
+                        todo = 3;
+                    } else {
+                        ceval = cell_lo - guard_rel * fabs(c3);
+                        st = ST_GL;
+                    }
+                } else if (st == ST_GL) {
+                    if (signs_differ(del, 0.0) != has(F_FLO_NEG)) flg |= F_GUARD;
+                    todo = 3;
+                } else if (st == ST_GS1) {
+                    if (signs_differ(del, del1)) {
+                        flg |= F_GUARD;
+                    } else {
+                        ceval = fmax(c1, c2) - guard_rel * fmax(c1, c2);
+                        st = ST_GS2;
+                    }
+                } else {
+                    if (signs_differ(del, del1)) flg |= F_GUARD;
+                    else todo = step_done<CNT>();
+                }
+            }
+            if (CNT && todo == 10) { // the index search between c1 (count n1) and c2 (nn steps above, count nhi > n1)
+                if (nn > 1) {
+                    int hh = nn / 2;
+                    if (nhi - n1 == 1) { // exactly one sign change in between: a straight line through the two values
+                        const double a1 = fabs(del1), a2 = fabs(del2);
+                        const double tt = (double)nn * (a1 / (a1 + a2));
+                        hh = (tt >= 1.0) ? ((tt < (double)(nn - 1)) ? (int)tt : nn - 1) : 1;
+                    }
+                    double cm_ = c1;
+                    for (int i = 0; i < hh; ++i) cm_ = cm_ + dc;
+                    jn = hh;
+                    ceval = cm_;
+                    st = ST_BIS;
+                    todo = 0;
+                } else if (!signs_differ(del1, del2)) { // an even number of roots inside one step: walked over
+                    c1 = c2;
+                    del1 = del2;
+                    n1 = nhi;
+                    isteps += 1;
+                    stride = stride_next;
+                    todo = 1;
+                } else {
+                    todo = bracketed<CNT>();
+                }
+            }
+        } else
         if (FAST && st >= ST_FX) { // the short refinement's own states (kept out of the switch: the reference build's text stays as it was)
             if (st == ST_FX) {
                 if (signs_differ(del, del1)) {
@@ -714,18 +992,6 @@ struct SearchT {
                 } else {
                     cp = c1; delp = del1;
                     c1 = ceval; del1 = del;
-                }
-                have_p = true;
-                todo = 7;
-            } else if (st == ST_FB) {
-                const bool low_is_1 = c1 < c2;
-                const bool below = signs_differ(del, low_is_1 ? del1 : del2); // sign change below betmx: it replaces the upper end
-                if (below == low_is_1) {
-                    cp = c2; delp = del2;
-                    c2 = betmxd; del2 = del;
-                } else {
-                    cp = c1; delp = del1;
-                    c1 = betmxd; del1 = del;
                 }
                 have_p = true;
                 todo = 7;
@@ -757,33 +1023,28 @@ struct SearchT {
             del1 = del;
             if (ifirst == 1) del1st = del1;
             idir = (ifirst != 1 && signs_differ(del1st, del1)) ? -1 : +1;
+            if (CNT) {
+                isteps = 0;
+                n1 = nv;
+                put(F_CNT_OK, has(F_CNT_ON) && nv >= 0 && idir > 0);
+            }
             todo = 1;
             break;
         case ST_STEP:
             del2 = del;
             if (signs_differ(del1, del2)) { // bracketed: enter nevill with (c1,c2,del1,del2)
-                if (FAST && (PHASE_ONLY || !group)) {
-                    have_p = false;
-                    fit = 0;
-                    // A bracket that reaches beyond the fastest S velocity (a root up there is rejected, :468-471, and the
-                    // secular function has further sign changes there): look at betmx first and keep the side below it
-                    // if the root is there -- the one nevill walks into from its midpoint.
-                    if (fmax(c1, c2) > betmxd && fmin(c1, c2) < betmxd) {
-                        ceval = betmxd;
-                        st = ST_FB;
-                    } else {
-                        todo = 7;
-                    }
-                } else {
-                    c3 = 0.5 * (c1 + c2);
-                    ceval = c3;
-                    st = ST_NEV0;
-                }
+                todo = bracketed<CNT>();
             } else {
-                c1 = c2;
-                del1 = del2;
-                if (c1 < cm || c1 >= betmxd + dc) todo = 2;
-                else todo = 1;
+                bool probing = false;
+                if (FAST && fmax(c1, c2) >= vsafe && !has(F_GUARD)) { // a step over a half-space velocity that showed no sign change: the guard's probes
+                    const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+                    if ((lo <= vh0 && vh0 <= hi) || (lo <= vh1 && vh1 <= hi)) {
+                        ceval = lo + guard_rel * hi;
+                        st = ST_GS1;
+                        probing = true;
+                    }
+                }
+                if (!probing) todo = step_done<CNT>();
             }
             break;
         case ST_NEV0:
@@ -908,6 +1169,19 @@ struct SearchT {
                 todo = 0;
             }
         }
+        if (FAST && todo == 3 && (flg & (F_GUARD_ON | F_GUARD)) == F_GUARD_ON && st < ST_GH) { // the guard at an accepted bracket (see the struct's comment)
+            const double cn = c3, m2 = 2.0 * dc;
+            if (fabs(cn - vh0) < m2 || fabs(cn - vh1) < m2 || fabs(cn - betmxd) < m2) {
+                const double eps = guard_rel * fabs(cn);
+                if (cell_hi - cn < eps || cn - cell_lo < eps || fabs(cn - betmxd) < eps) {
+                    flg |= F_GUARD;
+                } else {
+                    ceval = cell_hi + eps;
+                    st = ST_GH;
+                    todo = 0;
+                }
+            }
+        }
         if (todo == 3) { // getsol after nevill (:468-471)
             c1 = c3;
             todo = (c1 > betmxd) ? 2 : 6;
@@ -923,6 +1197,7 @@ struct SearchT {
                     } else {
                         iq = iq + 1;
                         k = 0;
+                        iprev = iprevb = 0;
                         next_search();
                     }
                 } else {
@@ -937,6 +1212,7 @@ struct SearchT {
                         c1 = c1 - onea * dc;
                         st = ST_FIRST;
                         ceval = c1;
+                        plan_first_jump();
                     } else {
                         period_done = true;
                     }
@@ -963,7 +1239,23 @@ struct SearchT {
             }
             todo = 0;
         }
+        if (CNT && todo == 1 && has(F_CNT_OK)) { // the counted scan: the grid point `stride` steps ahead (below vlim)
+            if (!has(F_JUMP_READY)) jn = grid_ahead(c1, stride, cnext, cnext1);
+            flg &= ~F_JUMP_READY;
+            if (jn >= 2) {
+                ceval = cnext;
+                st = ST_JUMP;
+                todo = 0;
+            } else {
+                flg &= ~F_CNT_OK; // too close to the limit: the reference's steps from here
+            }
+        }
+        if (FAST && has(F_GUARD)) { // the guard fired: this run's results are not used (the engine runs the model again)
+            active = false;
+            return;
+        }
         if (todo == 1) { // label 1000 of getsol: next bracket step (:437-446)
+            if (CNT) flg &= ~F_JUMP_READY;
             c2 = (idir > 0) ? c1 + dc : c1 - dc;
             if (c2 <= clow) {
                 idir = +1;

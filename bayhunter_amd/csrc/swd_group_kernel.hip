@@ -6,6 +6,7 @@
 #include "bh_device.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #define BH_HD __device__ __forceinline__
@@ -107,9 +108,9 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
 }
 
 // Phase B of the group kernel, Love: parked per layer (cosq, y, z, xmu, rcp(xmu)).
-template <bool RAGGED, bool EXACT>
+template <bool RAGGED, bool EXACT, bool COUNT>
 __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
-                                                 int mmax, int llw, DivRange &dr)
+                                                 int mmax, int llw, DivRange &dr, LoveCount &lc)
 {
     const int mstart = (RAGGED ? mtop : __builtin_amdgcn_readfirstlane(mmax)) - 2;
     // software-pipelined: the terms of layer m-1 are fetched while layer m is processed
@@ -124,6 +125,7 @@ __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const d
         DivRange d2 = dr;
         love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
         if (on) {
+            if (COUNT) lc.layer(p2.y, e2, n2); // (p2.y: floor(q / pi) of the layer, parked by phase A)
             e1 = n1;
             e2 = n2;
             dr = d2;
@@ -177,7 +179,12 @@ __device__ __forceinline__ void wave_sync()
 // (4 / 6 / 8 trials: 1.82 / 1.53 / 1.42 ms for 1016 models of 3-9 layers), so the shallow models of a window get eight,
 // its deep ones keep four.  Scheduling only: which values the search consumes does not depend on it.
 constexpr int ADAPT_MAX_TRIALS = 8;
-template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT>
+// CNTB: the build with the counted scan of Love targets (SearchT, swd_common.h: same brackets, same bits, a third of the scan's
+// evaluations).  Its state machine and the mode count in Love's recursion cost every wavefront of the launch a little (code
+// size, scalar registers), so it is compiled into the launches where it pays -- one model per wavefront (ADAPT: a single
+// model, the chains' windows), launches of Love targets only -- and not where Rayleigh wavefronts set the time anyway
+// (c2: Rayleigh + Love at B = 4096: 3.37 ms without, 3.47 with; the Rayleigh wavefront alone on its SIMD takes 3.06).
+template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -200,11 +207,16 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     }
     int G = A.lanes[cls];
     const SwdTarget T = A.t[ty];
+    int nlist = A.B; // entries of the processing order this launch covers
+    if (T.count != nullptr) { // (a re-run of listed models: the count lives on the device)
+        const int c = *T.count;
+        nlist = c < nlist ? c : nlist;
+    }
     int J = T.look > 1 ? T.look : 1; // look-ahead: trial velocities per round (per target), one lane group each
     int rows_own = 0;
     if (ADAPT) { // (one class, one model per wavefront: wavefront `wid` has model `wid` of the processing order)
         const int32_t *perm0 = T.perm != nullptr ? T.perm : A.perm;
-        const bool v0 = !beyond && wid < A.B;
+        const bool v0 = !beyond && wid < nlist;
         int m0 = v0 ? A.nlay[perm0 ? perm0[wid] : wid] : 2;
         m0 = __builtin_amdgcn_readfirstlane(m0);
         m0 = m0 < 2 ? 2 : (m0 > A.rows[1] ? A.rows[1] : m0);
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     const int lane = threadIdx.x & (BH_WAVE - 1);
     // the workgroup's shared copy of the libm tables, then one private region per wavefront
     // this launch's range of the processing order (see SwdMultiArgs::split)
-    int lo = 0, hi = A.B;
+    int lo = 0, hi = nlist;
     if (A.split != nullptr) {
         const int ndeep = A.split[0];
         if (cls == 0) hi = ndeep;
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0);
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
@@ -356,9 +368,11 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
         if (prof) t0 = clock64();
         const double omg = S.omega;
         const int cb = rr * JL + (li % JL); // the trial this lane carries through the recursion
-        const double cev = (J * JL == 1) ? S.ceval : S.candidate(cb);
+        // (Rayleigh wavefronts take the instantiations without the counted scan -- `ifunc` is uniform per wavefront)
+        const double cev = (J * JL == 1) ? S.ceval : ((!CNTB || ifunc == 2) ? S.template candidate<false>(cb) : S.template candidate<CNTB>(cb));
         const double wvno = omg / cev;
         double del;
+        int nv = -1; // Love: the packed mode count of this lane's trial (LoveCount)
         if (ifunc == 2) {
             double omega = omg;
             if (omega < 1.0e-4) omega = 1.0e-4;
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
             }
             // ---- phase A (Love): cosq, y, z, xmu per layer, for each of the group's JL trials ----------
             for (int jj = 0; jj < JL; ++jj) {
-                const double wv = (JL == 1) ? wvno : omg / S.candidate(rr * JL + jj);
+                const double wv = (JL == 1) ? wvno : omg / S.template candidate<CNTB>(rr * JL + jj);
                 for (int m = li; m <= mmax - 2; m += G) {
                     if (m >= llw - 1) {
                         const double beta1 = md.Bv(m);
@@ -485,12 +499,13 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                         const double wvnom = fabs(wv - xkb);
                         const double rb = sqrt(wvnop * wvnom);
                         const double q = dm * rb;
-                        double cosq, y, z;
+                        double cosq, y, z, fl = 0.0;
                         if (wv < xkb) {
                             double sinq;
                             bh_sincos(q, &sinq, &cosq, LT);
                             y = sinq / rb;
                             z = -rb * sinq;
+                            if (CNTB) fl = love_zero_floor(q);
                         } else if (wv == xkb) {
                             cosq = 1.0;
                             y = dm;
@@ -506,11 +521,12 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                         double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE + LOVE_TERMS * jj);
                         dst[0] = make_double2(cosq, y);
                         dst[1] = make_double2(z, xmu);
-                        dst[2] = make_double2(bh_rcp_refined(xmu), 0.0);
+                        dst[2] = make_double2(bh_rcp_refined(xmu), fl);
                     }
                 }
             }
             double e1, e2;
+            LoveCount lc;
             {
                 const double rho1 = md.R(mmax - 1);
                 const double xkb = h_xkb;
@@ -519,29 +535,36 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                 const double rb = sqrt(wvnop * wvnom);
                 e1 = rho1 * rb;
                 e2 = h_gammk;
+                lc.reset(wvno > xkb);
             }
             wave_sync();
             if (prof) t1c = clock64();
             {
                 const double s1 = e1, s2 = e2;
+                const LoveCount lc0 = lc;
                 DivRange dr;
                 dr.reset();
                 const double *camt = cam + LOVE_TERMS * (li % JL); // this lane's trial
-                if (ragged) love_chain_group<true, false>(e1, e2, camt, mtop, mmax, llw, dr);
-                else love_chain_group<false, false>(e1, e2, camt, mtop, mmax, llw, dr);
+                if (ragged) love_chain_group<true, false, CNTB>(e1, e2, camt, mtop, mmax, llw, dr, lc);
+                else love_chain_group<false, false, CNTB>(e1, e2, camt, mtop, mmax, llw, dr, lc);
                 if (!dr.ok() && S.active) {
                     e1 = s1;
                     e2 = s2;
-                    love_chain_group<true, true>(e1, e2, camt, mtop, mmax, llw, dr);
+                    lc = lc0;
+                    love_chain_group<true, true, CNTB>(e1, e2, camt, mtop, mmax, llw, dr, lc);
                 }
             }
             del = e1;
+            if (CNTB) nv = lc.packed(e1, e2);
             wave_sync();
         }
         if (prof) t2c = clock64();
+        auto consume = [&](auto cnt_tag) {
+            constexpr bool CNT = decltype(cnt_tag)::value;
         // Every lane of the model can read all J (velocity, value) pairs; the search consumes them for
         // as long as its next request is the very velocity (at the same omega) the next group evaluated.
-        if (BULK && J * JL > 2) { // (measured: pays from three trials per round on; with two it costs 6 % at B = 4096)
+        if (BULK && !CNT && J * JL > 2) { // (measured: pays from three trials per round on; with two it costs 6 % at B = 4096; Love's
+                                          //  counted scan hardly ever takes plain steps: not compiled in for its wavefronts)
             // The same consumption with the runs of plain bracket steps taken in one go.  A trial is PLAIN for its model
             // when the search is scanning (ST_STEP), the value has the sign of del1, the velocity is inside the scan's
             // bounds and the request after it is again the plain next step: consuming it only moves (c1, del1) on.
@@ -556,10 +579,12 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                 const int tj = live ? jn : 0;
                 const int srcn = (g * J + tj / JL) * G + (tj % JL);
                 const double cj = __shfl(cev, srcn), dj = __shfl(del, srcn);
+                const int nj = __shfl(nv, srcn);
                 if (jn > 0) live = live && S.ceval == cj && S.omega == omg;
                 const double nxt = (S.idir > 0) ? cev + S.dc : cev - S.dc;
+                // (a step that reaches a half-space velocity goes through advance(): the guard's probes)
                 const bool plain = S.active && S.st == ST_STEP && !signs_differ(S.del1, del) &&
-                                   !(cev < S.cm || cev >= S.betmxd + S.dc) && nxt > S.clow;
+                                   !(cev < S.cm || cev >= S.betmxd + S.dc) && nxt > S.clow && fmax(cev, S.c1) < S.vsafe;
                 const unsigned long long pm = __ballot(plain);
                 bool run = false;
                 if (live && S.st == ST_STEP) {
@@ -575,11 +600,12 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                         S.c2 = (S.idir > 0) ? cl + S.dc : cl - S.dc;
                         S.ceval = S.c2;
                         S.evals += (unsigned)(t - jn);
+                        S.isteps += t - jn;
                         jn = t;
                     }
                 }
                 if (live && !run) {
-                    S.advance(dj);
+                    S.template advance<CNT>(dj, nj);
                     ++jn;
                 }
                 live = live && S.active && jn < Jtot;
@@ -589,10 +615,12 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
             const int Jtot = J * JL;
             for (int j = 0; j < Jtot; ++j) {
                 double dj = del;
+                int nj = nv;
                 if (Jtot > 1) {
                     const int src = (g * J + j / JL) * G + (j % JL); // a lane that carried trial j
                     const double cj = __shfl(cev, src);
                     dj = __shfl(del, src);
+                    nj = __shfl(nv, src);
                     // trial 0 IS the pending request (consumed unconditionally, also when a broken model
                     // has driven the search to NaN); a later trial only if the search now asks for it
                     if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
@@ -604,7 +632,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                     // does then, without its way through the continuation tags
                     const double nx = (S.idir > 0) ? S.c2 + S.dc : S.c2 - S.dc;
                     const bool plain = live && S.st == ST_STEP && !signs_differ(S.del1, dj) &&
-                                       !(S.c2 < S.cm || S.c2 >= S.betmxd + S.dc) && nx > S.clow;
+                                       !(S.c2 < S.cm || S.c2 >= S.betmxd + S.dc) && nx > S.clow && fmax(S.c1, S.c2) < S.vsafe;
                     if (plain) {
                         S.del2 = dj;
                         S.c1 = S.c2;
@@ -612,12 +640,16 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                         S.c2 = nx;
                         S.ceval = nx;
                         ++S.evals;
+                        ++S.isteps;
                     } else if (live) {
-                        S.advance(dj);
+                        S.template advance<CNT>(dj, nj);
                     }
-                } else if (live) S.advance(dj);
+                } else if (live) S.template advance<CNT>(dj, nj);
             }
         }
+        };
+        if (!CNTB || ifunc == 2) consume(std::false_type{});
+        else consume(std::integral_constant<bool, CNTB>{});
         if (prof) {
             const long long t3 = clock64();
             tA += t1c - t0;
@@ -626,7 +658,10 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
         }
     }
     if (board != nullptr) *reinterpret_cast<volatile unsigned *>(board + hw_slot) = (A.stamp << 16) | 0xffffu;
-    if (valid && li == 0 && rr == 0 && !spare) T.err[ib] = S.errflag;
+    if (valid && li == 0 && rr == 0 && !spare) {
+        T.err[ib] = S.errflag;
+        if (FAST && S.has(S.F_GUARD) && T.gcount != nullptr) T.glist[atomicAdd(T.gcount, 1)] = ib; // to be run again with the reference's sequence
+    }
     if (prof) {
         unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
         unsigned long long lps = tot * (unsigned long long)(valid ? mmax - 1 : 0);
@@ -825,7 +860,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     dim3 grid((nwaves + wpb - 1) / wpb, a.ntargets, two ? 2 : 1);
     a.wg_n0 = a.wg_n1 = 0;
     static const bool no_mix = std::getenv("BH_SWD_NO_MIX") != nullptr; // experiment switch
-    if (a.ntargets == 2 && !two && !no_mix) { // two targets, one depth class: interleave their wavefronts (see the kernel)
+    if (a.ntargets == 2 && !two && !no_mix && !a.rerun) { // two targets, one depth class: interleave their wavefronts (see the kernel)
         int n[2];
         for (int t = 0; t < 2; ++t) {
             int J = a.t[t].look > 1 ? a.t[t].look : 1;
@@ -926,22 +961,33 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     a.fast = build;
     const dim3 block(BH_WAVE * wpb);
     const bool counted = a.neval != nullptr;
-#define BH_GROUP_LAUNCH(WP, FM, SI, PR) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, false>), grid, block, lds, stream, a, redundant, (int)wave_lds)
-#define BH_GROUP_LAUNCH_ADAPT(FM, PR) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, FM, true, PR, true>), grid, block, lds, stream, a, redundant, (int)wave_lds)
+    // The builds with the counted scan (CNTB, see the kernel): asked for, a Love target in the launch, and the launch is of the
+    // kind it pays in -- one model per wavefront, or Love targets only.  BH_SWD_SCAN_ALWAYS=1: wherever asked for (measurements).
+    bool any_love = false, all_love = true;
+    for (int t = 0; t < a.ntargets; ++t) {
+        any_love = any_love || a.t[t].iwave == 1;
+        all_love = all_love && a.t[t].iwave == 1;
+    }
+    static const bool cnt_always = std::getenv("BH_SWD_SCAN_ALWAYS") != nullptr; // experiment switch
+    const bool cntb = a.counted != 0 && any_love && wpb == GROUP_WPB && (adapt || all_love || cnt_always);
+    a.counted = cntb ? 1 : 0;
+#define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
+#define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
+#define BH_GROUP_LAUNCH_ADAPT(FM, PR) do { if (cntb) BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, true); else BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, false); } while (0)
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
-    if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only)
+    if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
         static bool big_lds = false;
         if (lds > WG_LDS_CAP && !big_lds) {
-            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false>),
-                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true, false>)};
+            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false, false>),
+                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true, false, false>)};
             for (const void *k : k4)
                 if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
             big_lds = true;
         }
-        if (build == 2) BH_GROUP_LAUNCH(4, 2, false, true);
-        else if (build == 1) BH_GROUP_LAUNCH(4, 1, false, true);
-        else BH_GROUP_LAUNCH(4, 0, false, true);
+        if (build == 2) BH_GROUP_LAUNCH_(4, 2, false, true, false, false);
+        else if (build == 1) BH_GROUP_LAUNCH_(4, 1, false, true, false, false);
+        else BH_GROUP_LAUNCH_(4, 0, false, true, false, false);
     } else if (adapt && build == 2) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
         else BH_GROUP_LAUNCH_ADAPT(2, false);
@@ -963,6 +1009,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     }
 #undef BH_GROUP_LAUNCH_ADAPT
 #undef BH_GROUP_LAUNCH
+#undef BH_GROUP_LAUNCH_
     return 0;
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
 
     SearchT<BH_WAVE, NEV_LO, FAST, SIMPLE> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
-           cpl + lane, cpl + (size_t)K * BH_WAVE + lane);
+           cpl + lane, cpl + (size_t)K * BH_WAVE + lane, IFUNC, A.counted != 0);
     {
         const size_t nl = (size_t)gridDim.x * LANE_WPB * BH_WAVE; // lanes of the launch
         double *hx = A.nev_high + (size_t)wid * BH_WAVE + lane;
@@ -156,23 +156,24 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
         }
         if (!S.active) continue; // (the lanes of a model share its state: they leave together)
         const double omg = S.omega;
-        const double cev = LOOK ? S.candidate(r) : S.ceval;
+        const double cev = LOOK ? S.template candidate<IFUNC == 1>(r) : S.ceval;
         const double wvno = omg / cev;
         double del;
+        int nv = -1; // Love: the packed mode count of this evaluation (LoveCount)
         DivRange dr;
         dr.reset();
         if (IFUNC == 1)
-            del = love_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT);
+            del = love_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT, &nv);
         else
             del = rayleigh_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT);
         if (!dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
             if (IFUNC == 1)
-                del = love_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT);
+                del = love_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT, &nv);
             else
                 del = rayleigh_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT);
         }
         if (!LOOK) {
-            S.advance(del);
+            S.template advance<IFUNC == 1>(del, nv);
         } else {
             // every lane of the model reads all J (velocity, value) pairs; the search consumes them for as long as
             // its next request is the very velocity (at the same omega) the next lane evaluated
@@ -180,14 +181,18 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
             for (int j = 0; j < J; ++j) {
                 const double cj = __shfl(cev, lbase + j);
                 const double dj = __shfl(del, lbase + j);
+                const int nj = (IFUNC == 1) ? __shfl(nv, lbase + j) : -1;
                 // trial 0 IS the pending request (consumed unconditionally); a later one only if asked for now
                 if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;
                 if (__ballot(live) == 0ull) break;
-                if (live) S.advance(dj);
+                if (live) S.template advance<IFUNC == 1>(dj, nj);
             }
         }
     }
-    if (valid && r == 0) A.err[ib] = S.errflag;
+    if (valid && r == 0) {
+        A.err[ib] = S.errflag;
+        if (FAST != 0 && S.has(S.F_GUARD) && A.gcount != nullptr) A.glist[atomicAdd(A.gcount, 1)] = ib; // to be run again with the reference's sequence
+    }
     if (A.neval != nullptr) {
         // [0] secular evaluations; per wave type ([8] Rayleigh / [9] Love) evaluations and ([10] / [11]) layer-
         // propagator steps = evaluations x finite layers of the model (the flop model of SURVEY.md 8(d))

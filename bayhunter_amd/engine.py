@@ -26,6 +26,7 @@ RF_P, RF_SV = 0, 1
 LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
 TARGET_SWD, TARGET_RF, TARGET_USER = 0, 1, 2
 SEARCH_REFERENCE, SEARCH_FAST = 0, 1  # bh_engine_set_swd_search
+SCAN_STEPS, SCAN_COUNTED = 0, 1        # bh_engine_set_swd_scan
 MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
 
 _d = C.POINTER(C.c_double)
@@ -107,6 +108,9 @@ def load_library():
     L.bh_engine_set_swd_lookahead.argtypes = [vp, C.c_int]
     L.bh_engine_set_swd_search.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_search.argtypes = [vp]
+    L.bh_engine_set_swd_scan.argtypes = [vp, C.c_int]
+    L.bh_engine_get_swd_scan.argtypes = [vp]
+    L.bh_engine_guard_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
     L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
@@ -129,19 +133,19 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 5:
+    if L.bh_abi_version() != 6:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -238,6 +242,26 @@ class Engine(object):
 
     def swd_search(self):
         return "fast" if self._L.bh_engine_get_swd_search(self._h) == SEARCH_FAST else "reference"
+
+    def set_swd_scan(self, scan):
+        """"counted" (default): Love bracket scans skip the steps a mode count proves to be without a sign change -- same
+        brackets, same bits, a third of the scan's evaluations; "steps": every step evaluated, as the reference does
+        (include/bh_engine.h: bh_engine_set_swd_scan)."""
+        code = {"steps": SCAN_STEPS, "counted": SCAN_COUNTED, SCAN_STEPS: SCAN_STEPS, SCAN_COUNTED: SCAN_COUNTED}.get(scan)
+        if code is None:
+            raise ValueError("scan must be 'steps' or 'counted'")
+        self._check(self._L.bh_engine_set_swd_scan(self._h, code))
+
+    def swd_scan(self):
+        return "counted" if self._L.bh_engine_get_swd_scan(self._h) == SCAN_COUNTED else "steps"
+
+    def guard_stats(self):
+        """(models per target of the last dispersion call that the guard of the "fast" search re-ran with the reference's
+        sequence, re-run launches enqueued since the engine was created)"""
+        counts = (C.c_int32 * 8)()
+        n = C.c_uint64(0)
+        self._check(self._L.bh_engine_guard_stats(self._h, counts, C.byref(n)))
+        return list(counts), int(n.value)
 
     def timing_reset(self):
         self._check(self._L.bh_timing_reset(self._h))

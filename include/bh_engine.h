@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 5
+#define BH_ABI_VERSION 6
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -91,16 +91,39 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  *     (regula falsi, then an inverse-quadratic estimate accepted on a sign change within +-5e-8 relative) instead of
  *     nevill's 10-12, whose stop test is the bracket width.  Phase-velocity targets only (group-velocity targets keep
  *     the reference sequence: a group velocity is a difference quotient of two roots and amplifies their scatter a
- *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5); the failure
- *     flag agrees except where the reference's own outcome hinges on a 1e-6 shift of its scan grid (a Love root within
- *     ~1.3e-3 km/s of the half-space velocity at the LAST period: 145 of 9.4 million random models);
- *     a deterministic function of the model (independent of batch and launch plan), but NOT the
+ *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5).  The failure
+ *     flag and the period from which a failed model's row is zero are the REFERENCE's: where the reference's own outcome
+ *     hinges on a 1e-6 shift of its scan grid (a root and its mirror image around a half-space velocity closer together
+ *     than a scan step) a guard detects the situation with one or two probe evaluations and the model is
+ *     run again with the reference's sequence in a second, small launch of the same call (bh_engine_guard_stats).
+ *     A deterministic function of the model (independent of batch and launch plan), but NOT the
  *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
  * Also BH_SWD_SEARCH=fast in the environment at engine creation. */
 #define BH_SEARCH_REFERENCE 0
 #define BH_SEARCH_FAST 1
 int bh_engine_set_swd_search(bh_engine *e, int search);
 int bh_engine_get_swd_search(const bh_engine *e);
+/* The bracket scan of Love targets (both search modes).
+ *   BH_SCAN_COUNTED (default): getsol's scan (surfdisp96.f:437-460) looks for the first step of its grid c1 + i dc over which
+ *     the secular function changes sign, one evaluation per step.  For Love waves the number of sign changes below a trial
+ *     velocity can be read off the very recursion that evaluates the function (Sturm's oscillation theorem for the SH
+ *     problem: zeros of the displacement in the layers, csrc/swd_common.h LoveCount), so two evaluations certify that none
+ *     of the steps between them shows a sign change -- they are skipped -- or that exactly one does -- it is located by a
+ *     search over the step index.  The grid points are the reference's (repeated additions of dc), the bracket handed to
+ *     the refinement is the reference's, hence every bit of the result: same velocities, same failure flags, about a third
+ *     of the scan's evaluations (c2 Love: 927 -> 470 evaluations per model; with BH_SEARCH_FAST 673 -> 216).
+ *   BH_SCAN_STEPS: every step evaluated, as the reference does (measurements; the evaluation counts of the oracle's
+ *     restatement of the reference).
+ * Rayleigh targets always take BH_SCAN_STEPS (no such count for the P-SV problem here).  Also BH_SWD_SCAN=steps|counted in
+ * the environment at engine creation. */
+#define BH_SCAN_STEPS 0
+#define BH_SCAN_COUNTED 1
+int bh_engine_set_swd_scan(bh_engine *e, int scan);
+int bh_engine_get_swd_scan(const bh_engine *e);
+/* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
+ * dispersion call that its guard sent back to the reference's sequence; *rerun_launches (may be NULL) = re-run launches
+ * enqueued since the engine was created.  Synchronises the engine's stream when counts != NULL. */
+int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches);
 /* Tuning hint for BH_DEVICE calls: the typical number of layers (incl. the half-space) of the models in
  * the batches to come, when it is well below Lmax (transdimensional chains: capacity 21, typically 5-7).
  * The lanes-per-model choice is sized for it; 0 = unknown (Lmax is used).  BH_HOST calls look at nlay

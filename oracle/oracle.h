@@ -38,6 +38,18 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
  * only) instead of the reference's nevill -- a restatement of THIS repo's swd_common.h, not of the reference; 0 (default):
  * the reference's sequence.  Process-wide switch. */
 void bho_swd_set_search(int fast);
+/* 2: the same, GUARDED the way the engine runs BH_SEARCH_FAST: a model whose short-sequence run fails in any mode or accepts
+ * a root within two scan steps of the fastest S velocity / a half-space velocity is run again with the reference's sequence
+ * (swd_oracle.c, bho_surfdisp96).  bho_swd_guarded_count: how many models that was since the last reset. */
+int64_t bho_swd_guarded_count(int reset);
+/* Scan mode: 0 (default here) = getsol's scan, one step of dc per evaluation -- the restatement proper, the one pinned to the
+ * compiled reference; 1 = the engine's counted scan (Love: steps a mode count proves to be without a sign change are not
+ * visited; swd_oracle.c, bracket_and_refine): the same brackets and bits with fewer evaluations, restated here so that the
+ * device's evaluation counts can be checked and the certificate itself tested against mode 0 on the CPU. */
+void bho_swd_set_scan(int counted);
+void bho_swd_set_scan_tuning(int first, int next, int back);
+double bho_dltar1_count(double wvno, double omega, const float *d, const float *b, const float *rho,
+                        int mmax, int llw, int *count, int *valid);
 
 /* Secular functions, exposed so that tests can compare them 1:1 with the reference's
  * exported dltar1_/dltar4_ symbols.  surfdisp96.f:710-769 and :773-871. */

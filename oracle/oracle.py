@@ -47,6 +47,12 @@ def lib():
         L.bho_dltar4.argtypes = [C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int]
         L.bho_swd_set_search.restype = None
         L.bho_swd_set_search.argtypes = [C.c_int]
+        L.bho_swd_set_scan.restype = None
+        L.bho_swd_set_scan.argtypes = [C.c_int]
+        L.bho_swd_set_scan_tuning.restype = None
+        L.bho_swd_set_scan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.bho_swd_guarded_count.restype = C.c_int64
+        L.bho_swd_guarded_count.argtypes = [C.c_int]
         L.bho_gtsolh.restype = C.c_float
         L.bho_gtsolh.argtypes = [C.c_float, C.c_float]
         L.bho_swd_batch.restype = None
@@ -90,9 +96,29 @@ def surfdisp96(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, 
 
 
 def set_swd_search(fast):
-    """True: the engine's optional short refinement (a restatement of swd_common.h, NOT of the reference) instead of the
-    reference's nevill; process-wide.  Use `with swd_search(True): ...` in tests."""
-    lib().bho_swd_set_search(1 if fast else 0)
+    """1 / True: the engine's short root refinement as it is (a restatement of swd_common.h, NOT of the reference) instead of
+    the reference's nevill; 2: the same with the guard the engine applies (models in the situations where the reference's
+    own outcome hinges on the last bits of a root are re-run with the reference's sequence); 0: the reference's sequence.
+    Process-wide.  Use `with swd_search(2): ...` in tests."""
+    lib().bho_swd_set_search(int(fast))
+
+
+def swd_guarded_count(reset=True):
+    """models the guard of search mode 2 sent back to the reference sequence since the last reset"""
+    return int(lib().bho_swd_guarded_count(1 if reset else 0))
+
+
+class swd_scan:
+    """with swd_scan(1): the engine's counted scan (same bits, fewer evaluations) instead of getsol's step-by-step scan"""
+
+    def __init__(self, counted):
+        self.counted = counted
+
+    def __enter__(self):
+        lib().bho_swd_set_scan(int(self.counted))
+
+    def __exit__(self, *a):
+        lib().bho_swd_set_scan(0)
 
 
 class swd_search:

@@ -81,6 +81,78 @@ double bho_dltar1(double wvno, double omega, const float *d, const float *b, con
     return e1;
 }
 
+/* ---- Love: the same function with a MODE COUNT (not in the reference; restates swd_common.h, love count) -----------
+ * The SH problem at fixed omega is a Sturm-Liouville problem in k^2: with (e1, e2) ~ (stress, displacement) of the solution
+ * that decays in the half-space (valid for c < beta of the half-space), integrated upward as dltar1 does,
+ *     N(c) = number of roots of dltar1(., omega) below c = Z + [e1 * e2 < 0 at the surface],
+ * Z = zeros of the displacement in the finite layers (oscillation theorem: zeros enter at the free surface one by one, each
+ * Dirichlet eigenvalue between two Neumann ones).  Zeros inside ONE layer: the displacement there is a pure sinusoid of
+ * phase advance q = d * rb (or a cosh/sinh combination: at most one zero), so their number is floor(q / pi) or that + 1,
+ * and the parity is the sign change of e2 across the layer -- which the recursion gives with the reference's own bits.
+ * Hence sign(dltar1) == (-1)^N exactly as computed, and N(c2) - N(c1) certifies how many sign changes of the reference's
+ * function lie between two trial velocities WITHOUT evaluating the grid points in between.
+ * *valid = 0 where that argument does not hold: c >= beta of the half-space, or q / pi within 1e-9 of an integer in some
+ * layer (floor ambiguous by two).  Returns the very bits of bho_dltar1. */
+double bho_dltar1_count(double wvno, double omega, const float *d, const float *b, const float *rho,
+                        int mmax, int llw, int *count, int *valid)
+{
+    const double rpi = 0.31830988618379067154; /* 1/pi */
+    double beta1 = (double)b[mmax - 1];
+    double rho1 = (double)rho[mmax - 1];
+    double xkb = omega / beta1;
+    double wvnop = wvno + xkb;
+    double wvnom = fabs(wvno - xkb);
+    double rb = sqrt(wvnop * wvnom);
+    double e1 = rho1 * rb;
+    double e2 = 1.0 / (beta1 * beta1);
+    int n = 0, ok = (wvno > xkb);
+    for (int m = mmax - 2; m >= llw - 1; --m) {
+        double cosq, y, z;
+        beta1 = (double)b[m];
+        rho1 = (double)rho[m];
+        double xmu = rho1 * beta1 * beta1;
+        xkb = omega / beta1;
+        wvnop = wvno + xkb;
+        wvnom = fabs(wvno - xkb);
+        rb = sqrt(wvnop * wvnom);
+        double q = (double)d[m] * rb;
+        int fl = 0;
+        if (wvno < xkb) { /* propagating */
+            double sinq;
+            sincos(q, &sinq, &cosq);
+            y = sinq / rb;
+            z = -rb * sinq;
+            const double x = q * rpi, xf = floor(x);
+            if (!(x - xf > 1.0e-9 && xf + 1.0 - x > 1.0e-9) || !(x < 1.0e9)) ok = 0;
+            fl = (x < 1.0e9) ? (int)xf : 0;
+        } else if (wvno == xkb) {
+            cosq = 1.0;
+            y = (double)d[m];
+            z = 0.0;
+        } else { /* evanescent, scaled by exp(-q) */
+            double fac = 0.0;
+            if (q < 16.0) fac = exp(-2.0 * q);
+            cosq = (1.0 + fac) * 0.5;
+            double sinq = (1.0 - fac) * 0.5;
+            y = sinq / rb;
+            z = rb * sinq;
+        }
+        double e10 = e1 * cosq + e2 * xmu * z;
+        double e20 = e1 * y / xmu + e2 * cosq;
+        double xnor = fabs(e10);
+        double ynor = fabs(e20);
+        if (ynor > xnor) xnor = ynor;
+        if (xnor < 1.0e-40) xnor = 1.0;
+        const int flip = signs_differ(e20, e2);
+        n += fl + (((fl & 1) != flip) ? 1 : 0);
+        e1 = e10 / xnor;
+        e2 = e20 / xnor;
+    }
+    *count = n + (signs_differ(e1, e2) ? 1 : 0);
+    *valid = ok;
+    return e1;
+}
+
 /* ---- Rayleigh helpers -------------------------------------------------------------- */
 
 typedef struct {
@@ -277,6 +349,18 @@ static inline double secular(const medium *md, double wvno, double omega)
     return bho_dltar4(wvno, omega, md->d, md->a, md->b, md->rho, md->mmax, md->llw);
 }
 
+/* Love only: value + mode count (bho_dltar1_count); *valid = 0 for Rayleigh (no such count for the P-SV problem here). */
+static inline double secular_count(const medium *md, double wvno, double omega, int *count, int *valid)
+{
+    if (md->ifunc != 1) {
+        *count = 0;
+        *valid = 0;
+        return secular(md, wvno, omega);
+    }
+    ++g_neval;
+    return bho_dltar1_count(wvno, omega, md->d, md->b, md->rho, md->mmax, md->llw, count, valid);
+}
+
 /* ---- half-space Rayleigh velocity, 5 Newton steps, all binary32.  surfdisp96.f:367-388 -- */
 float bho_gtsolh(float a, float b)
 {
@@ -379,8 +463,26 @@ static double refine_root(const medium *md, double t, double c1, double c2, doub
  * x - tau and x + tau (tau = 5e-8 |x|: the root is known twenty times closer than the reference's own stop test
  * |c1 - c2| <= 1e-6 c1 leaves it); a miss moves the bracket and repeats, bisection from the seventh pass on. */
 #define BHO_FAST_TAU 5.0e-8
-static int g_fast_search = 0;
-void bho_swd_set_search(int fast) { g_fast_search = fast ? 1 : 0; }
+static int g_fast_search = 0; /* 0 reference sequence, 1 the short sequence as it is, 2 the short sequence with the guard below */
+void bho_swd_set_search(int fast) { g_fast_search = (fast < 0 || fast > 2) ? 0 : fast; }
+/* Scan mode (bh_engine_set_swd_scan): 0 = getsol's scan, one step of dc per evaluation; 1 (the engine's default) = the same
+ * scan with the steps a MODE COUNT certifies as empty skipped (Love; bracket_and_refine).  Same brackets, same bits. */
+static int g_scan_mode = 0;
+void bho_swd_set_scan(int counted) { g_scan_mode = counted ? 1 : 0; }
+static int g_stride_first = 16, g_stride_next = 4, g_stride_back = -1, g_stride_secant = 1; /* (tuning experiments) */
+void bho_swd_set_scan_tuning(int first, int next, int back) { g_stride_first = first; g_stride_next = next % 100; g_stride_back = back; g_stride_secant = next < 100; }
+static int64_t g_guarded = 0; /* models the guard sent back to the reference sequence (statistics) */
+int64_t bho_swd_guarded_count(int reset)
+{
+    int64_t v;
+#pragma omp atomic read
+    v = g_guarded;
+    if (reset) {
+#pragma omp atomic write
+        g_guarded = 0;
+    }
+    return v;
+}
 
 static double refine_root_fast(const medium *md, double t, double c1, double c2, double del1, double del2, double betmx)
 {
@@ -460,17 +562,173 @@ static double refine_root_fast(const medium *md, double t, double c1, double c2,
 }
 
 /* ---- bracket search.  surfdisp96.f:390-482 (`getsol`).  Returns 1 ok / -1 failed. ------- */
+/* The guard of search mode 2 (see bho_surfdisp96).  The half-space terms of both secular functions contain |k - k_v|
+ * (surfdisp96.f:728-729, :793-797), so a root r creeping up to a half-space velocity v has a mirror-image sign change r'
+ * just above v.  The reference's scan grid is anchored at the PREVIOUS root, which the short sequence knows to ~1e-6 only:
+ * the two grids differ by s, |s| < 6e-6 km/s, and the two scans see different sign patterns exactly when a sign change lies
+ * within |s| of a grid point.  With a lone root that only moves the bracket by a cell (same root); with the pair (r, r') it
+ * decides whether the reference sees a sign change AT ALL.  So, with eps = 3e-6 x the velocity (|s| <= 1.05e-6 x it: the
+ * reference stops at a bracket of 1e-6 c1, the short sequence at 5e-8):
+ *   - a scan step [c1, c2] without a sign change that contains a half-space velocity may hide the pair: probe the secular
+ *     function at eps inside both ends; a sign change there means the shifted grid could split the pair   -> guard;
+ *   - an accepted bracket whose root lies within two steps of a half-space velocity (or of betmx): guard if the root is
+ *     within eps of a bracket end, or if the function changes sign within eps OUTSIDE a bracket end (the image sitting
+ *     right behind it), or if the root is within eps of betmx (the `c1 > betmx` test of getsol).
+ * Probes cost evaluations only where a root is near a half-space velocity; the guard itself fires ~1e-3 of those times. */
+#define BHO_GUARD_REL 3.0e-6 /* eps = this x the velocity: three times what the two sequences' roots can differ by */
+#define BHO_GUARD_MARGIN (2.0 * (double)0.005f) /* "near": two scan steps (km/s) */
+typedef struct {
+    int on;       /* collect */
+    int hit;      /* result */
+    double vh[3]; /* half-space S, half-space P (Rayleigh), betmx */
+    int nvh;
+} guard_t;
+
+static int guard_probe(const medium *md, double omega, double c, double ref)
+{
+    return signs_differ(secular(md, omega / c, omega), ref);
+}
+
+/* The counted scan (scan mode 1, Love).  getsol looks for the first step [g, g + dc] of its grid g_i = g_(i-1) + dc over
+ * which the secular function changes sign.  With the mode count N (bho_dltar1_count; sign f == (-1)^N as computed, N the
+ * number of sign changes below) the grid points need not all be visited: N(g_(i+s)) == N(g_i) proves that none of the s
+ * steps in between shows a sign change -- the reference would walk through them -- and a larger count proves there is one, which a
+ * bisection over the grid INDEX finds (the lowest step whose upper end counts more than g_i; taken as the bracket when the
+ * difference is odd, walked over when even: two roots inside one step, invisible to the reference as well).  Every grid
+ * point is formed by the reference's own repeated additions of dc, so the bracket handed to the refinement -- and every
+ * bit after it -- is the reference's.  Upward scans below the slowest of (half-space S velocity, betmx) only; anything
+ * else (downward scans, a scan that has turned round at clow, an ambiguous count) takes the reference's steps one by one.
+ * The stride is a deterministic function of the search state: the first one aims two steps short of where the last
+ * period's bracket was found (*iprev), then 4, 8, ... (first period: 16, 32, 64). */
+typedef struct {
+    int on;
+    int iprev; /* steps from the start value to the bracket of the previous period (0: none yet) */
+} scan_t;
+
+static void guard_after_root(const medium *md, double omega, double c1, double c2, double del1, double del2, double cn,
+                             double betmx, guard_t *gd)
+{
+    const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+    const double flo = (c1 < c2) ? del1 : del2, fhi = (c1 < c2) ? del2 : del1;
+    const double eps = BHO_GUARD_REL * fabs(cn);
+    int near = 0;
+    for (int i = 0; i < gd->nvh; ++i) near = near || fabs(cn - gd->vh[i]) < BHO_GUARD_MARGIN;
+    if (!near) return;
+    if (hi - cn < eps || cn - lo < eps || fabs(cn - betmx) < eps) gd->hit = 1;
+    else if (guard_probe(md, omega, hi + eps, fhi)) gd->hit = 1;
+    else if (guard_probe(md, omega, lo - eps, flo)) gd->hit = 1;
+}
+
+/* A bracketed root: the refinement (+ the guard of search mode 2).  Returns 1 ok / -1 failed / -2 the guard fired.
+ * A bracket that contains betmx can hold THREE sign changes (the root, its mirror image, and the first of the unphysical
+ * ones above the half-space velocity): which of them nevill ends at depends on its whole sequence, so the short sequence
+ * does not try -- the guard fires. */
+static int refine_bracket(const medium *md, double t1, double omega, double c1, double c2, double del1, double del2,
+                          double betmx, int fast, guard_t *gd, double *c1io)
+{
+    if (fast && gd && gd->on && fmax(c1, c2) > betmx && fmin(c1, c2) < betmx) {
+        gd->hit = 1;
+        return -2;
+    }
+    const double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx) : refine_root(md, t1, c1, c2, del1, del2);
+    *c1io = cn;
+    if (fast && gd && gd->on) {
+        guard_after_root(md, omega, c1, c2, del1, del2, cn, betmx, gd);
+        if (gd->hit) return -2;
+    }
+    if (cn > betmx) return -1;
+    return 1;
+}
+
 static int bracket_and_refine(const medium *md, double t1, double *c1io, double clow, double dc,
-                              double cm, double betmx, int ifirst, double *del1st, int fast)
+                              double cm, double betmx, int ifirst, double *del1st, int fast, guard_t *gd, scan_t *sc)
 {
     const double twopi = 2.0 * 3.141592653589793;
     double c1 = *c1io, c2;
     double omega = twopi / t1;
-    double del1 = secular(md, omega / c1, omega);
+    int n1 = 0, v1 = 0;
+    const int counted = sc && sc->on && md->ifunc == 1;
+    double del1 = counted ? secular_count(md, omega / c1, omega, &n1, &v1) : secular(md, omega / c1, omega);
     if (ifirst == 1) *del1st = del1;
     int idir = 1;
     if (ifirst != 1 && signs_differ(*del1st, del1)) idir = -1;
+    int use_count = counted && v1 && idir > 0;
+    int isteps = 0;                                     /* steps taken from the start value */
+    int stride = 0;
+    if (use_count) stride = (sc->iprev > 0) ? sc->iprev - g_stride_back : g_stride_first;
+    const double vlim = fmin((double)md->b[md->mmax - 1], betmx);
     for (;;) {
+        if (use_count) {
+            int s = 0;
+            double cs = c1;
+            while (s < stride) {
+                const double nx = cs + dc;
+                if (!(nx < vlim)) break;
+                cs = nx;
+                ++s;
+            }
+            if (s >= 2) {
+                int ns = 0, vs = 0;
+                const double dels = secular_count(md, omega / cs, omega, &ns, &vs);
+                if (!vs || ns < n1) {
+                    use_count = 0; /* (the value is not used: the reference's steps from c1 on) */
+                    continue;
+                }
+                if (ns == n1) { /* s steps without a sign change */
+                    c1 = cs;
+                    del1 = dels;
+                    isteps += s;
+                    stride = (stride < g_stride_next) ? g_stride_next : 2 * stride;
+                    if (stride > 64) stride = 64;
+                    continue;
+                }
+                /* the lowest step whose upper end counts more than n1 */
+                double chi = cs, delhi = dels;
+                int nhi = ns, n = s, ok = 1;
+                while (n > 1) {
+                    /* where to look next: a straight line through the two known values when exactly one sign change
+                     * lies between them (regula falsi over the grid index), the middle otherwise */
+                    int h = n / 2;
+                    if (g_stride_secant && nhi - n1 == 1) {
+                        const double a1 = fabs(del1), a2 = fabs(delhi);
+                        const double tt = (double)n * (a1 / (a1 + a2));
+                        h = (tt >= 1.0) ? ((tt < (double)(n - 1)) ? (int)tt : n - 1) : 1;
+                    }
+                    double cmid = c1;
+                    for (int i = 0; i < h; ++i) cmid = cmid + dc;
+                    int nm = 0, vm = 0;
+                    const double dm = secular_count(md, omega / cmid, omega, &nm, &vm);
+                    if (!vm || nm < n1 || nm > nhi) {
+                        ok = 0;
+                        break;
+                    }
+                    if (nm > n1) {
+                        chi = cmid; delhi = dm; nhi = nm;
+                        n = h;
+                    } else {
+                        c1 = cmid; del1 = dm;
+                        isteps += h;
+                        n = n - h;
+                    }
+                }
+                if (!ok) {
+                    use_count = 0;
+                    continue;
+                }
+                if (!signs_differ(del1, delhi)) { /* an even number of roots inside one step: walked over */
+                    c1 = chi;
+                    del1 = delhi;
+                    n1 = nhi;
+                    isteps += 1;
+                    stride = g_stride_next;
+                    continue;
+                }
+                c2 = chi; /* == c1 + dc */
+                if (sc) sc->iprev = isteps;
+                return refine_bracket(md, t1, omega, c1, c2, del1, delhi, betmx, fast, gd, c1io);
+            }
+            use_count = 0; /* too close to the limit: the reference's steps from here */
+        }
         c2 = (idir > 0) ? c1 + dc : c1 - dc;
         if (c2 <= clow) { /* never search below clow: turn round, restart from clow */
             idir = 1;
@@ -480,13 +738,22 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
         omega = twopi / t1;
         double del2 = secular(md, omega / c2, omega);
         if (signs_differ(del1, del2)) {
-            double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx) : refine_root(md, t1, c1, c2, del1, del2);
-            *c1io = cn;
-            if (cn > betmx) return -1;
-            return 1;
+            if (sc) sc->iprev = isteps;
+            return refine_bracket(md, t1, omega, c1, c2, del1, del2, betmx, fast, gd, c1io);
+        }
+        if (fast && gd && gd->on && !gd->hit) { /* a step over a half-space velocity that showed no sign change */
+            const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+            int over = 0;
+            for (int i = 0; i < 2 && i < gd->nvh; ++i) over = over || (lo <= gd->vh[i] && gd->vh[i] <= hi);
+            const double eps = BHO_GUARD_REL * hi;
+            if (over && (guard_probe(md, omega, lo + eps, del1) || guard_probe(md, omega, hi - eps, del1))) {
+                gd->hit = 1;
+                return -2; /* the model is run again with the reference's sequence: nothing more to do here */
+            }
         }
         c1 = c2;
         del1 = del2;
+        isteps += 1;
         if (c1 < cm) break;
         if (c1 >= betmx + dc) break;
     }
@@ -550,17 +817,19 @@ static void sphere_density(int ifunc, float *d, float *rho, int mmax, const sphe
     d[mmax - 1] = 0.0f;
 }
 
-/* ---- driver.  surfdisp96.f:55-360 ---------------------------------------------------- */
-int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
-                   int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
-                   const double *t, double *cg, int64_t *neval)
+/* ---- driver.  surfdisp96.f:55-360 ----------------------------------------------------
+ * fast_mode: 0 = the reference's sequence (the restatement proper); 1 = phase-velocity roots refined by the engine's short
+ * sequence (refine_root_fast).  *guard (fast_mode 1 only; may be NULL) is set when the run met one of the situations in
+ * which the REFERENCE's own outcome hinges on the last bits of a previous root -- see bho_surfdisp96 below. */
+static int surfdisp96_run(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                          int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                          const double *t, double *cg, int fast_mode, int *guard)
 {
     float d[NLMAX], a[NLMAX], b[NLMAX], rho[NLMAX];
     double c[NPMAX], cb[NPMAX];
     sphere_state sph;
     int err = 0;
     const int mmax = nlayer;
-    g_neval = 0;
     for (int i = 0; i < mmax; ++i) {
         b[i] = vsm[i];
         a[i] = vpm[i];
@@ -604,11 +873,18 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
         cb[i] = 0.0;
         c[i] = 0.0;
     }
+    guard_t gd = {guard != NULL && fast_mode && igr == 0, 0, {(double)b[mmax - 1], (double)betmx, (double)a[mmax - 1]}, ifunc == 2 ? 3 : 2};
+    { /* (order: half-space S, then -- Rayleigh only, where it also enters |k - k_alpha| -- half-space P; betmx last) */
+        gd.vh[1] = (ifunc == 2) ? (double)a[mmax - 1] : (double)betmx;
+        gd.vh[2] = (double)betmx;
+    }
+    scan_t sc = {g_scan_mode, 0}, sc2 = {g_scan_mode, 0}; /* first / second root of a period */
     double del1st = 0.0; /* Fortran SAVE variable; always (re)set when ifirst == 1 */
     int ift = 999;       /* 1-based index of the first period a previous mode failed at */
     for (int iq = 1; iq <= mode; ++iq) {
         int k;
         int failed = 0;
+        sc.iprev = sc2.iprev = 0;
         for (k = 1; k <= kmax; ++k) {
             if (k >= ift) {
                 failed = 1;
@@ -645,8 +921,12 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
             }
             /* (the short refinement applies to phase-velocity runs only: a group velocity is a difference quotient of
                two roots and amplifies their 1e-6 scatter a hundredfold) */
-            const int fast = g_fast_search && igr == 0;
-            int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st, fast);
+            const int fast = fast_mode && igr == 0;
+            int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st, fast, &gd, &sc);
+            if (iret == -2) { /* the guard fired: this run's results are not used */
+                *guard = 1;
+                return 0;
+            }
             if (iret == -1) {
                 failed = 1;
                 break;
@@ -656,7 +936,7 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
                 t1 = (double)t1b;
                 clow = cb[k - 1] + one * dc;
                 c1 = c1 - onea * dc;
-                iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, 0, &del1st, 0);
+                iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, 0, &del1st, 0, NULL, &sc2);
                 if (iret == -1) c1 = c[k - 1];
                 cb[k - 1] = c1;
             } else {
@@ -676,6 +956,32 @@ int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const 
             ift = k;
             for (int i = k; i <= kmax; ++i) cg[i - 1] = 0.0;
         }
+    }
+    return err;
+}
+
+/* Search mode 2 (bh_engine_set_swd_search(e, BH_SEARCH_FAST) as the engine runs it): the short sequence, GUARDED.  The
+ * scan grid of a period is anchored at the previous period's root (c1 = c(k-1) - 1.5 dc), so where a root and a second sign
+ * change of the secular function lie closer together than a scan step, whether the reference sees a sign change at all
+ * depends on that root to the last bit -- its own outcome flips under a 1e-6 perturbation, and the short sequence's roots
+ * differ from the reference's by up to that.  The one mechanism found (9.4 million random models): a root
+ * creeping up to a half-space velocity has a mirror image just above it (the half-space terms use |k - k_beta|).  The
+ * guard: a model whose short-sequence run (a) fails in any mode or (b) accepts a root within two scan steps of the fastest
+ * S velocity or of a half-space velocity is run AGAIN with the reference's sequence, and that result is the one returned:
+ * failure flags and the zero-from-period-k rows are then the reference's by construction, velocities its bits. */
+int bho_surfdisp96(const float *thkm, const float *vpm, const float *vsm, const float *rhom,
+                   int nlayer, int iflsph, int iwave, int mode, int igr, int kmax,
+                   const double *t, double *cg, int64_t *neval)
+{
+    const int fm = g_fast_search;
+    int guard = 0;
+    g_neval = 0;
+    int err = surfdisp96_run(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, cg, fm != 0,
+                             fm == 2 ? &guard : NULL);
+    if (guard) {
+#pragma omp atomic
+        g_guarded += 1;
+        err = surfdisp96_run(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, cg, 0, NULL);
     }
     if (neval) *neval = g_neval;
     return err;

@@ -135,3 +135,92 @@ def test_short_refinement_restatement_stays_within_tolerance_of_the_reference(or
         assert nfast < 0.8 * nref
     v0, _, n0 = oracle.swd_batch(nlay, *a, per, 1, 0)                # (the switch is off again)
     assert np.array_equal(v0, ov) and n0 == nref
+
+
+def test_love_mode_count_is_monotone_and_consistent_with_the_sign_of_the_secular_function(oracle):
+    """bho_dltar1_count (the restatement of swd_common.h's LoveCount): N(c) = sign changes of dltar1 below c.  On a fine
+    velocity grid N never decreases, it changes parity exactly where the function changes sign, and the value returned is
+    dltar1's bit for bit -- LVZ-rich models, 1 to 60 s."""
+    import ctypes as C
+    from bayhunter_amd.synth import synth_models
+    L = oracle.lib()
+    fp = C.POINTER(C.c_float)
+    L.bho_dltar1_count.restype = C.c_double
+    L.bho_dltar1_count.argtypes = [C.c_double, C.c_double, fp, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rs = np.random.RandomState(5)
+    nlay, h, vp, vs, rho = synth_models(rs, 40, 12, lvz_frac=0.4, ragged=True)
+    pairs = 0
+    for b in range(40):
+        n = int(nlay[b])
+        d, bb, r = [np.ascontiguousarray(x[:n, b], dtype=np.float32) for x in (h, vs, rho)]
+        for T in (1.0, 3.0, 11.0, 60.0):
+            om = 2 * np.pi / T
+            prev = None
+            for c in np.linspace(0.5 * float(bb.min()), float(bb[-1]) * 0.99999, 1500):
+                cnt, val = C.c_int(), C.c_int()
+                f = L.bho_dltar1_count(om / c, om, d.ctypes.data_as(fp), bb.ctypes.data_as(fp), r.ctypes.data_as(fp), n, 1,
+                                       C.byref(cnt), C.byref(val))
+                assert f == L.bho_dltar1(om / c, om, d.ctypes.data_as(fp), bb.ctypes.data_as(fp), r.ctypes.data_as(fp), n, 1)
+                if prev is not None and val.value and prev[2]:
+                    assert cnt.value >= prev[0]
+                    assert ((cnt.value - prev[0]) % 2 == 1) == (np.signbit(f) != np.signbit(prev[1]))
+                    pairs += 1
+                prev = (cnt.value, f, val.value)
+    assert pairs > 200000
+
+
+def test_counted_scan_finds_the_reference_brackets(oracle):
+    """Scan mode 1 (the engine's default; swd_common.h: the counted scan) against getsol's step-by-step scan: the SAME
+    velocities and failure flags, bit for bit, with fewer evaluations -- reference refinement and short refinement, Love
+    phase / group, higher modes, earth flattening, thin and deep LVZ-rich models; Rayleigh unaffected."""
+    from bayhunter_amd.synth import synth_models
+    per = np.linspace(2, 60, 30)
+    cases = [(2024, 4000, 12, 1, 0, 1, 0, per), (7, 6000, 4, 1, 0, 1, 0, np.array([0.5, 1, 2, 3, 5, 8, 13, 21, 34, 55.])),
+             (3, 1500, 12, 1, 0, 3, 0, per), (4, 1500, 12, 1, 1, 2, 0, per), (5, 1500, 12, 1, 0, 1, 1, per),
+             (6, 400, 40, 1, 0, 1, 0, np.linspace(0.3, 40, 60)), (8, 500, 12, 2, 0, 1, 0, per)]
+    for seed, B, L, iwave, igr, mode, flsph, pp in cases:
+        rs = np.random.RandomState(seed)
+        nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.3, ragged=True, hmin=0.2 if L > 20 else 1.5, hmax=3 if L > 20 else 8.0)
+        a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+        for search in (0, 1):
+            with oracle.swd_search(search):
+                v0, e0, n0 = oracle.swd_batch(nlay, *a, pp, iwave, igr, mode=mode, flsph=flsph)
+                with oracle.swd_scan(1):
+                    v1, e1, n1 = oracle.swd_batch(nlay, *a, pp, iwave, igr, mode=mode, flsph=flsph)
+            assert np.array_equal(v0, v1) and np.array_equal(e0, e1), (seed, search)
+            if iwave == 1:
+                assert n1 < 0.85 * n0, (seed, search, n0, n1)
+            else:
+                assert n1 == n0
+
+
+def test_guarded_short_refinement_returns_the_reference_failure_flags(oracle):
+    """Search mode 2 = what BH_SEARCH_FAST runs: the short refinement with its guard (swd_common.h).  Where the reference's
+    own outcome hinges on the last bits of a previous root (a root and its mirror image around a half-space velocity closer
+    together than a scan step; a bracket that contains betmx) the guard fires and the model is run again with the
+    reference's sequence: failure flags AND the period from which a failed row is zero are the reference's on every model,
+    velocities within 1e-5 (achieved 1.2e-6).  Thin models with long periods are where the unguarded sequence differs
+    (here: some tens of rows)."""
+    from bayhunter_amd.synth import synth_models
+    per = np.linspace(2, 60, 30)
+    nraw = 0
+    for seed, B, L, iwave, mode in ((11, 60000, 4, 1, 1), (12, 20000, 12, 1, 1), (13, 6000, 12, 2, 1), (14, 8000, 6, 1, 2)):
+        rs = np.random.RandomState(seed)
+        nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.25, ragged=True)
+        a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+        with oracle.swd_scan(1):
+            ov, oe, nref = oracle.swd_batch(nlay, *a, per, iwave, 0, mode=mode)
+            with oracle.swd_search(1):
+                rv, re_, _ = oracle.swd_batch(nlay, *a, per, iwave, 0, mode=mode)
+            oracle.swd_guarded_count()
+            with oracle.swd_search(2):
+                gv, ge, ng = oracle.swd_batch(nlay, *a, per, iwave, 0, mode=mode)
+            nguard = oracle.swd_guarded_count()
+        nraw += int(((rv == 0) != (ov == 0)).any(axis=1).sum())
+        assert np.array_equal(ge, oe), seed
+        assert np.array_equal(gv == 0, ov == 0), seed
+        both = (gv != 0) & (ov != 0)
+        assert np.max(np.abs(gv[both] - ov[both]) / ov[both]) <= 1.2e-6
+        assert 0 < nguard < 0.3 * B or iwave == 2
+        assert ng < nref or iwave == 1
+    assert nraw > 10   # the unguarded sequence does differ on these sets

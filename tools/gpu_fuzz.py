@@ -3,9 +3,11 @@
 raggedness, periods, wave/velocity types, modes, earth flattening, lane mappings, look-ahead and depth
 hints (dev tool; the fixed cases live in tests/).
     python tools/gpu_fuzz.py SEED NCONFIG          the reference sequence: bit-identical to the oracle
-    FAST=1 python tools/gpu_fuzz.py SEED NCONFIG   the short refinement (bh_engine_set_swd_search): bit-identical to ITS
-                                                   CPU restatement, and against the reference sequence: failure flags,
-                                                   worst relative difference, rows whose zero pattern differs"""
+    FAST=1 python tools/gpu_fuzz.py SEED NCONFIG   the short refinement with its guard (bh_engine_set_swd_search): bit-identical
+                                                   to ITS CPU restatement (oracle search mode 2), and against the reference
+                                                   sequence: failure flags and zero patterns (both must be the reference's),
+                                                   worst relative difference; how many models the guard re-ran
+    SCAN=steps ...                                 every scan step evaluated (default: the counted scan of Love targets)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,6 +24,9 @@ bad = 0
 FAST = os.environ.get("FAST", "0") == "1"
 if FAST:
     eng.set_swd_search("fast")
+if os.environ.get("SCAN", "counted") == "steps":
+    eng.set_swd_scan("steps")
+nguard = 0
 worst, flagdiff, zerodiff, nmodels = 0.0, 0, 0, 0
 t0 = time.time()
 for it in range(ncfg):
@@ -40,7 +45,7 @@ for it in range(ncfg):
     J = int(rs.choice([0, 0, 1, 2, 3, 4, 7]))
     hint = int(rs.choice([0, 0, 3, 6, 12]))
     eng.set_swd_group(G); eng.set_swd_lookahead(J); eng.set_typical_layers(hint)
-    with O.swd_search(FAST):
+    with O.swd_search(2 if FAST else 0):
         ov, oe, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
     if rs.rand() < 0.5:
         v, e = eng.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr, mode=mode, flsph=flsph)
@@ -59,6 +64,7 @@ for it in range(ncfg):
         print("MISMATCH", dict(B=B, L=L, ragged=ragged, K=K, iwave=iwave, igr=igr, mode=mode, flsph=flsph, G=G, J=J, hint=hint),
               "err diff", int((e != oe).sum()), "vel diff", int((v != ov).sum()), flush=True)
     if FAST:   # against the reference sequence
+        nguard += sum(eng.guard_stats()[0])
         rv, re_, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
         both = (v != 0) & (rv != 0)
         if both.any():
@@ -71,6 +77,7 @@ for it in range(ncfg):
         nmodels += B
 if FAST:
     print("against the reference sequence: %d models, worst relative difference %.3g, failure flags differing %d, rows with a "
-          "different zero pattern %d" % (nmodels, worst, flagdiff, zerodiff))
+          "different zero pattern %d, models re-run by the guard %d" % (nmodels, worst, flagdiff, zerodiff, nguard))
+    bad += flagdiff + zerodiff
 print("%d configurations, %d mismatches, %.0f s" % (ncfg, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
