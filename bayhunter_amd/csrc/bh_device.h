@@ -88,6 +88,7 @@ struct SwdTarget {
     const int32_t *count; // optional (device): the launch covers the first *count entries of the processing order only (the
                           // re-run of the models the short refinement's guard fired on: perm = that list)
     int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
+    int refseq;              // 1: in a launch with the short refinement this (phase-velocity) target keeps the reference's sequence
 };
 struct SwdMultiArgs {
     int B, Lmax, ntargets;

@@ -77,9 +77,11 @@ struct bh_engine {
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = 0;  // bh_engine_set_swd_search / BH_SWD_SEARCH=fast: 1 = the short refinement for phase-velocity targets
-    int swd_scan = 1;    // bh_engine_set_swd_scan / BH_SWD_SCAN=plain: 1 = Love scans skip the steps a mode count proves empty (same bits)
+    int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
+    uint64_t guard_total[BH_MAX_TARGETS] = {0}; // guarded models of retired buffers (the live buffer carries its own running sum)
+    bool guard_fresh = true;     // the guard buffer is new: zero its cumulative words as well
     int love_inlook = 0; // BH_SWD_LOVE_INLOOK env (experiment switch): Love trials inside a lane group, 0 = automatic
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -280,11 +282,23 @@ int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
 constexpr int GUARD_HEAD = 16;
 int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t **lists)
 {
-    int rc = ensure(e, e->guard, ((size_t)GUARD_HEAD + (size_t)BH_MAX_TARGETS * (size_t)(B + 4)) * sizeof(int32_t));
+    const size_t need = ((size_t)GUARD_HEAD + (size_t)BH_MAX_TARGETS * (size_t)(B + 4)) * sizeof(int32_t);
+    if (need > e->guard.cap) { // (a new buffer: carry the cumulative counts over on the host side)
+        if (e->guard.p) {
+            int32_t cum[BH_MAX_TARGETS];
+            HIPCHK(e, hipStreamSynchronize(st));
+            HIPCHK(e, hipMemcpy(cum, (int32_t *)e->guard.p + BH_MAX_TARGETS, sizeof(cum), hipMemcpyDeviceToHost));
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) e->guard_total[t] += (uint64_t)cum[t];
+        }
+        e->guard_fresh = true;
+    }
+    int rc = ensure(e, e->guard, need);
     if (rc) return rc;
     *counts = (int32_t *)e->guard.p;
     *lists = (int32_t *)e->guard.p + GUARD_HEAD;
-    HIPCHK(e, hipMemsetAsync(e->guard.p, 0, GUARD_HEAD * sizeof(int32_t), st));
+    // words [0, 8): this call's counts; [8, 16): cumulative since the buffer was made
+    HIPCHK(e, hipMemsetAsync(e->guard.p, 0, (e->guard_fresh ? GUARD_HEAD : BH_MAX_TARGETS) * sizeof(int32_t), st));
+    e->guard_fresh = false;
     return BH_OK;
 }
 
@@ -424,8 +438,9 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         for (int t = 0; t < nlive2; ++t) lane_waves += (long)((B + 63) / 64) * (look[t] > 1 ? look[t] : 1);
         int32_t *gcounts = nullptr, *glists = nullptr;
         bool any_fast = false;
-        for (int j = 0; j < njobs; ++j) any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0);
-        any_fast = any_fast && e->swd_search != 0;
+        for (int j = 0; j < njobs; ++j)
+            any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0 &&
+                                    (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && jobs[j].iwave == BH_WAVE_RAYLEIGH)));
         if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
         ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan;
@@ -458,9 +473,9 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             // their own are left alone (a low-priority phase costs them 8 %: the CU's front end is shared)
             a.fair = lane_waves <= 1024 ? -1 : (lane_waves <= 2048 ? 18 : 12);
             a.nev_high = (double *)e->nevhi.p + nev_off[nth];
-            a.fast = e->swd_search;
+            a.fast = (J.igr == 0 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && J.iwave == BH_WAVE_RAYLEIGH))) ? 1 : 0;
             a.counted = e->swd_scan;
-            if (any_fast && J.igr == 0) {
+            if (a.fast) {
                 a.gcount = gcounts + nth;
                 a.glist = glists + (size_t)nth * (size_t)(B + 4);
             }
@@ -506,18 +521,10 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         }
         t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
     }
-    int32_t *gcounts = nullptr, *glists = nullptr;
-    bool any_fast = false;
-    for (int t = 0; t < a.ntargets; ++t) any_fast = any_fast || a.t[t].igr == 0;
-    any_fast = any_fast && e->swd_search != 0;
-    if (any_fast) {
-        if ((rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
-        for (int t = 0; t < a.ntargets; ++t)
-            if (a.t[t].igr == 0) {
-                a.t[t].gcount = gcounts + t;
-                a.t[t].glist = glists + (size_t)t * (size_t)(B + 4);
-            }
-    }
+    // which targets take the short refinement: phase velocities; with BH_SEARCH_FAST_RAYLEIGH only the Rayleigh ones
+    auto takes_fast = [&](const SwdTarget &t) {
+        return t.igr == 0 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && t.iwave == BH_WAVE_RAYLEIGH));
+    };
     a.counted = e->swd_scan;
     for (int t = 0; t < a.ntargets; ++t) {
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
@@ -525,7 +532,6 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     a.started = e->started;
     a.prio_low = e->swd_prio_low_now;
-    a.fast = e->swd_search;
     a.adapt_ok = (e->force_group == 0 && e->force_look == 0 && e->look_r == 0 && e->look_l == 0) ? 1 : 0;
     {
         static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
@@ -536,14 +542,49 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             std::fprintf(stderr, "\n");
         }
     }
-    ev_begin(e, 0, st);
-    const int lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
-    e->last_swd_wpb = e->swd_wpb_now;
-    if (lrc != 0) {
-        ev_end(e, 0, st);
-        return fail(e, BH_EINVAL, "model too deep for LDS");
-    }
+    // ONE launch for all targets.  Where some phase-velocity targets take the short refinement and others keep the reference's
+    // sequence (BH_SEARCH_FAST_RAYLEIGH with Love targets in the call) the launch takes the build with both sequences and the
+    // targets say which is theirs (two launches side by side were measured: the Rayleigh / Love pairs on the SIMDs are lost,
+    // c4 1.37 -> 1.58 ms per window).
+    SwdMultiArgs part[2];
+    int nparts = 0;
     {
+        int nfast = 0;
+        for (int t = 0; t < a.ntargets; ++t) nfast += takes_fast(a.t[t]) ? 1 : 0;
+        for (int t = 0; t < a.ntargets; ++t) a.t[t].refseq = (nfast > 0 && a.t[t].igr == 0 && !takes_fast(a.t[t])) ? 1 : 0;
+        a.fast = nfast > 0 ? 1 : 0;
+        part[nparts++] = a;
+    }
+    const bool side_by_side = nparts == 2 && e->aux2 != nullptr;
+    int32_t *gcounts = nullptr, *glists = nullptr;
+    if (part[0].fast) {
+        if ((rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
+        for (int t = 0; t < part[0].ntargets; ++t)
+            if (part[0].t[t].igr == 0) {
+                part[0].t[t].gcount = gcounts + t;
+                part[0].t[t].glist = glists + (size_t)t * (size_t)(B + 4);
+            }
+    }
+    ev_begin(e, 0, st);
+    if (side_by_side) {
+        HIPCHK(e, hipEventRecord(e->ev_fork2, st));
+        HIPCHK(e, hipStreamWaitEvent(e->aux2, e->ev_fork2, 0));
+    }
+    unsigned started_by = 0;
+    for (int p = 0; p < nparts; ++p) {
+        SwdMultiArgs &ap = part[p];
+        if (p > 0) {
+            ap.stamp = (++e->swd_stamp) & 0xffffu;
+            if (ap.stamp == 0) ap.stamp = (++e->swd_stamp) & 0xffffu;
+        }
+        hipStream_t sp = (p == 1 && side_by_side) ? e->aux2 : st;
+        const bool pair_ok = use_pair && nparts == 1;
+        const int lrc = bh_launch_swd_group(ap, G, sp, &e->last_swd, e->swd_wpb_now, pair_ok ? &e->pairwork : nullptr);
+        e->last_swd_wpb = e->swd_wpb_now;
+        if (lrc != 0) {
+            ev_end(e, 0, st);
+            return fail(e, BH_EINVAL, "model too deep for LDS");
+        }
         // (the counter a second stream waits on moves only once the launch is known to have been accepted: a failed launch
         // never increments the device word, and every later wait for the advanced value would hang -- ADVICE r03)
         const hipError_t le = hipGetLastError();
@@ -551,11 +592,17 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             ev_end(e, 0, st);
             return fail(e, BH_EHIP, "dispersion kernel launch", le);
         }
-        if (e->started) e->started_expected += e->last_swd.workgroups;
+        started_by += e->last_swd.workgroups;
     }
-    if (any_fast && (rc = launch_swd_rerun(e, st, a, gcounts, glists))) {
+    if (e->started) e->started_expected += started_by;
+    e->last_swd.workgroups = started_by;
+    if (part[0].fast && (rc = launch_swd_rerun(e, st, part[0], gcounts, glists))) {
         ev_end(e, 0, st);
         return rc;
+    }
+    if (side_by_side) {
+        HIPCHK(e, hipEventRecord(e->ev_join2, e->aux2));
+        HIPCHK(e, hipStreamWaitEvent(st, e->ev_join2, 0));
     }
     ev_end(e, 0, st);
     return BH_OK;
@@ -685,8 +732,9 @@ int bh_engine_create(int device, bh_engine **out)
     }
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
-    if (const char *g = std::getenv("BH_SWD_SEARCH")) e->swd_search = (g[0] == 'f' || g[0] == '1') ? 1 : 0;
-    if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == 'p' || g[0] == '0') ? 0 : 1;
+    if (const char *g = std::getenv("BH_SWD_SEARCH"))
+        e->swd_search = (g[0] == 'f' || g[0] == '1') ? ((std::strstr(g, "rayleigh") != nullptr) ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (g[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : 0);
+    if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == '0') ? BH_SCAN_STEPS : ((g[0] == 'c' || g[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
         e->love_inlook = std::atoi(g);
         if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
@@ -717,8 +765,8 @@ int bh_engine_set_model_order(bh_engine *e, int sort_by_depth)
 int bh_engine_set_swd_search(bh_engine *e, int search)
 {
     if (!e) return BH_EINVAL;
-    if (search != BH_SEARCH_REFERENCE && search != BH_SEARCH_FAST)
-        return fail(e, BH_EINVAL, "search must be BH_SEARCH_REFERENCE (0) or BH_SEARCH_FAST (1)");
+    if (search != BH_SEARCH_REFERENCE && search != BH_SEARCH_FAST && search != BH_SEARCH_FAST_RAYLEIGH)
+        return fail(e, BH_EINVAL, "search must be BH_SEARCH_REFERENCE (0), BH_SEARCH_FAST (1) or BH_SEARCH_FAST_RAYLEIGH (2)");
     e->swd_search = search;
     return BH_OK;
 }
@@ -728,22 +776,26 @@ int bh_engine_get_swd_search(const bh_engine *e) { return e ? e->swd_search : 0;
 int bh_engine_set_swd_scan(bh_engine *e, int scan)
 {
     if (!e) return BH_EINVAL;
-    if (scan != BH_SCAN_STEPS && scan != BH_SCAN_COUNTED) return fail(e, BH_EINVAL, "scan must be BH_SCAN_STEPS or BH_SCAN_COUNTED");
+    if (scan != BH_SCAN_STEPS && scan != BH_SCAN_COUNTED && scan != BH_SCAN_AUTO) return fail(e, BH_EINVAL, "scan must be BH_SCAN_STEPS, BH_SCAN_COUNTED or BH_SCAN_AUTO");
     e->swd_scan = scan;
     return BH_OK;
 }
 int bh_engine_get_swd_scan(const bh_engine *e) { return e ? e->swd_scan : 0; }
 
-int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches)
+int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches, uint64_t *total)
 {
     if (!e) return BH_EINVAL;
     if (rerun_launches) *rerun_launches = e->rerun_launches;
-    if (counts) {
-        for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = 0;
-        if (e->guard.p) {
+    if (counts || total) {
+        int32_t w[2 * BH_MAX_TARGETS] = {0};
+        if (e->guard.p && !e->guard_fresh) {
             HIPCHK(e, hipStreamSynchronize(e->stream));
-            HIPCHK(e, hipMemcpy(counts, e->guard.p, BH_MAX_TARGETS * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(w, e->guard.p, sizeof(w), hipMemcpyDeviceToHost));
         }
+        if (counts)
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = w[t];
+        if (total)
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)w[BH_MAX_TARGETS + t];
     }
     return BH_OK;
 }

@@ -556,6 +556,8 @@ struct SearchT {
     // (per-lane flags share ONE register: a `bool` member lives as a 64-bit lane mask in a scalar register pair, and this
     //  kernel has none to spare -- six more of them cost the round loop 30 spilled SGPRs)
     enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u };
+    // (F_GUARD_ON doubles as "this search takes the short refinement": in a build with both sequences (FASTM = 1) a phase-velocity
+    //  target can be told to keep the reference's -- init(.., refseq) --, e.g. the Love targets under BH_SEARCH_FAST_RAYLEIGH)
     unsigned flg = 0u;
     __device__ __forceinline__ bool has(unsigned f) const { return (flg & f) != 0u; }
     __device__ __forceinline__ void put(unsigned f, bool v) { flg = v ? (flg | f) : (flg & ~f); }
@@ -644,7 +646,7 @@ struct SearchT {
     template <class MD>
     __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
                          double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
-                         double *cper_ = nullptr, double *cbper_ = nullptr, int ifunc = 2, bool counted = false)
+                         double *cper_ = nullptr, double *cbper_ = nullptr, int ifunc = 2, bool counted = false, bool refseq = false)
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
@@ -709,7 +711,7 @@ struct SearchT {
         flg &= ~(F_CNT_OK | F_JUMP_READY);
         iprev = iprevb = 0;
         vlim = fmin(md.Bv(mmax - 1), betmxd);
-        put(F_GUARD_ON, FAST && (PHASE_ONLY || !group));
+        put(F_GUARD_ON, FAST && (PHASE_ONLY || (!group && !refseq)));
         flg &= ~F_GUARD;
         vh0 = md.Bv(mmax - 1);                          // half-space S velocity
         vh1 = (ifunc == 2) ? md.A(mmax - 1) : betmxd;   // half-space P velocity (Rayleigh: it enters |k - k_alpha| there)
@@ -867,7 +869,7 @@ struct SearchT {
             if (!NOGROUP && root == 1) iprevb = isteps;
             else iprev = isteps;
         }
-        if (FAST && (PHASE_ONLY || !group)) {
+        if (FAST && (PHASE_ONLY || has(F_GUARD_ON))) {
             cell_lo = fmin(c1, c2);
             cell_hi = fmax(c1, c2);
             put(F_FLO_NEG, signs_differ((c1 < c2) ? del1 : del2, 0.0));

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
     S.XS = MPW;
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, T.refseq != 0);
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
@@ -660,7 +660,10 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     if (board != nullptr) *reinterpret_cast<volatile unsigned *>(board + hw_slot) = (A.stamp << 16) | 0xffffu;
     if (valid && li == 0 && rr == 0 && !spare) {
         T.err[ib] = S.errflag;
-        if (FAST && S.has(S.F_GUARD) && T.gcount != nullptr) T.glist[atomicAdd(T.gcount, 1)] = ib; // to be run again with the reference's sequence
+        if (FAST && S.has(S.F_GUARD) && T.gcount != nullptr) { // to be run again with the reference's sequence
+            T.glist[atomicAdd(T.gcount, 1)] = ib;
+            atomicAdd(T.gcount + BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
+        }
     }
     if (prof) {
         unsigned long long tot = (li == 0 && rr == 0 && !spare) ? S.evals : 0u;
@@ -949,13 +952,14 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // build: 0 = reference sequence; with the short refinement asked for: 2 = no group-velocity target in the launch (nevill
     // not compiled in), 1 = mixed (group-velocity targets keep the reference sequence), 0 = group-velocity targets only.
     // simple: fundamental-mode phase velocities only (builds 0 and 2; no second root, no mode loop in the kernel).
-    bool any_phase = false, any_group = false, any_modes = false;
+    bool any_phase = false, any_group = false, any_modes = false, any_refseq = false;
     for (int t = 0; t < a.ntargets; ++t) {
-        any_phase = any_phase || a.t[t].igr == 0;
+        any_phase = any_phase || (a.t[t].igr == 0 && !a.t[t].refseq);
         any_group = any_group || a.t[t].igr != 0;
+        any_refseq = any_refseq || (a.t[t].igr == 0 && a.t[t].refseq);
         any_modes = any_modes || a.t[t].mode > 1;
     }
-    const int build = (a.fast && any_phase) ? (any_group ? 1 : 2) : 0;
+    const int build = (a.fast && any_phase) ? ((any_group || any_refseq) ? 1 : 2) : 0;
     static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
     const bool simple = !any_group && !any_modes && !no_simple;
     a.fast = build;
@@ -968,8 +972,11 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         any_love = any_love || a.t[t].iwave == 1;
         all_love = all_love && a.t[t].iwave == 1;
     }
-    static const bool cnt_always = std::getenv("BH_SWD_SCAN_ALWAYS") != nullptr; // experiment switch
-    const bool cntb = a.counted != 0 && any_love && wpb == GROUP_WPB && (adapt || all_love || cnt_always);
+    // a.counted: 1 = wherever a Love target is (BH_SCAN_COUNTED), 2 = where it pays (BH_SCAN_AUTO): launches of Love targets only
+    // with several models per wavefront (B = 4096: 2.06 -> 1.71 ms).  One model per wavefront (the trial lanes already walk
+    // the scan seven steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches (the Rayleigh
+    // wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
+    const bool cntb = any_love && wpb == GROUP_WPB && (build != 1 || !adapt) && (a.counted == 1 || (a.counted == 2 && all_love && !adapt && build != 1));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
@@ -991,6 +998,9 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     } else if (adapt && build == 2) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
         else BH_GROUP_LAUNCH_ADAPT(2, false);
+    } else if (adapt && build == 1) { // (both sequences in one launch: Rayleigh targets short, Love targets the reference's)
+        if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
+        else BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, false, true, false);
     } else if (adapt) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(0, true);
         else BH_GROUP_LAUNCH_ADAPT(0, false);

@@ -191,7 +191,10 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
     }
     if (valid && r == 0) {
         A.err[ib] = S.errflag;
-        if (FAST != 0 && S.has(S.F_GUARD) && A.gcount != nullptr) A.glist[atomicAdd(A.gcount, 1)] = ib; // to be run again with the reference's sequence
+        if (FAST != 0 && S.has(S.F_GUARD) && A.gcount != nullptr) { // to be run again with the reference's sequence
+            A.glist[atomicAdd(A.gcount, 1)] = ib;
+            atomicAdd(A.gcount + BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
+        }
     }
     if (A.neval != nullptr) {
         // [0] secular evaluations; per wave type ([8] Rayleigh / [9] Love) evaluations and ([10] / [11]) layer-

@@ -25,8 +25,8 @@ VEL_PHASE, VEL_GROUP = 0, 1
 RF_P, RF_SV = 0, 1
 LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
 TARGET_SWD, TARGET_RF, TARGET_USER = 0, 1, 2
-SEARCH_REFERENCE, SEARCH_FAST = 0, 1  # bh_engine_set_swd_search
-SCAN_STEPS, SCAN_COUNTED = 0, 1        # bh_engine_set_swd_scan
+SEARCH_REFERENCE, SEARCH_FAST, SEARCH_FAST_RAYLEIGH = 0, 1, 2  # bh_engine_set_swd_search
+SCAN_STEPS, SCAN_COUNTED, SCAN_AUTO = 0, 1, 2  # bh_engine_set_swd_scan
 MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
 
 _d = C.POINTER(C.c_double)
@@ -110,7 +110,7 @@ def load_library():
     L.bh_engine_get_swd_search.argtypes = [vp]
     L.bh_engine_set_swd_scan.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_scan.argtypes = [vp]
-    L.bh_engine_guard_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    L.bh_engine_guard_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
     L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
     L.bh_timing_reset.argtypes = [vp]
@@ -234,34 +234,50 @@ class Engine(object):
     def set_swd_search(self, search):
         """"reference" (default): the reference's sequence of secular-function evaluations, velocities bit-identical to
         surfdisp96.  "fast": the same brackets, ~3 evaluations inside each instead of nevill's 10-12; phase-velocity
-        targets only; within 1.2e-6 relative of the reference (include/bh_engine.h: bh_engine_set_swd_search)."""
-        code = {"reference": SEARCH_REFERENCE, "fast": SEARCH_FAST, SEARCH_REFERENCE: SEARCH_REFERENCE, SEARCH_FAST: SEARCH_FAST}.get(search)
+        targets only; within 1.2e-6 relative of the reference, failure flags the reference's (a guard re-runs the models
+        whose outcome hinges on the last bits of a root with the reference's sequence).  "fast_rayleigh": the same for the
+        Rayleigh targets only -- for samplers, whose Love proposals trip the guard too often (include/bh_engine.h)."""
+        codes = {"reference": SEARCH_REFERENCE, "fast": SEARCH_FAST, "fast_rayleigh": SEARCH_FAST_RAYLEIGH}
+        codes.update({v: v for v in list(codes.values())})
+        code = codes.get(search)
         if code is None:
-            raise ValueError("search must be 'reference' or 'fast'")
+            raise ValueError("search must be 'reference', 'fast' or 'fast_rayleigh'")
         self._check(self._L.bh_engine_set_swd_search(self._h, code))
 
     def swd_search(self):
-        return "fast" if self._L.bh_engine_get_swd_search(self._h) == SEARCH_FAST else "reference"
+        return {SEARCH_FAST: "fast", SEARCH_FAST_RAYLEIGH: "fast_rayleigh"}.get(self._L.bh_engine_get_swd_search(self._h), "reference")
 
     def set_swd_scan(self, scan):
-        """"counted" (default): Love bracket scans skip the steps a mode count proves to be without a sign change -- same
-        brackets, same bits, a third of the scan's evaluations; "steps": every step evaluated, as the reference does
-        (include/bh_engine.h: bh_engine_set_swd_scan)."""
-        code = {"steps": SCAN_STEPS, "counted": SCAN_COUNTED, SCAN_STEPS: SCAN_STEPS, SCAN_COUNTED: SCAN_COUNTED}.get(scan)
+        """Love bracket scans: "counted" = skip the steps a mode count proves to be without a sign change (same brackets, same
+        bits, a third of the scan's evaluations) wherever a Love target is; "auto" (default) = only where that is measured
+        to pay; "steps" = every step evaluated, as the reference does (include/bh_engine.h: bh_engine_set_swd_scan)."""
+        codes = {"steps": SCAN_STEPS, "counted": SCAN_COUNTED, "auto": SCAN_AUTO}
+        codes.update({v: v for v in list(codes.values())})
+        code = codes.get(scan)
         if code is None:
-            raise ValueError("scan must be 'steps' or 'counted'")
+            raise ValueError("scan must be 'steps', 'counted' or 'auto'")
         self._check(self._L.bh_engine_set_swd_scan(self._h, code))
 
     def swd_scan(self):
-        return "counted" if self._L.bh_engine_get_swd_scan(self._h) == SCAN_COUNTED else "steps"
+        return {SCAN_STEPS: "steps", SCAN_COUNTED: "counted"}.get(self._L.bh_engine_get_swd_scan(self._h), "auto")
 
     def guard_stats(self):
         """(models per target of the last dispersion call that the guard of the "fast" search re-ran with the reference's
         sequence, re-run launches enqueued since the engine was created)"""
         counts = (C.c_int32 * 8)()
         n = C.c_uint64(0)
-        self._check(self._L.bh_engine_guard_stats(self._h, counts, C.byref(n)))
+        self._check(self._L.bh_engine_guard_stats(self._h, counts, C.byref(n), None))
         return list(counts), int(n.value)
+
+    def guard_total(self):
+        """guarded (model, target) pairs since the engine was created"""
+        return sum(self.guard_totals())
+
+    def guard_totals(self):
+        """the same per dispersion target of the calls (in the order the targets were registered)"""
+        tot = (C.c_uint64 * 8)()
+        self._check(self._L.bh_engine_guard_stats(self._h, None, None, tot))
+        return [int(x) for x in tot]
 
     def timing_reset(self):
         self._check(self._L.bh_timing_reset(self._h))

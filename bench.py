@@ -258,11 +258,15 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
     eng.timing_reset()
     fence()
     launches0 = dc.launches
+    iter0 = dc.iiter               # (a speculative window may have carried the burn-in past iteration 0: count what is timed)
+    guard0 = np.array(eng.guard_totals()) if eng.swd_search() != "reference" else np.zeros(8, dtype=np.int64)
     t0 = time.perf_counter()
     while dc.iiter < dc.iter_phase2:
         dc.iterate()
     fence()
     elapsed = time.perf_counter() - t0
+    timed_iters = dc.iiter - iter0
+    guard1 = np.array(eng.guard_totals()) if eng.swd_search() != "reference" else np.zeros(8, dtype=np.int64)
     ncalls, tot_ms, fam_ms = eng.timing_collect()
     eng.set_instrumentation(timing=False, counting=False)
     eng.set_typical_layers(0)      # (the engine is shared with the evaluate workloads that follow)
@@ -275,16 +279,21 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
         return None
     st = dc.state_host()
     launches = dc.launches - launches0
-    return {"metric": "forward-model+logL evals/sec consumed by the chains = chain-iterations/s (device-resident transdimensional chains)",
-            "value": world * C * steps / elapsed, "unit": "chain-iterations/s", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+    return {"metric": "chain-iterations/s (device-resident transdimensional chains)",
+            "value": world * C * timed_iters / elapsed, "unit": "chain-iterations/s", "n_gpus": world, "steps": steps,
+            "timed_iterations_per_chain": int(timed_iters),
+            "warmup": warmup, "ms_per_step": elapsed / max(1, timed_iters) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": {"c4": "BASELINE configs[3]: independent chains sharded per GPU, joint Rayleigh+Love+P-RF, up to 20 layers",
                                     "c5": "BASELINE configs[4]: parallel tempering, one temperature of an 8-rung ladder per rank, exchange "
                                           "every 100 iterations, joint Rayleigh+Love+P-RF, up to 20 layers"}[workload],
                        "chains_per_gpu": C, "mean_layers_at_end": float(st["n"].mean()), "accepted_swaps": nswaps,
                        "parallelism": "chains sharded per GPU; c5: one small all-gather per exchange"},
-            "speculation": {"depth": dc.depth, "evaluation_launches": launches, "iterations_per_launch": steps / max(1, launches),
+            "search": {"mode": eng.swd_search(), "scan": eng.swd_scan(),
+                       "models_rerun_by_the_guard": int((guard1 - guard0).sum()),
+                       "models_rerun_by_target": [int(x) for x in (guard1 - guard0)[:2]],
+                       "dispersion_models_evaluated": int(launches * C * ((1 << dc.depth) - 1) * 2)},
+            "speculation": {"depth": dc.depth, "evaluation_launches": launches, "iterations_per_launch": timed_iters / max(1, launches),
                             "models_evaluated_per_launch": C * ((1 << dc.depth) - 1), "ms_per_launch": elapsed / max(1, launches) * 1e3,
                             "note": "the proposals of both outcomes of the next `depth` accept/reject decisions are evaluated in one "
                                     "launch and the realised path replayed: bit-identical to depth 1 (tests/test_gpu_device_chains.py)"},
@@ -572,7 +581,7 @@ def main():
     ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
                     "--workload c4/c5, 600 inside --workload all)")
     ap.add_argument("--spec-depth", type=int, default=0, help="c4/c5: iterations per evaluation launch (0 = automatic)")
-    ap.add_argument("--search", default="reference", choices=["reference", "fast"],
+    ap.add_argument("--search", default="reference", choices=["reference", "fast", "fast_rayleigh"],
                     help="root refinement of the dispersion search: the reference's sequence (bit-identical velocities, the default "
                          "and what `value` is measured with) or the engine's short one (bh_engine_set_swd_search: within 1.2e-6 relative)")
     ap.add_argument("--batch", type=int, default=4096)

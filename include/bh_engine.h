@@ -101,29 +101,42 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  * Also BH_SWD_SEARCH=fast in the environment at engine creation. */
 #define BH_SEARCH_REFERENCE 0
 #define BH_SEARCH_FAST 1
+/* BH_SEARCH_FAST for the Rayleigh phase-velocity targets only; Love targets keep the reference's sequence (with the counted
+ * scan).  For launches of one model per wavefront -- a sampler's windows, single models --, where ONE guarded model costs the
+ * call a second launch as long as a whole root search: the guard fires on ~2 % of a transdimensional sampler's Love proposals
+ * (periods out to 60 s over models a few layers deep: the Love root creeps up to the half-space velocity) and on < 1e-5 of
+ * its Rayleigh proposals (bench.py c4 / c5).  Rayleigh and Love targets of a call then run as two launches side by side. */
+#define BH_SEARCH_FAST_RAYLEIGH 2
 int bh_engine_set_swd_search(bh_engine *e, int search);
 int bh_engine_get_swd_search(const bh_engine *e);
-/* The bracket scan of Love targets (both search modes).
- *   BH_SCAN_COUNTED (default): getsol's scan (surfdisp96.f:437-460) looks for the first step of its grid c1 + i dc over which
- *     the secular function changes sign, one evaluation per step.  For Love waves the number of sign changes below a trial
- *     velocity can be read off the very recursion that evaluates the function (Sturm's oscillation theorem for the SH
- *     problem: zeros of the displacement in the layers, csrc/swd_common.h LoveCount), so two evaluations certify that none
- *     of the steps between them shows a sign change -- they are skipped -- or that exactly one does -- it is located by a
- *     search over the step index.  The grid points are the reference's (repeated additions of dc), the bracket handed to
- *     the refinement is the reference's, hence every bit of the result: same velocities, same failure flags, about a third
- *     of the scan's evaluations (c2 Love: 927 -> 470 evaluations per model; with BH_SEARCH_FAST 673 -> 216).
- *   BH_SCAN_STEPS: every step evaluated, as the reference does (measurements; the evaluation counts of the oracle's
- *     restatement of the reference).
- * Rayleigh targets always take BH_SCAN_STEPS (no such count for the P-SV problem here).  Also BH_SWD_SCAN=steps|counted in
- * the environment at engine creation. */
+/* The bracket scan of Love targets (all search modes).
+ *   getsol's scan (surfdisp96.f:437-460) looks for the first step of its grid c1 + i dc over which the secular function
+ *   changes sign, one evaluation per step.  For Love waves the number of sign changes below a trial velocity can be read
+ *   off the very recursion that evaluates the function (Sturm's oscillation theorem for the SH problem: zeros of the
+ *   displacement in the layers, csrc/swd_common.h LoveCount), so two evaluations certify that none of the steps between
+ *   them shows a sign change -- they are skipped -- or that exactly one does -- it is located by a search over the step
+ *   index.  The grid points are the reference's (repeated additions of dc), the bracket handed to the refinement is the
+ *   reference's, hence every bit of the result: same velocities, same failure flags, a third of the scan's evaluations
+ *   (c2 Love: 927 -> 470 evaluations per model; with BH_SEARCH_FAST 673 -> 216).
+ *   BH_SCAN_STEPS: every step evaluated, as the reference does.
+ *   BH_SCAN_COUNTED: the counted scan wherever a launch holds a Love target (and the build exists: not in the one-model-per-
+ *     wavefront launch that mixes both refinements, BH_SEARCH_FAST_RAYLEIGH).
+ *   BH_SCAN_AUTO (default): the counted scan where it is measured to pay -- launches of Love targets only with several models
+ *     per wavefront (4096 models: 2.06 -> 1.71 ms), and the lane-per-model kernels.  Where Rayleigh wavefronts set the time
+ *     anyway, or the trial lanes already walk the scan seven steps a round, its state machine costs what it saves.
+ * Results never depend on it.  Rayleigh targets always step (no such count for the P-SV problem here).  Also
+ * BH_SWD_SCAN=steps|counted|auto in the environment at engine creation. */
 #define BH_SCAN_STEPS 0
 #define BH_SCAN_COUNTED 1
+#define BH_SCAN_AUTO 2
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
  * dispersion call that its guard sent back to the reference's sequence; *rerun_launches (may be NULL) = re-run launches
- * enqueued since the engine was created.  Synchronises the engine's stream when counts != NULL. */
-int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches);
+ * enqueued since the engine was created; total[t] (BH_MAX_TARGETS entries; may be NULL) = guarded models of the t-th dispersion
+ * target of the calls since the engine was created.
+ * Synchronises the engine's stream when counts or total is given. */
+int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches, uint64_t *total);
 /* Tuning hint for BH_DEVICE calls: the typical number of layers (incl. the half-space) of the models in
  * the batches to come, when it is well below Lmax (transdimensional chains: capacity 21, typically 5-7).
  * The lanes-per-model choice is sized for it; 0 = unknown (Lmax is used).  BH_HOST calls look at nlay

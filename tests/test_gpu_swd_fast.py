@@ -23,11 +23,15 @@ ACHIEVED = 1.2e-6
 
 @pytest.fixture()
 def fast(engine):
+    """the short refinement; the counted scan wherever a Love target is, as the oracle's restatement has it (evaluation
+    counts are compared; velocities and flags do not depend on the scan setting)"""
     engine.set_swd_search("fast")
+    engine.set_swd_scan("counted")
     try:
         yield engine
     finally:
         engine.set_swd_search("reference")
+        engine.set_swd_scan("auto")
 
 
 class restatement:
@@ -112,7 +116,7 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
     nlay, h, vp, vs, rho = synth_models(rs, 3000, 14, lvz_frac=0.3, ragged=True)
     per = np.linspace(1.5, 70, 35)
     a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
-    assert engine.swd_scan() == "counted"
+    assert engine.swd_scan() == "auto"
     engine.set_instrumentation(False, True)
     try:
         for iwave, igr, mode, flsph in ((1, 0, 1, 0), (1, 1, 2, 0), (1, 0, 3, 1), (2, 0, 1, 0)):
@@ -129,7 +133,7 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
             assert np.array_equal(cv, ov) and np.array_equal(ce, oe)
             assert (n1 < 0.8 * n0) if iwave == 1 else (n1 == n0)
     finally:
-        engine.set_swd_scan("counted")
+        engine.set_swd_scan("auto")
         engine.set_instrumentation(False, False)
 
 
@@ -271,6 +275,41 @@ def test_speculative_chain_windows_stay_exact_with_the_short_refinement(fast):
     fast.set_swd_search("fast")
     assert not np.array_equal(r1["like"], s1["like"])
     assert abs(np.median(r1["like"]) - np.median(s1["like"])) < 0.2 * abs(np.median(r1["like"])) + 50.0
+
+
+def test_fast_rayleigh_keeps_the_reference_sequence_for_love_targets(engine, oracle):
+    """BH_SEARCH_FAST_RAYLEIGH: in ONE launch (the build with both sequences) the Rayleigh phase target takes the guarded
+    short refinement -- the bits of its restatement --, the Love phase target and the group-velocity target the reference's
+    sequence -- the reference's bits; for several models per wavefront and for one model per wavefront."""
+    from bayhunter_amd import engine as E
+    per = np.linspace(2, 60, 30)
+    rs = np.random.RandomState(41)
+    try:
+        engine.set_swd_search("fast_rayleigh")
+        assert engine.swd_search() == "fast_rayleigh"
+        for B in (300, 3000):
+            nlay, h, vp, vs, rho = synth_models(rs, B, 12, lvz_frac=0.25, ragged=True)
+            a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+            yobs = 3.4 + 0.01 * per
+            engine.set_targets([dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=2, igr=0),
+                                dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=1, igr=0),
+                                dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=2, igr=1)])
+            noise = np.tile([0, 0.05] * 3, (B, 1))
+            logL, misf, err, ymod = engine.evaluate_batch(nlay, h, vp, vs, noise, want_ymod=True)
+            with restatement(oracle):
+                rv, re_, _ = oracle.swd_batch(nlay, *a, per, 2, 0)
+            lv, le, _ = oracle.swd_batch(nlay, *a, per, 1, 0)
+            gv, ge, _ = oracle.swd_batch(nlay, *a, per, 2, 1)
+            ok = (re_ == 0) & (le == 0) & (ge == 0)
+            assert np.array_equal(err == 0, ok)
+            assert np.array_equal(ymod[ok, :30], rv[ok]) and np.array_equal(ymod[ok, 30:60], lv[ok]) and np.array_equal(ymod[ok, 60:], gv[ok])
+            # and target by target (a Love-only call takes the reference build, a Rayleigh-only call the short one)
+            v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, 1, 0)
+            assert np.array_equal(v, lv) and np.array_equal(e, le)
+            v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, 2, 0)
+            assert np.array_equal(v, rv) and np.array_equal(e, re_)
+    finally:
+        engine.set_swd_search("reference")
 
 
 def test_the_switch_is_per_engine_and_validated(engine):
