@@ -60,7 +60,7 @@ def auto_spec_depth(nchains, budget=None):
 
 class DeviceChains(object):
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None):
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast_rayleigh"):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
         torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
         (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
@@ -76,7 +76,14 @@ class DeviceChains(object):
         device: CUDA device index; default = the engine's (`JointTarget(..., engine=)`), else 0.
         spec_depth: iterations per evaluation launch (speculative window, 1..7; module docstring).  None = chosen
         from the number of chains so that a launch stays in the latency regime (`auto_spec_depth`); 1 = one
-        iteration per launch.  Results do not depend on it."""
+        iteration per launch.  Results do not depend on it.
+        search: root refinement of the dispersion search in the chains' evaluation launches (Engine.set_swd_search;
+        applied around every launch, the engine's own setting is left as it was).  Default "fast_rayleigh": Rayleigh
+        phase velocities within 1.2e-6 relative of the reference's, the reference's failure flags, Love and group
+        velocities the reference's bits -- what the chains sample does not change
+        (tests/test_gpu_device_chains.py::test_search_modes_sample_the_same_posterior), a window takes 13-22 % less.
+        "reference": the reference's bits throughout (what `ChainBatch`, the replay of recorded reference runs, uses);
+        None: whatever the engine is set to."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
@@ -84,6 +91,9 @@ class DeviceChains(object):
             from .engine import default_engine
             self.targets._engine = default_engine(int(device))   # kernels and tensors on the same GPU
         self.engine = self.targets.engine
+        if search not in (None, "reference", "fast", "fast_rayleigh"):
+            raise ValueError("search must be None, 'reference', 'fast' or 'fast_rayleigh'")
+        self.search = search
         if device is None:
             device = self.engine.device
         if int(device) != int(self.engine.device):
@@ -196,6 +206,7 @@ class DeviceChains(object):
             setattr(st, k[0], None if v is None else v.data_ptr())
         self.state = st
         torch.cuda.synchronize(dev)
+        self._ext_stream = torch.cuda.ExternalStream(int(self.engine.stream), device=dev)   # the engine's stream, for torch work
         # replica exchange on the device (one rank, or RCCL): the ladder of every chain of the job is static
         if betas is not None and self.swap_every > 0:
             on_gpu = dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or dist.get_backend() == "nccl"
@@ -204,7 +215,6 @@ class DeviceChains(object):
                 ladder_all = gather_chain_axis(self.ladder, 0, dist, int(device))
                 start = int(sum(self.rank_counts[:self.rank]))         # position of this rank's block in gather order
                 mine = slice(start, start + Cn)
-                self._ext_stream = torch.cuda.ExternalStream(int(self.engine.stream), device=dev)
                 self._dev_exchange = DeviceExchange(ladder_all, self.seed, mine, dev, self.rank_counts)
         self.snap = {"p1": [], "p2": []}
 
@@ -231,17 +241,24 @@ class DeviceChains(object):
         # also does it at every snapshot).  The engine uses it for batches of more than a wavefront's worth of models per
         # SIMD pair (many chains); a window of ~1000 models gets one wavefront per model whatever its depth.
         if self.launches % self.HINT_EVERY == 0:
-            self._hint = int(self.torch.ceil(t["n"].double().mean()).item())
+            # (read on the ENGINE's stream: the accept kernels that write t["n"] run there, not on torch's current stream)
+            with self.torch.cuda.stream(self._ext_stream):
+                self._hint = int(self.torch.ceil(t["n"].double().mean()).item())
         w = self.window()
         B = Cn * ((1 << w) - 1)
         e.chain_propose_window(self.cfg, self.state, Cn, self.iiter, w, self.ld)
         e.set_typical_layers(self._hint)       # (for this call only: the engine is shared with other callers)
+        prev = e.swd_search() if self.search is not None else None
+        if prev is not None and prev != self.search:
+            e.set_swd_search(self.search)
         try:
             e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
                                  t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
                                  self.mis.data_ptr(), self.err.data_ptr())
         finally:
             e.set_typical_layers(0)
+            if prev is not None and prev != self.search:
+                e.set_swd_search(prev)
         e.chain_accept_window(self.cfg, self.state, Cn, self.iiter, w, self.ld, self.logL.data_ptr(), self.mis.data_ptr())
         self.iiter += w
         self.launches += 1

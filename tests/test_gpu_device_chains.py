@@ -65,7 +65,7 @@ def test_injected_draws_same_trajectory(name, depth):
     priors = dict(su["priors"], mantle=(4.3, 1.8))
     C = 48
     targets = make_targets(g)
-    dc = DeviceChains(targets, C, init, priors, seed=7, inject=True, spec_depth=depth)
+    dc = DeviceChains(targets, C, init, priors, seed=7, inject=True, spec_depth=depth, search="reference")   # (the host twin's bits)
     hb = host_twin(dc, targets, init, priors)
     rs = np.random.RandomState(99)
     it = 0
@@ -307,6 +307,46 @@ def test_posterior_statistics_match_reference_order_chains():
     sem = np.sqrt(H.var(axis=0, ddof=1) / N + D.var(axis=0, ddof=1) / N)
     z = (D.mean(axis=0) - H.mean(axis=0)) / sem
     assert np.all(np.abs(z) < 4.5), z
+
+
+def test_search_modes_sample_the_same_posterior():
+    """The chains' default search ("fast_rayleigh": Rayleigh roots within 1.2e-6 of the reference's instead of its bits) does
+    not change what they sample: the same problem sampled by 768 device chains with the reference's sequence and by 768
+    others (other seeds) with the default; posterior summaries -- logL, number of nuclei, vp/vs, the three free noise
+    parameters, vs at five depths -- agree within Monte-Carlo error (pairs of runs of ONE mode scatter up to 2.6 standard
+    errors, profiles/r03_chains_stat_search.txt; the pooled difference there was 1.7)."""
+    g = golden("chain_golden.npz")
+    N, burn, main = 256, 4000, 2000
+    priors = dict(vpvs=(1.4, 2.1), layers=(1, 10), vs=(2, 5), z=(0, 60), rfnoise_corr=(0.35, 0.75), rfnoise_sigma=(1e-5, 0.05),
+                  swdnoise_corr=0., swdnoise_sigma=(1e-5, 0.1))
+    init = dict(nchains=1, iter_burnin=burn, iter_main=main, acceptance=(40, 45), thickmin=0.1, lvz=0.1, hvz=None, rcond=None,
+                maxmodels=main // 20)
+
+    def targets():
+        t1 = bh.RayleighDispersionPhase(g["xsw"], g["ysw"])
+        t2 = bh.PReceiverFunction(g["xrf"], g["yrf"])
+        t2.moddata.plugin.set_modelparams(gauss=1.0, p=6.4)
+        return bh.JointTarget([t1, t2])
+
+    def summaries(models, likes, noise, vpvs):
+        n = np.array([bh.Model.split_modelparams(m)[0] for m in models])
+        depths = np.array([2.0, 10.0, 25.0, 40.0, 55.0])
+        v = np.zeros((models.shape[0], depths.size))
+        for i, m in enumerate(models):
+            _, vs, z = bh.Model.split_modelparams(m)
+            v[i] = vs[np.argmin(np.abs(z[:, None] - depths[None, :]), axis=0)]
+        return np.concatenate(([likes.mean(), n.mean(), vpvs.mean(), noise[:, 1].mean(), noise[:, 2].mean(), noise[:, 3].mean()],
+                               v.mean(axis=0)))
+
+    out = {"reference": [], "fast_rayleigh": []}
+    for search, seeds in (("reference", (77, 79, 81)), ("fast_rayleigh", (83, 85, 87))):
+        for seed in seeds:
+            dc = DeviceChains(targets(), N, init, priors, seed=seed, search=search).run()
+            s = dc.samples("p2")
+            out[search] += [summaries(s["models"][:, c], s["likes"][:, c], s["noise"][:, c], s["vpvs"][:, c]) for c in range(N)]
+    R, F = np.array(out["reference"]), np.array(out["fast_rayleigh"])
+    z = (F.mean(axis=0) - R.mean(axis=0)) / np.sqrt(R.var(axis=0, ddof=1) / R.shape[0] + F.var(axis=0, ddof=1) / F.shape[0])
+    assert np.all(np.abs(z) < 4.0), z
 
 
 def test_baseline_config4_shape_tempered_transdimensional_ladder():

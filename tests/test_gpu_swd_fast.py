@@ -265,7 +265,7 @@ def test_speculative_chain_windows_stay_exact_with_the_short_refinement(fast):
     keys = ("n", "vs", "z", "like", "noise", "vpvs", "misfits", "propdist", "accepted")
 
     def run(depth):
-        return DeviceChains(make_targets(g), 8, init, su["priors"], seed=11, spec_depth=depth).run().state_host()
+        return DeviceChains(make_targets(g), 8, init, su["priors"], seed=11, spec_depth=depth, search=None).run().state_host()   # (the engine's setting)
 
     s1, s5 = run(1), run(5)
     for k in keys:

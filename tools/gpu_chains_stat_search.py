@@ -43,7 +43,7 @@ RUNS = tuple((m, int(s_)) for m, s_ in (x.split(":") for x in os.environ.get("RU
 for search, seed in RUNS:
     eng.set_swd_search(search)
     t0 = time.time()
-    dc = DeviceChains(targets(), N, init, priors, seed=seed).run()
+    dc = DeviceChains(targets(), N, init, priors, seed=seed, search=None).run()   # (the engine's setting, set above)
     s = dc.samples("p2")
     out[(search, seed)] = np.array([summaries(s["models"][:, c], s["likes"][:, c], s["noise"][:, c], s["vpvs"][:, c]) for c in range(N)])
     print("%-9s seed %d: %d chains, %d + %d iterations, %.0f s" % (search, seed, N, burn, main, time.time() - t0), flush=True)
