@@ -48,6 +48,21 @@ __device__ __forceinline__ bool bh_div_safe(double x)
     return (ex - 623u) <= 800u;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize applies per DEVICE: remember per device (bit d of *done) that a set of kernels
+// has been allowed `bytes` of dynamic LDS.  (A process-wide flag left the second GPU of a process without it: ADVICE r03.)
+#include <atomic>
+inline bool bh_allow_big_lds(std::atomic<unsigned long long> *done, const void *const *kernels, int nkernels, int bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    const unsigned long long bit = 1ull << dev;
+    if (done->load(std::memory_order_acquire) & bit) return true;
+    for (int k = 0; k < nkernels; ++k)
+        if (hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done->fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
 struct SwdKernelArgs {
     int B, Lmax, K, igr, mode;
     const int32_t *nlay;

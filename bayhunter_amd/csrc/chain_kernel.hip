@@ -627,11 +627,9 @@ int bh_chain_propose_window(void *stream, const bh_chain_config *cfg, const bh_c
         const size_t lds = (size_t)per_wg * ((1 << depth) - 1) * (node_rec_doubles(cfg->nt, cfg->maxlayers) | 1) * sizeof(double);
         if (lds > 160 * 1024) return BH_EUNSUPPORTED;
         if (lds > 64 * 1024) {
-            static bool big = false;
-            if (!big && hipFuncSetAttribute(reinterpret_cast<const void *>(chain_propose_window_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return BH_EHIP;
-            big = true;
+            static std::atomic<unsigned long long> big{0};
+            const void *k[1] = {reinterpret_cast<const void *>(chain_propose_window_kernel)};
+            if (!bh_allow_big_lds(&big, k, 1, 160 * 1024)) return BH_EHIP;
         }
         hipLaunchKernelGGL(chain_propose_window_kernel, dim3((C + per_wg - 1) / per_wg), dim3(64), lds, (hipStream_t)stream, *cfg,
                            *state, C, (size_t)ld, iiter, depth);

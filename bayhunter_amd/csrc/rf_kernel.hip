@@ -787,17 +787,10 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     if (lds > BH_RF_MAX_LDS) return -1;
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;
     if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit: a workgroup may take the CU's whole 160 KB
-        static size_t allowed = 0;
-        if (lds > allowed) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BH_RF_MAX_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel_w3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BH_RF_MAX_LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(rf_synth_kernel_beside), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)BH_RF_MAX_LDS) != hipSuccess)
-                return -1;
-            allowed = BH_RF_MAX_LDS;
-        }
+        static std::atomic<unsigned long long> allowed{0};
+        const void *k[3] = {reinterpret_cast<const void *>(rf_synth_kernel), reinterpret_cast<const void *>(rf_synth_kernel_w3),
+                            reinterpret_cast<const void *>(rf_synth_kernel_beside)};
+        if (!bh_allow_big_lds(&allowed, k, 3, (int)BH_RF_MAX_LDS)) return -1;
     }
     if (a.Lmax <= 16 && a.coef_small)
         hipLaunchKernelGGL((rf_coef_layers_kernel_small<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);

@@ -984,13 +984,11 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
     if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
-        static bool big_lds = false;
-        if (lds > WG_LDS_CAP && !big_lds) {
+        static std::atomic<unsigned long long> big_lds{0};
+        if (lds > WG_LDS_CAP) {
             const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false, false>),
                                  reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true, false, false>)};
-            for (const void *k : k4)
-                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-            big_lds = true;
+            if (!bh_allow_big_lds(&big_lds, k4, 3, 160 * 1024)) return -1;
         }
         if (build == 2) BH_GROUP_LAUNCH_(4, 2, false, true, false, false);
         else if (build == 1) BH_GROUP_LAUNCH_(4, 1, false, true, false, false);
