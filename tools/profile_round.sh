@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- the rocprofv3 evidence of one round, run ON THE GPU BOX:
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
+#   gpurun --timeout 3000 -- "BH_PROFILE_COMMIT=$(git rev-parse --short HEAD) bash tools/profile_round.sh r04"
 # Bench lines; kernel-trace statistics of c2 / c3 / the chain workloads / the receiver function alone (ONE batch
 # shape per pass) / the Gauss-law contraction / the B = 65536 throughput regime; and, in SEPARATE passes (never
 # together with a trace domain), the HBM counters (FETCH_SIZE / WRITE_SIZE) and the SQ activity counters of the c2, c3
@@ -30,9 +30,25 @@ python $R/bench.py --workload c2 --batch 512 --steps 20 --warmup 3 --no-cpu-base
 python $R/bench.py --workload c4 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c4_depth1.json" 2> "$OUT/bench_c4_depth1.err"
 python $R/bench.py --workload c5 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c5_depth1.json" 2> "$OUT/bench_c5_depth1.err"
 python $R/tools/gpu_latency.py > "$OUT/latency.txt" 2>&1
-# the optional short root refinement (bh_engine_set_swd_search): c2 line and single-model latency
+# the short root refinement (bh_engine_set_swd_search): c2 line, chains with every search mode, single-model latency
 python $R/bench.py --workload c2 --search fast --no-cpu-baseline > "$OUT/bench_c2_fast.json" 2> "$OUT/bench_c2_fast.err"
+for w in c4 c5; do for sm in reference fast_rayleigh fast; do
+  python $R/bench.py --workload $w --steps 600 --warmup 300 --search $sm > "$OUT/bench_${w}_$sm.json" 2> "$OUT/bench_${w}_$sm.err"
+done; done
 BH_SWD_SEARCH=fast python $R/tools/gpu_latency.py > "$OUT/latency_fast.txt" 2>&1
+# the counted Love scan (bh_engine_set_swd_scan): a launch of Love targets only, B = 4096, every step / counted; B = 65536
+{ echo "== Love only, B = 4096, scan auto (counted)"; TARGETS=L python $R/tools/gpu_trace.py 0 0 | head -6
+  echo "== Love only, B = 4096, scan steps"; BH_SWD_SCAN=steps TARGETS=L python $R/tools/gpu_trace.py 0 0 | head -6
+  echo "== Rayleigh + Love, B = 4096, scan counted everywhere"; BH_SWD_SCAN=counted python $R/tools/gpu_trace.py 0 0 | head -7
+  echo "== Rayleigh + Love, B = 4096, scan auto (= steps here)"; python $R/tools/gpu_trace.py 0 0 | head -7
+  for sc in auto steps; do for sm in reference fast; do
+    echo "== c2 at B = 65536, scan $sc, search $sm: $(BH_SWD_SCAN=$sc python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 --no-cpu-baseline --no-parity --search $sm 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), 'ms', round(d['value']), 'evals/s')")"
+  done; done; } > "$OUT/love_scan.txt" 2>&1
+# the dispersion kernel's phase clocks with and without the receiver function beside it (c3 against c2)
+python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3.txt" 2>&1
+# randomised parity sweeps (tools/gpu_fuzz.py): reference sequence; short refinement with its guard
+python $R/tools/gpu_fuzz.py 404 ${BH_FUZZ_REF:-3000} > "$OUT/fuzz_reference.txt" 2>&1
+FAST=1 python $R/tools/gpu_fuzz.py 405 ${BH_FUZZ_FAST:-8000} > "$OUT/fuzz_fast.txt" 2>&1
 for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
 for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
 fi
