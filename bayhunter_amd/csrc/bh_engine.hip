@@ -439,7 +439,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         int32_t *gcounts = nullptr, *glists = nullptr;
         bool any_fast = false;
         for (int j = 0; j < njobs; ++j)
-            any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0 &&
+            any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0 && jobs[j].mode <= 1 &&
                                     (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && jobs[j].iwave == BH_WAVE_RAYLEIGH)));
         if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
@@ -473,7 +473,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             // their own are left alone (a low-priority phase costs them 8 %: the CU's front end is shared)
             a.fair = lane_waves <= 1024 ? -1 : (lane_waves <= 2048 ? 18 : 12);
             a.nev_high = (double *)e->nevhi.p + nev_off[nth];
-            a.fast = (J.igr == 0 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && J.iwave == BH_WAVE_RAYLEIGH))) ? 1 : 0;
+            a.fast = (J.igr == 0 && J.mode <= 1 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && J.iwave == BH_WAVE_RAYLEIGH))) ? 1 : 0;
             a.counted = e->swd_scan;
             if (a.fast) {
                 a.gcount = gcounts + nth;
@@ -523,7 +523,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     // which targets take the short refinement: phase velocities; with BH_SEARCH_FAST_RAYLEIGH only the Rayleigh ones
     auto takes_fast = [&](const SwdTarget &t) {
-        return t.igr == 0 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && t.iwave == BH_WAVE_RAYLEIGH));
+        return t.igr == 0 && t.mode <= 1 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && t.iwave == BH_WAVE_RAYLEIGH));
     };
     a.counted = e->swd_scan;
     for (int t = 0; t < a.ntargets; ++t) {
@@ -629,6 +629,10 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     // (with the start gate of bh_evaluate_batch in force the LDS floor is not needed: RF workgroups are dispatched
     // after every dispersion wavefront is resident and only take what finished wavefronts have freed)
     a.lds_min = (beside_swd && !e->rf_coresident_now && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
+    {   // experiment switch: LDS floor of the synthesis workgroups of a GATED fused call (fewer of them per CU at a time)
+        static const int gated_floor = std::getenv("BH_RF_LDS_GATED") ? std::atoi(std::getenv("BH_RF_LDS_GATED")) : 0;
+        if (beside_swd && e->rf_gated_now && gated_floor > 0) a.lds_min = gated_floor;
+    }
     a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
     a.coef_small = (beside_swd && e->rf_gated_now && std::getenv("BH_RF_COEF_BIG") == nullptr) ? 1 : 0;
     ev_begin(e, 1, st);

@@ -555,7 +555,10 @@ struct SearchT {
     static constexpr int stride_first = 16, stride_next = 4, stride_max = 64;
     // (per-lane flags share ONE register: a `bool` member lives as a 64-bit lane mask in a scalar register pair, and this
     //  kernel has none to spare -- six more of them cost the round loop 30 spilled SGPRs)
-    enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u };
+    enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u,
+                      F_SEED3 = 64u,   // Rayleigh, short refinement: the scan's last replaced point seeds the first estimate
+                      F_SEEDED = 128u  // this bracket's refinement started with a third point
+    };
     // (F_GUARD_ON doubles as "this search takes the short refinement": in a build with both sequences (FASTM = 1) a phase-velocity
     //  target can be told to keep the reference's -- init(.., refseq) --, e.g. the Love targets under BH_SEARCH_FAST_RAYLEIGH)
     unsigned flg = 0u;
@@ -712,6 +715,8 @@ struct SearchT {
         iprev = iprevb = 0;
         vlim = fmin(md.Bv(mmax - 1), betmxd);
         put(F_GUARD_ON, FAST && (PHASE_ONLY || (!group && !refseq)));
+        // Rayleigh only: a Love scan may be the counted one, whose visited points differ -- the result must not depend on the scan mode
+        put(F_SEED3, FAST && ifunc == 2 && has(F_GUARD_ON));
         flg &= ~F_GUARD;
         vh0 = md.Bv(mmax - 1);                          // half-space S velocity
         vh1 = (ifunc == 2) ? md.A(mmax - 1) : betmxd;   // half-space P velocity (Rayleigh: it enters |k - k_alpha| there)
@@ -856,6 +861,11 @@ struct SearchT {
     template <bool CNT>
     __device__ __forceinline__ int step_done()
     {
+        if (FAST) { // (the point the scan leaves behind: third point of the short refinement's first estimate, F_SEED3)
+            cp = c1;
+            delp = del1;
+            have_p = true;
+        }
         c1 = c2;
         del1 = del2;
         if (CNT) isteps += 1;
@@ -873,7 +883,11 @@ struct SearchT {
             cell_lo = fmin(c1, c2);
             cell_hi = fmax(c1, c2);
             put(F_FLO_NEG, signs_differ((c1 < c2) ? del1 : del2, 0.0));
-            have_p = false;
+            // With the scan's previous point (Rayleigh) the inverse-quadratic estimate through three points is available at
+            // once -- its error is ~1e-8, below tau -- and the refinement starts with the acceptance pair: two evaluations
+            // (one round with two trial lanes) instead of three in two rounds.
+            have_p = have_p && has(F_SEED3);
+            put(F_SEEDED, have_p);
             fit = 0;
             // A bracket that contains betmx can hold THREE sign changes (the root, its mirror image and the first of the
             // unphysical ones above the half-space velocity); which of them nevill ends at depends on its whole
@@ -1025,10 +1039,13 @@ struct SearchT {
             del1 = del;
             if (ifirst == 1) del1st = del1;
             idir = (ifirst != 1 && signs_differ(del1st, del1)) ? -1 : +1;
+            if (FAST) have_p = false; // (a new scan: no point left behind yet)
             if (CNT) {
                 isteps = 0;
                 n1 = nv;
-                put(F_CNT_OK, has(F_CNT_ON) && nv >= 0 && idir > 0);
+                // (c1 + dc <= clow: getsol first moves the start to clow -- at its loop top, also when searching upward: a higher
+                //  mode whose previous root lies below the floor the previous mode sets -- which changes the grid: plain steps then)
+                put(F_CNT_OK, has(F_CNT_ON) && nv >= 0 && idir > 0 && c1 + dc > clow);
             }
             todo = 1;
             break;
@@ -1094,7 +1111,7 @@ struct SearchT {
                 const bool up = c2 > c1;
                 const double x1 = up ? x - tau : x + tau;
                 const double x2 = up ? x + tau : x - tau;
-                const bool single = (fit == 1 || fit > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
+                const bool single = ((fit == 1 && !has(F_SEEDED)) || fit > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
                 c3 = x;
                 ceval = single ? x : x1;
                 st = single ? ST_FX : ST_FP1;
@@ -1262,6 +1279,7 @@ struct SearchT {
             if (c2 <= clow) {
                 idir = +1;
                 c1 = clow;
+                if (FAST) have_p = false; // (del1 is not the value at clow)
                 c2 = c1 + dc;
                 // dc > 0, so the retried c2 = clow + dc is above clow: no further loop
             }

@@ -594,6 +594,12 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                     if (run) {
                         const int src = (g * J + (t - 1) / JL) * G + ((t - 1) % JL);
                         const double cl = __shfl(cev, src), dl = __shfl(del, src);
+                        // (the point the run leaves behind: the trial before the last, or -- a run of one -- the old c1)
+                        const int srcp = (t - jn >= 2) ? (g * J + (t - 2) / JL) * G + ((t - 2) % JL) : src;
+                        const double cq = __shfl(cev, srcp), dq = __shfl(del, srcp);
+                        S.cp = (t - jn >= 2) ? cq : S.c1;
+                        S.delp = (t - jn >= 2) ? dq : S.del1;
+                        S.have_p = true;
                         S.c1 = cl;
                         S.del1 = dl;
                         S.del2 = dl;
@@ -634,6 +640,9 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                     const bool plain = live && S.st == ST_STEP && !signs_differ(S.del1, dj) &&
                                        !(S.c2 < S.cm || S.c2 >= S.betmxd + S.dc) && nx > S.clow && fmax(S.c1, S.c2) < S.vsafe;
                     if (plain) {
+                        S.cp = S.c1;      // (the point the scan leaves behind, see SearchT::step_done)
+                        S.delp = S.del1;
+                        S.have_p = true;
                         S.del2 = dj;
                         S.c1 = S.c2;
                         S.del1 = dj;

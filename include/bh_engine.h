@@ -89,7 +89,10 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  *     surfdisp96.f:390-686), evaluation for evaluation: velocities bit-identical to the reference's.
  *   BH_SEARCH_FAST: the same bracket scan (the same bracket, hence the same root), but inside the bracket ~3 evaluations
  *     (regula falsi, then an inverse-quadratic estimate accepted on a sign change within +-5e-8 relative) instead of
- *     nevill's 10-12, whose stop test is the bracket width.  Phase-velocity targets only (group-velocity targets keep
+ *     nevill's 10-12, whose stop test is the bracket width.  FUNDAMENTAL-MODE phase-velocity targets only (mode = 1, the
+ *     reference's default; targets with higher modes keep the reference sequence: their modes lie close together at short
+ *     periods, pairs of roots inside one scan step, and which of them a scan finds hinges on the last bits of the previous
+ *     mode's root; group-velocity targets keep
  *     the reference sequence: a group velocity is a difference quotient of two roots and amplifies their scatter a
  *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5).  The failure
  *     flag and the period from which a failed model's row is zero are the REFERENCE's: where the reference's own outcome

@@ -484,12 +484,17 @@ int64_t bho_swd_guarded_count(int reset)
     return v;
 }
 
-static double refine_root_fast(const medium *md, double t, double c1, double c2, double del1, double del2, double betmx)
+static int g_fast_third = 1; /* (experiment) the scan's last replaced point seeds the inverse-quadratic estimate */
+void bho_swd_set_fast_third(int on) { g_fast_third = on; }
+static double refine_root_fast(const medium *md, double t, double c1, double c2, double del1, double del2, double betmx,
+                               double cp0, double delp0, int have_p0)
 {
     const double twopi = 2.0 * 3.141592653589793;
     const double omega = twopi / t;
-    double cp = 0.0, delp = 0.0;
-    int have_p = 0;
+    double cp = cp0, delp = delp0;
+    int have_p = have_p0 && g_fast_third && md->ifunc == 2; /* (Rayleigh only: Love's scan may be the counted one, whose visited
+                                                                points differ -- the result must not depend on the scan mode) */
+    const int seeded = have_p;
     /* A bracket that reaches beyond the fastest S velocity (a root up there is rejected, :468-471, and the secular
      * function has further sign changes there): look at betmx first and keep the side below it if the root is there --
      * the one nevill walks into from its midpoint. */
@@ -531,7 +536,7 @@ static double refine_root_fast(const medium *md, double t, double c1, double c2,
         const int up = c2 > c1;
         const double x1 = up ? x - tau : x + tau; /* towards c1 */
         const double x2 = up ? x + tau : x - tau; /* towards c2 */
-        const int single = (it == 1 || it > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
+        const int single = ((it == 1 && !seeded) || it > 6 || !(x1 > lo && x1 < hi && x2 > lo && x2 < hi));
         if (single) {
             const double fx = secular(md, omega / x, omega);
             if (signs_differ(fx, del1)) {
@@ -624,13 +629,13 @@ static void guard_after_root(const medium *md, double omega, double c1, double c
  * ones above the half-space velocity): which of them nevill ends at depends on its whole sequence, so the short sequence
  * does not try -- the guard fires. */
 static int refine_bracket(const medium *md, double t1, double omega, double c1, double c2, double del1, double del2,
-                          double betmx, int fast, guard_t *gd, double *c1io)
+                          double betmx, int fast, guard_t *gd, double *c1io, double cp, double delp, int have_p)
 {
     if (fast && gd && gd->on && fmax(c1, c2) > betmx && fmin(c1, c2) < betmx) {
         gd->hit = 1;
         return -2;
     }
-    const double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx) : refine_root(md, t1, c1, c2, del1, del2);
+    const double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx, cp, delp, have_p) : refine_root(md, t1, c1, c2, del1, del2);
     *c1io = cn;
     if (fast && gd && gd->on) {
         guard_after_root(md, omega, c1, c2, del1, del2, cn, betmx, gd);
@@ -652,8 +657,12 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
     if (ifirst == 1) *del1st = del1;
     int idir = 1;
     if (ifirst != 1 && signs_differ(*del1st, del1)) idir = -1;
-    int use_count = counted && v1 && idir > 0;
+    /* (c1 + dc <= clow: getsol first moves the start to clow -- its loop top, also when searching upward: a higher mode whose
+       previous root lies below the floor the previous mode sets -- and that changes the grid: the reference's steps then) */
+    int use_count = counted && v1 && idir > 0 && c1 + dc > clow;
     int isteps = 0;                                     /* steps taken from the start value */
+    double cp = 0.0, delp = 0.0;                        /* the evaluated point a bracket end last replaced (third point of the */
+    int have_p = 0;                                     /* short refinement's first estimate) */
     int stride = 0;
     if (use_count) stride = (sc->iprev > 0) ? sc->iprev - g_stride_back : g_stride_first;
     const double vlim = fmin((double)md->b[md->mmax - 1], betmx);
@@ -675,6 +684,7 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
                     continue;
                 }
                 if (ns == n1) { /* s steps without a sign change */
+                    cp = c1; delp = del1; have_p = 1;
                     c1 = cs;
                     del1 = dels;
                     isteps += s;
@@ -703,9 +713,11 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
                         break;
                     }
                     if (nm > n1) {
+                        cp = chi; delp = delhi; have_p = 1;
                         chi = cmid; delhi = dm; nhi = nm;
                         n = h;
                     } else {
+                        cp = c1; delp = del1; have_p = 1;
                         c1 = cmid; del1 = dm;
                         isteps += h;
                         n = n - h;
@@ -716,6 +728,7 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
                     continue;
                 }
                 if (!signs_differ(del1, delhi)) { /* an even number of roots inside one step: walked over */
+                    cp = c1; delp = del1; have_p = 1;
                     c1 = chi;
                     del1 = delhi;
                     n1 = nhi;
@@ -725,7 +738,7 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
                 }
                 c2 = chi; /* == c1 + dc */
                 if (sc) sc->iprev = isteps;
-                return refine_bracket(md, t1, omega, c1, c2, del1, delhi, betmx, fast, gd, c1io);
+                return refine_bracket(md, t1, omega, c1, c2, del1, delhi, betmx, fast, gd, c1io, cp, delp, have_p);
             }
             use_count = 0; /* too close to the limit: the reference's steps from here */
         }
@@ -733,13 +746,14 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
         if (c2 <= clow) { /* never search below clow: turn round, restart from clow */
             idir = 1;
             c1 = clow;
+            have_p = 0; /* (del1 is not the value at clow: no third point, and see refine_root_fast) */
             continue;
         }
         omega = twopi / t1;
         double del2 = secular(md, omega / c2, omega);
         if (signs_differ(del1, del2)) {
             if (sc) sc->iprev = isteps;
-            return refine_bracket(md, t1, omega, c1, c2, del1, del2, betmx, fast, gd, c1io);
+            return refine_bracket(md, t1, omega, c1, c2, del1, del2, betmx, fast, gd, c1io, cp, delp, have_p);
         }
         if (fast && gd && gd->on && !gd->hit) { /* a step over a half-space velocity that showed no sign change */
             const double lo = fmin(c1, c2), hi = fmax(c1, c2);
@@ -751,6 +765,7 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
                 return -2; /* the model is run again with the reference's sequence: nothing more to do here */
             }
         }
+        cp = c1; delp = del1; have_p = 1;
         c1 = c2;
         del1 = del2;
         isteps += 1;
@@ -873,7 +888,7 @@ static int surfdisp96_run(const float *thkm, const float *vpm, const float *vsm,
         cb[i] = 0.0;
         c[i] = 0.0;
     }
-    guard_t gd = {guard != NULL && fast_mode && igr == 0, 0, {(double)b[mmax - 1], (double)betmx, (double)a[mmax - 1]}, ifunc == 2 ? 3 : 2};
+    guard_t gd = {guard != NULL && fast_mode && igr == 0 && mode == 1, 0, {(double)b[mmax - 1], (double)betmx, (double)a[mmax - 1]}, ifunc == 2 ? 3 : 2};
     { /* (order: half-space S, then -- Rayleigh only, where it also enters |k - k_alpha| -- half-space P; betmx last) */
         gd.vh[1] = (ifunc == 2) ? (double)a[mmax - 1] : (double)betmx;
         gd.vh[2] = (double)betmx;
@@ -921,7 +936,10 @@ static int surfdisp96_run(const float *thkm, const float *vpm, const float *vsm,
             }
             /* (the short refinement applies to phase-velocity runs only: a group velocity is a difference quotient of
                two roots and amplifies their 1e-6 scatter a hundredfold) */
-            const int fast = fast_mode && igr == 0;
+            /* ... and to the fundamental mode only (mode == 1, the reference's default): higher modes lie close together at
+               short periods -- pairs of roots inside one scan step, which a 1e-6 shift of the grid splits or not, and no guard
+               can see them without a mode count (found by tools/gpu_fuzz.py in round 4: a Love mode-2 target at T = 1 s) */
+            const int fast = fast_mode && igr == 0 && mode == 1;
             int iret = bracket_and_refine(&md, t1, &c1, clow, dc, cm, (double)betmx, ifirst, &del1st, fast, &gd, &sc);
             if (iret == -2) { /* the guard fired: this run's results are not used */
                 *guard = 1;

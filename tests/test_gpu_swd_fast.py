@@ -84,7 +84,8 @@ BIG = [  # (target, layers up to, higher modes, earth flattening, models): 2.3 m
 
 @pytest.mark.parametrize("ref,L,mode,flsph,n", BIG)
 def test_failure_flags_and_zero_rows_are_the_references_on_millions_of_models(fast, oracle, ref, L, mode, flsph, n):
-    """LVZ-rich ragged models, all four target kinds, modes 1-2, flat and flattened earth -- 0 differing
+    """LVZ-rich ragged models, all four target kinds, modes 1-2 (the short refinement is for fundamental-mode
+    phase velocities; the others must come out as the reference's bits), flat and flattened earth -- 0 differing
     failure flags, 0 rows whose zero pattern differs, velocities within 1e-5 (achieved 1.2e-6) of the oracle's restatement of
     the REFERENCE's sequence (group velocities: its bits).  Thin models observed out to 60 s are where a Love root creeps up
     to the half-space velocity and the unguarded short sequence differed."""
@@ -99,11 +100,11 @@ def test_failure_flags_and_zero_rows_are_the_references_on_millions_of_models(fa
         ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
         assert np.array_equal(e, oe)
         assert np.array_equal(v == 0, ov == 0)
-        if igr == 1:
+        if igr == 1 or mode > 1:      # group velocities and targets with higher modes keep the reference sequence: its bits
             assert np.array_equal(v, ov)
         else:
             assert worst_rel(v, ov, (v != 0) & (ov != 0)) <= ACHIEVED
-    if igr == 1:
+    if igr == 1 or mode > 1:
         assert nguard == 0
     elif iwave == 1:
         assert nguard > 0      # (the sets do contain the situations the guard is there for)
@@ -113,13 +114,13 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
     """Reference search, Love: BH_SCAN_COUNTED (default) against BH_SCAN_STEPS -- identical velocities and flags, fewer
     evaluations; each against the oracle's restatement of the same scan, count for count.  Rayleigh: no difference."""
     rs = np.random.RandomState(31)
-    nlay, h, vp, vs, rho = synth_models(rs, 3000, 14, lvz_frac=0.3, ragged=True)
-    per = np.linspace(1.5, 70, 35)
+    nlay, h, vp, vs, rho = synth_models(rs, 6000, 10, lvz_frac=0.3, ragged=True)
+    per = np.sort(rs.uniform(1.0, 80.0, 30))   # (irregular periods, higher modes, group velocities: where a mode's start lies below its floor)
     a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
     assert engine.swd_scan() == "auto"
     engine.set_instrumentation(False, True)
     try:
-        for iwave, igr, mode, flsph in ((1, 0, 1, 0), (1, 1, 2, 0), (1, 0, 3, 1), (2, 0, 1, 0)):
+        for iwave, igr, mode, flsph in ((1, 0, 1, 0), (1, 1, 2, 0), (1, 0, 3, 1), (1, 1, 3, 0), (2, 0, 1, 0)):
             got = {}
             for scan in ("counted", "steps"):
                 engine.set_swd_scan(scan)

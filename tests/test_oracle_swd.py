@@ -177,7 +177,11 @@ def test_counted_scan_finds_the_reference_brackets(oracle):
     per = np.linspace(2, 60, 30)
     cases = [(2024, 4000, 12, 1, 0, 1, 0, per), (7, 6000, 4, 1, 0, 1, 0, np.array([0.5, 1, 2, 3, 5, 8, 13, 21, 34, 55.])),
              (3, 1500, 12, 1, 0, 3, 0, per), (4, 1500, 12, 1, 1, 2, 0, per), (5, 1500, 12, 1, 0, 1, 1, per),
-             (6, 400, 40, 1, 0, 1, 0, np.linspace(0.3, 40, 60)), (8, 500, 12, 2, 0, 1, 0, per)]
+             (6, 400, 40, 1, 0, 1, 0, np.linspace(0.3, 40, 60)), (8, 500, 12, 2, 0, 1, 0, per),
+             # higher modes whose previous root lies below the floor the previous mode sets (getsol moves the start to clow
+             # first: the counted scan must step there -- found by tools/gpu_fuzz.py in round 4)
+             (9, 6000, 8, 1, 1, 3, 0, np.sort(np.random.RandomState(9).uniform(1.0, 80.0, 30))),
+             (10, 3000, 10, 1, 1, 3, 1, np.sort(np.random.RandomState(10).uniform(1.0, 80.0, 21)))]
     for seed, B, L, iwave, igr, mode, flsph, pp in cases:
         rs = np.random.RandomState(seed)
         nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.3, ragged=True, hmin=0.2 if L > 20 else 1.5, hmax=3 if L > 20 else 8.0)
@@ -221,6 +225,8 @@ def test_guarded_short_refinement_returns_the_reference_failure_flags(oracle):
         assert np.array_equal(gv == 0, ov == 0), seed
         both = (gv != 0) & (ov != 0)
         assert np.max(np.abs(gv[both] - ov[both]) / ov[both]) <= 1.2e-6
-        assert 0 < nguard < 0.3 * B or iwave == 2
-        assert ng < nref or iwave == 1
+        if mode > 1:      # targets with higher modes keep the reference sequence: its bits, no guard
+            assert nguard == 0 and np.array_equal(gv, ov) and np.array_equal(rv, ov)
+        assert 0 < nguard < 0.3 * B or iwave == 2 or mode > 1
+        assert ng < nref or iwave == 1 or mode > 1
     assert nraw > 10   # the unguarded sequence does differ on these sets
