@@ -82,6 +82,7 @@ struct bh_engine {
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
     uint64_t guard_total[BH_MAX_TARGETS] = {0}; // guarded models of retired buffers (the live buffer carries its own running sum)
     bool guard_fresh = true;     // the guard buffer is new: zero its cumulative words as well
+    bool guard_last = false;     // the most recent dispersion call had targets with the short refinement (its counts are in the buffer)
     int love_inlook = 0; // BH_SWD_LOVE_INLOOK env (experiment switch): Love trials inside a lane group, 0 = automatic
     // one EventSet per timed *_batch call since the last bh_timing_reset()
     struct EventSet {
@@ -441,6 +442,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         for (int j = 0; j < njobs; ++j)
             any_fast = any_fast || (jobs[j].K != 0 && jobs[j].igr == 0 && jobs[j].mode <= 1 &&
                                     (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && jobs[j].iwave == BH_WAVE_RAYLEIGH)));
+        e->guard_last = any_fast;
         if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
         ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan;
@@ -557,6 +559,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     const bool side_by_side = nparts == 2 && e->aux2 != nullptr;
     int32_t *gcounts = nullptr, *glists = nullptr;
+    e->guard_last = part[0].fast != 0;
     if (part[0].fast) {
         if ((rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         for (int t = 0; t < part[0].ntargets; ++t)
@@ -797,7 +800,7 @@ int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launche
             HIPCHK(e, hipMemcpy(w, e->guard.p, sizeof(w), hipMemcpyDeviceToHost));
         }
         if (counts)
-            for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = w[t];
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = e->guard_last ? w[t] : 0;
         if (total)
             for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)w[BH_MAX_TARGETS + t];
     }
