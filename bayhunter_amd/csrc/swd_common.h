@@ -723,7 +723,7 @@ struct SearchT {
         vsafe = has(F_GUARD_ON) ? fmin(vh0, vh1) : 1.0e300;
         if (active) set_period(0);
         ceval = c1;
-        plan_first_jump();
+        if (counted) plan_first_jump();
     }
 
     // The grid point `want` steps above `from` by the reference's repeated additions, stopping below vlim.
@@ -766,6 +766,7 @@ struct SearchT {
 
     // Set up the root search of period k of mode iq (initial guess logic, :253-272), moving on to
     // the next mode when the period list is exhausted or a previous mode already failed here.
+    template <bool CNT = true> // (CNT = false: none of the counted scan's state is touched -- the Rayleigh wavefronts' instantiation)
     __device__ void next_search()
     {
         for (;;) {
@@ -781,7 +782,7 @@ struct SearchT {
             }
             iq = iq + 1;
             k = 0;
-            iprev = iprevb = 0;
+            if (CNT) iprev = iprevb = 0;
         }
         set_period(k);
         root = 0;
@@ -805,7 +806,7 @@ struct SearchT {
         }
         st = ST_FIRST;
         ceval = c1;
-        plan_first_jump();
+        if (CNT) plan_first_jump();
     }
 
     // Look-ahead: candidate 0 is the pending request; candidate r > 0 is the phase velocity the r-th
@@ -1216,8 +1217,8 @@ struct SearchT {
                     } else {
                         iq = iq + 1;
                         k = 0;
-                        iprev = iprevb = 0;
-                        next_search();
+                        if (CNT) iprev = iprevb = 0;
+                        next_search<CNT>();
                     }
                 } else {
                     ck = c1;
@@ -1231,7 +1232,7 @@ struct SearchT {
                         c1 = c1 - onea * dc;
                         st = ST_FIRST;
                         ceval = c1;
-                        plan_first_jump();
+                        if (CNT) plan_first_jump();
                     } else {
                         period_done = true;
                     }
@@ -1254,7 +1255,7 @@ struct SearchT {
                 }
                 if (writer) vel[k] = out;
                 k = k + 1;
-                next_search();
+                next_search<CNT>();
             }
             todo = 0;
         }
