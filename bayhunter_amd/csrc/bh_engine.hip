@@ -1112,6 +1112,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     e->targets.swap(tmp);
     e->nt = nt;
     e->ldy = off;
+    if (const char *g = std::getenv("BH_LDY_PAD")) e->ldy += std::atoi(g); // experiment switch: wider rows of synthetics (host callers: want_ymod unsupported with it)
     e->err_t_nt = e->err_t_B = -1;
     return BH_OK;
 }

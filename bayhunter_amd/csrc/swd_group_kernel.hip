@@ -579,7 +579,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                 const int tj = live ? jn : 0;
                 const int srcn = (g * J + tj / JL) * G + (tj % JL);
                 const double cj = __shfl(cev, srcn), dj = __shfl(del, srcn);
-                const int nj = __shfl(nv, srcn);
+                const int nj = CNT ? __shfl(nv, srcn) : -1;
                 if (jn > 0) live = live && S.ceval == cj && S.omega == omg;
                 const double nxt = (S.idir > 0) ? cev + S.dc : cev - S.dc;
                 // (a step that reaches a half-space velocity goes through advance(): the guard's probes)
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                     const int src = (g * J + j / JL) * G + (j % JL); // a lane that carried trial j
                     const double cj = __shfl(cev, src);
                     dj = __shfl(del, src);
-                    nj = __shfl(nv, src);
+                    if (CNT) nj = __shfl(nv, src);
                     // trial 0 IS the pending request (consumed unconditionally, also when a broken model
                     // has driven the search to NaN); a later trial only if the search now asks for it
                     if (j > 0) live = live && S.active && S.ceval == cj && S.omega == omg;

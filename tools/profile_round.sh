@@ -46,6 +46,7 @@ BH_SWD_SEARCH=fast python $R/tools/gpu_latency.py > "$OUT/latency_fast.txt" 2>&1
   done; done; } > "$OUT/love_scan.txt" 2>&1
 # the dispersion kernel's phase clocks with and without the receiver function beside it (c3 against c2)
 python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3.txt" 2>&1
+python $R/tools/gpu_c3_tail.py > "$OUT/c3_tail.txt" 2>&1
 # randomised parity sweeps (tools/gpu_fuzz.py): reference sequence; short refinement with its guard
 python $R/tools/gpu_fuzz.py 404 ${BH_FUZZ_REF:-3000} > "$OUT/fuzz_reference.txt" 2>&1
 FAST=1 python $R/tools/gpu_fuzz.py 405 ${BH_FUZZ_FAST:-8000} > "$OUT/fuzz_fast.txt" 2>&1

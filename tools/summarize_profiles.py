@@ -58,7 +58,7 @@ def trace_stats(wl):
 
 for wl in ("c2", "c2fast", "c3", "c3g", "c2_b65536", "c4", "c5", "rf_c3", "rf_tut", "rf_t512u", "rf_t512r", "rf_n16384", "gauss"):
     trace_stats(wl)
-for name in ("latency.txt", "latency_fast.txt", "rf_alone.txt", "gauss_alone.txt", "love_scan.txt", "phase_c3.txt", "fuzz_reference.txt", "fuzz_fast.txt"):
+for name in ("latency.txt", "latency_fast.txt", "rf_alone.txt", "gauss_alone.txt", "love_scan.txt", "phase_c3.txt", "c3_tail.txt", "fuzz_reference.txt", "fuzz_fast.txt"):
     if os.path.exists(os.path.join(raw, name)):
         shutil.copy(os.path.join(raw, name), os.path.join(out, "%s_%s" % (tag, name)))
 b0 = os.path.join(raw, "bench_default.json")
