@@ -819,18 +819,34 @@ struct SearchT {
     {
         double q = ceval;
         if ((CNT || FAST) && st >= ST_JUMP) { // the counted scan (guard probes: nothing to foresee)
-            if (r == 1) {
-                // after the jump: the index search starts, most probably, at the step below the target (the stride aims
-                // one step beyond the last period's bracket); inside the index search: the step above (a root right
-                // behind the point), or -- the point being right below c2 -- nevill's first midpoint of that bracket
-                if (CNT && st == ST_JUMP) q = cnext1;
-                else if (CNT && st == ST_BIS) q = (!FAST && jn == nn - 1) ? 0.5 * (ceval + c2) : ceval + dc;
+            // The requests after the pending one are grid points around it: after the jump (k = jn steps above c1) the index
+            // search starts, most probably, a step or a few below the target (the stride aims one step beyond the last period's
+            // bracket); inside the index search they are the neighbours of the pending point (a root right behind or before it),
+            // or -- the pending point being right below c2 -- nevill's first midpoint of that bracket.  The kernels take a
+            // trial's value whenever the search asks for exactly that velocity, in whatever order (consume, CNT).
+            if (CNT && r >= 1) {
+                int k = -1;
+                if (st == ST_JUMP) k = jn - r;
+                else if (st == ST_BIS) {
+                    if (r == 1 && !FAST && jn == nn - 1) return 0.5 * (ceval + c2);
+                    const int d = (r + 1) / 2;
+                    k = (r & 1) ? jn + d : jn - d;
+                    if (k >= nn) k = -1;
+                }
+                if (k >= 1) {
+                    q = c1;
+                    for (int i = 0; i < k; ++i) q = q + dc;
+                }
             }
             return q;
         }
-        if (CNT && st == ST_FIRST && has(F_JUMP_READY)) { // start value of a period: the first jump of its counted scan, then the step below it
+        if (CNT && st == ST_FIRST && has(F_JUMP_READY)) { // start value of a period: the first jump of its counted scan, then the steps below it
             if (r == 1) q = cnext;
             else if (r == 2) q = cnext1;
+            else if (r >= 3 && jn - (r - 1) >= 1) {
+                q = c1;
+                for (int i = 0; i < jn - (r - 1); ++i) q = q + dc;
+            }
             return q;
         }
         if (FAST && st >= ST_FX) { // the only request that can be foreseen: the second point of an acceptance pair

@@ -616,6 +616,29 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
                 }
                 live = live && S.active && jn < Jtot;
             }
+        } else if (CNT && J * JL > 2) { // (with two trials per round the order is the only one possible)
+            // The counted scan asks for grid points in an order that depends on the values (start value, jump target, then an
+            // index search): every trial lane carries one of the likely ones (SearchT::candidate), and a trial's value is taken
+            // whenever the search asks for exactly its velocity -- in whatever order, each trial at most once.  Trial 0 IS the
+            // pending request.  (Which values the search consumes does not depend on it: the requests are the search's own.)
+            bool live = S.active;
+            unsigned long long used = 0ull;
+            int src = (g * J) * G; // a lane that carried trial 0
+            const bool rep = !spare && li < JL; // one lane per trial answers
+            const unsigned long long mine = (LPM >= 64) ? ~0ull : (((1ull << LPM) - 1ull) << (g * LPM)); // this model's lanes
+            for (int it = 0; it < J * JL; ++it) {
+                if (__ballot(live) == 0ull) break;
+                const double dj = __shfl(del, src);
+                const int nj = __shfl(nv, src);
+                if (live) {
+                    used |= 1ull << src;
+                    S.template advance<CNT>(dj, nj);
+                }
+                live = live && S.active && S.omega == omg;
+                const unsigned long long m = __ballot(live && rep && cev == S.ceval) & mine & ~used;
+                live = live && m != 0ull;
+                src = live ? (int)__builtin_ctzll(m) : src;
+            }
         } else {
             bool live = S.active;
             const int Jtot = J * JL;
@@ -985,7 +1008,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // with several models per wavefront (B = 4096: 2.06 -> 1.71 ms).  One model per wavefront (the trial lanes already walk
     // the scan seven steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches (the Rayleigh
     // wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
-    const bool cntb = any_love && wpb == GROUP_WPB && (build != 1 || !adapt) && (a.counted == 1 || (a.counted == 2 && all_love && !adapt && build != 1));
+    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && all_love && !adapt && build != 1));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
@@ -1006,8 +1029,8 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
         else BH_GROUP_LAUNCH_ADAPT(2, false);
     } else if (adapt && build == 1) { // (both sequences in one launch: Rayleigh targets short, Love targets the reference's)
-        if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
-        else BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, false, true, false);
+        if (counted) BH_GROUP_LAUNCH_ADAPT(1, true);
+        else BH_GROUP_LAUNCH_ADAPT(1, false);
     } else if (adapt) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(0, true);
         else BH_GROUP_LAUNCH_ADAPT(0, false);
