@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- forward-model + logL evaluations per second on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5|c2g|c3g] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5|c5_full|c2g|c3g] [--batch B]
+                    [--search reference|fast|fast_rayleigh]
 
 The default (--workload all) prints the c2 line -- the configuration the metric is quoted on -- and, inside the same
 JSON line, the other BASELINE configs as blocks timed the same way right after it: "c3" (configs[2], with an
-`rf_roofline` block for the receiver-function kernels measured alone on that configuration), "c4" and "c5"
-(configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s).
+`rf_roofline` block for the receiver-function kernels measured alone on that configuration), "c2g" / "c3g" (the second
+runs of SURVEY.md 8(d)), "c4" and "c5" (configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s; each
+also with the chains' default search under "default_search"), "c5_full" (configs[4] whole on one GPU, exchange sweeps inside
+the timed region; N = 1 only), "fast_search" (c2 / c3 with BH_SEARCH_FAST) and, as the LAST key, a "summary" of at most 600
+characters with every value, ms per step and roofline fraction.
 
 A "step" is ONE pass of the hot path over one batch of B synthetic candidate models that are
 already resident in HBM: `bh_evaluate_batch` (C ABI, memspace = device) = every registered
