@@ -371,6 +371,28 @@ def parity_check(spec, batch, noise, d_logL, d_misf, d_err, n=64):
     return out
 
 
+def velocity_check(spec, batch, d_ymod, d_err, n=64):
+    """Dispersion velocities of `n` models of the last step against the oracle's restatement of the REFERENCE's sequence:
+    the largest relative difference (north_star: 1e-5; 0.0 = bit-identical) over the models neither side fails on."""
+    from oracle import oracle as O
+    from bayhunter_amd import engine as E
+    nlay, h, vp, vs, rho = batch
+    idx = np.unique(np.linspace(0, nlay.size - 1, n).astype(int))
+    a = [np.ascontiguousarray(x.T[idx]) for x in (h, vp, vs, rho)]
+    ymod = d_ymod.cpu().numpy()[idx]
+    err = d_err.cpu().numpy()[idx]
+    worst, off = 0.0, 0
+    for s_ in spec:
+        if s_["kind"] == E.TARGET_SWD:
+            ov, oe, _ = O.swd_batch(nlay[idx], *a, s_["x"], s_["iwave"], s_["igr"])
+            ok = (oe == 0) & (err == 0)
+            if ok.any():
+                v = ymod[ok, off:off + s_["n"]]
+                worst = max(worst, float(np.max(np.abs(v - ov[ok]) / np.abs(ov[ok]))))
+        off += s_["n"]
+    return {"max_rel_velocity": worst, "velocity_tolerance": 1e-5, "velocity_within_tolerance": bool(worst <= 1e-5)}
+
+
 def pmc_summary(workload, B):
     """PMC figures of the dominant kernel for this workload and batch.  Counters cannot be read from inside the
     timed run: they come from the separate rocprofv3 --pmc passes of the same command (tools/profile_round.sh),
@@ -587,6 +609,15 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     if not args.no_parity:
         try:
             out["parity_check"] = parity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_logL, d_misf, d_err)
+            # the synthetics themselves (dispersion velocities) against the oracle's REFERENCE sequence -- north_star's own
+            # quantity and tolerance (1e-5 relative): one more call of the last step with the synthetics asked for, untimed
+            d_ymod = torch.zeros((B, eng.ldy), dtype=torch.float64, device=dev)
+            nl, h_, vp_, vs_, rho_ = d_batches[(args.warmup + args.steps - 1) % NPOOL]
+            eng.evaluate_batch_dev(B, L, nl.data_ptr(), h_.data_ptr(), vp_.data_ptr(), vs_.data_ptr(), rho_.data_ptr(), B, 1,
+                                   d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(), ymod=d_ymod.data_ptr(),
+                                   stream=stream)
+            torch.cuda.synchronize()
+            out["parity_check"].update(velocity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], d_ymod, d_err))
         except Exception as ex:
             out["parity_check"] = {"n": 0, "error": repr(ex)}
     if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline and rf_roof:
