@@ -7,7 +7,8 @@ hints (dev tool; the fixed cases live in tests/).
                                                    to ITS CPU restatement (oracle search mode 2), and against the reference
                                                    sequence: failure flags and zero patterns (both must be the reference's),
                                                    worst relative difference; how many models the guard re-ran
-    SCAN=steps ...                                 every scan step evaluated (default: the counted scan of Love targets)"""
+    SCAN=steps|counted ...                         every scan step evaluated / the counted Love scan wherever a Love target is
+                                                   (default: the engine's BH_SCAN_AUTO)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,8 +25,8 @@ bad = 0
 FAST = os.environ.get("FAST", "0") == "1"
 if FAST:
     eng.set_swd_search("fast")
-if os.environ.get("SCAN", "counted") == "steps":
-    eng.set_swd_scan("steps")
+if os.environ.get("SCAN", "auto") in ("steps", "counted"):     # (default: the engine's BH_SCAN_AUTO)
+    eng.set_swd_scan(os.environ["SCAN"])
 nguard = 0
 worst, flagdiff, zerodiff, nmodels = 0.0, 0, 0, 0
 t0 = time.time()
