@@ -76,7 +76,7 @@ struct bh_engine {
     int force_group = 0; // BH_SWD_GROUP env / bh_engine_set_swd_group: 0 = choose automatically
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
-    int swd_search = 0;  // bh_engine_set_swd_search / BH_SWD_SEARCH=fast: 1 = the short refinement for phase-velocity targets
+    int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
@@ -740,7 +740,7 @@ int bh_engine_create(int device, bh_engine **out)
     if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_SEARCH"))
-        e->swd_search = (g[0] == 'f' || g[0] == '1') ? ((std::strstr(g, "rayleigh") != nullptr) ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (g[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : 0);
+        e->swd_search = (g[0] == 'f' || g[0] == '1') ? ((std::strstr(g, "rayleigh") != nullptr) ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (g[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_REFERENCE);
     if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == '0') ? BH_SCAN_STEPS : ((g[0] == 'c' || g[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
         e->love_inlook = std::atoi(g);

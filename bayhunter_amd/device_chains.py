@@ -130,7 +130,8 @@ class DeviceChains(object):
         self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
 
         # ---- initial state through the reference-order host code --------------------------------
-        host = ChainBatch(self.targets, chain_seeds(seed, off, self.C), ip, pr)
+        host = ChainBatch(self.targets, chain_seeds(seed, off, self.C), ip, pr,
+                          search=self.search if self.search is not None else self.targets.engine.swd_search())
         self.noisepriors = host.noisepriors
         self.targets._register()  # constant target data + laws live on the device from here on
 

@@ -9,6 +9,7 @@ Host API  : numpy arrays in, numpy arrays out (the library stages through its ow
 Device API: raw device pointers (`tensor.data_ptr()`), asynchronous on a HIP stream -- what
             bench.py and the multi-GPU chain driver use with torch-owned HBM buffers.
 """
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -138,7 +139,7 @@ def load_library():
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 6:
+    if L.bh_abi_version() != 7:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
@@ -232,10 +233,11 @@ class Engine(object):
         self._check(self._L.bh_engine_set_swd_lookahead(self._h, int(trials_per_round)))
 
     def set_swd_search(self, search):
-        """"reference" (default): the reference's sequence of secular-function evaluations, velocities bit-identical to
-        surfdisp96.  "fast": the same brackets, ~3 evaluations inside each instead of nevill's 10-12; phase-velocity
-        targets only; within 1.2e-6 relative of the reference, failure flags the reference's (a guard re-runs the models
-        whose outcome hinges on the last bits of a root with the reference's sequence).  "fast_rayleigh": the same for the
+        """"fast" (the engine's default): the reference's brackets, ~3 evaluations inside each instead of nevill's 10-12;
+        fundamental-mode phase-velocity targets only; within 1.2e-6 relative of the reference (north_star: 1e-5), failure
+        flags the reference's (a guard re-runs the models whose outcome hinges on the last bits of a root with the
+        reference's sequence).  "reference": the reference's sequence of secular-function evaluations, velocities
+        bit-identical to surfdisp96 (replays of recorded reference chains: ChainBatch).  "fast_rayleigh": "fast" for the
         Rayleigh targets only -- for samplers, whose Love proposals trip the guard too often (include/bh_engine.h)."""
         codes = {"reference": SEARCH_REFERENCE, "fast": SEARCH_FAST, "fast_rayleigh": SEARCH_FAST_RAYLEIGH}
         codes.update({v: v for v in list(codes.values())})
@@ -246,6 +248,16 @@ class Engine(object):
 
     def swd_search(self):
         return {SEARCH_FAST: "fast", SEARCH_FAST_RAYLEIGH: "fast_rayleigh"}.get(self._L.bh_engine_get_swd_search(self._h), "reference")
+
+    @contextlib.contextmanager
+    def searching(self, search):
+        """The calls inside run with this root refinement; the engine's setting is restored afterwards."""
+        prev = self.swd_search()
+        self.set_swd_search(search)
+        try:
+            yield self
+        finally:
+            self.set_swd_search(prev)
 
     def set_swd_scan(self, scan):
         """Love bracket scans: "counted" = skip the steps a mode count proves to be without a sign change (same brackets, same

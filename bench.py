@@ -7,10 +7,16 @@
 The default (--workload all) prints the c2 line -- the configuration the metric is quoted on -- and, inside the same
 JSON line, the other BASELINE configs as blocks timed the same way right after it: "c3" (configs[2], with an
 `rf_roofline` block for the receiver-function kernels measured alone on that configuration), "c2g" / "c3g" (the second
-runs of SURVEY.md 8(d)), "c4" and "c5" (configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s; each
-also with the chains' default search under "default_search"), "c5_full" (configs[4] whole on one GPU, exchange sweeps inside
-the timed region; N = 1 only), "fast_search" (c2 / c3 with BH_SEARCH_FAST) and, as the LAST key, a "summary" of at most 600
-characters with every value, ms per step and roofline fraction.
+runs of SURVEY.md 8(d)), "c4" and "c5" (configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s, with
+the chains' default search), "c5_full" (configs[4] whole on one GPU, exchange sweeps inside the timed region; N = 1 only),
+"reference_search" (c2, c3 and the chains again with BH_SEARCH_REFERENCE, N = 1 only) and, as the LAST key, a "summary" of at
+most 600 characters with every value, ms per step and roofline fraction.
+
+The line is measured with the engine's DEFAULT dispersion search (--search fast, bh_engine.h: the reference's brackets, a
+three-evaluation refinement inside them; velocities within 1.2e-6 relative of the reference's -- north_star's tolerance is
+1e-5 --, failure flags the reference's); `parity_check` states the velocities' largest relative difference against the
+oracle's restatement of the REFERENCE's sequence with that tolerance.  --search reference measures everything with the
+reference's own sequence (bit-identical velocities; the line of rounds 1-3) and reports the short one beside ("fast_search").
 
 A "step" is ONE pass of the hot path over one batch of B synthetic candidate models that are
 already resident in HBM: `bh_evaluate_batch` (C ABI, memspace = device) = every registered
@@ -339,7 +345,10 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
 
 def parity_check(spec, batch, noise, d_logL, d_misf, d_err, n=64):
     """The outputs of the LAST timed step against the oracle on `n` models spread over the batch (the oracle as the
-    checker, after the timed region): max relative difference of logL and of the misfits, failure flags equal."""
+    checker, after the timed region): failure flags equal; largest relative (and absolute) difference of logL and of the
+    misfits END TO END against the oracle's REFERENCE sequence -- at rounding level with --search reference; with the short
+    refinement it is the velocities' 1e-6 (the reference's own roots are known to 1e-6: nevill's stop test) carried through
+    the likelihood, see synthetics_check for the quantities north_star puts a tolerance on."""
     from oracle import oracle as O
     from bayhunter_amd import engine as E
     nlay, h, vp, vs, rho = batch
@@ -365,23 +374,29 @@ def parity_check(spec, batch, noise, d_logL, d_misf, d_err, n=64):
         ref_L, ref_m = O.joint_batch(nlay[idx], ht, vpt, vst, rhot, spec, noise[idx], nthreads=0)
     ok = err == 0
     out = {"n": int(idx.size), "failure_flags_equal": bool(np.array_equal(ok, ref_L > -1e14)),
-           "max_rel_logL": float(np.max(np.abs(logL[ok] - ref_L[ok]) / np.abs(ref_L[ok]))) if ok.any() else None}
+           "max_rel_logL": float(np.max(np.abs(logL[ok] - ref_L[ok]) / np.abs(ref_L[ok]))) if ok.any() else None,
+           "max_abs_logL": float(np.max(np.abs(logL[ok] - ref_L[ok]))) if ok.any() else None}
     if ref_m is not None and ok.any():
         out["max_rel_misfit"] = float(np.max(np.abs(misf[ok] - ref_m[ok]) / np.abs(ref_m[ok])))
     return out
 
 
-def velocity_check(spec, batch, d_ymod, d_err, n=64):
-    """Dispersion velocities of `n` models of the last step against the oracle's restatement of the REFERENCE's sequence:
-    the largest relative difference (north_star: 1e-5; 0.0 = bit-identical) over the models neither side fails on."""
+def synthetics_check(spec, batch, noise, d_ymod, d_logL, d_err, n=64):
+    """The synthetics of `n` models of the last step against the oracle, in north_star's own quantities and tolerances:
+    dispersion velocities against the restatement of the REFERENCE's sequence (1e-5 relative; 0.0 = bit-identical), receiver
+    functions (1e-4 of the trace's peak) -- over the models neither side fails on -- and the likelihood as a function of the
+    synthetics: the oracle's dense likelihood of the DEVICE's synthetics against the device's logL (1e-8 relative).  With the
+    reference search logL also agrees end to end (parity_check's max_rel_logL); with the short refinement the end-to-end
+    difference is the velocities' 1e-6 carried through the likelihood, which has no tolerance of its own in north_star."""
     from oracle import oracle as O
     from bayhunter_amd import engine as E
     nlay, h, vp, vs, rho = batch
     idx = np.unique(np.linspace(0, nlay.size - 1, n).astype(int))
     a = [np.ascontiguousarray(x.T[idx]) for x in (h, vp, vs, rho)]
     ymod = d_ymod.cpu().numpy()[idx]
+    logL = d_logL.cpu().numpy()[idx]
     err = d_err.cpu().numpy()[idx]
-    worst, off = 0.0, 0
+    worst, worst_rf, off = 0.0, None, 0
     for s_ in spec:
         if s_["kind"] == E.TARGET_SWD:
             ov, oe, _ = O.swd_batch(nlay[idx], *a, s_["x"], s_["iwave"], s_["igr"])
@@ -389,8 +404,25 @@ def velocity_check(spec, batch, d_ymod, d_err, n=64):
             if ok.any():
                 v = ymod[ok, off:off + s_["n"]]
                 worst = max(worst, float(np.max(np.abs(v - ov[ok]) / np.abs(ov[ok]))))
+        elif s_["kind"] == E.TARGET_RF:
+            rf = O.rf_batch(nlay[idx], *a, s_["p"], s_["gauss"], s_["nsamp"], s_["fsamp"], s_["tshift"], s_["waveno"], s_["n"])
+            ok = err == 0
+            if ok.any():
+                worst_rf = max(worst_rf or 0.0, float(np.max(np.abs(ymod[ok, off:off + s_["n"]] - rf[ok]) / np.abs(rf[ok]).max(axis=1, keepdims=True))))
         off += s_["n"]
-    return {"max_rel_velocity": worst, "velocity_tolerance": 1e-5, "velocity_within_tolerance": bool(worst <= 1e-5)}
+    worst_l = 0.0
+    for k in np.flatnonzero(err == 0)[:32]:
+        o, off = 0.0, 0
+        for t, s_ in enumerate(spec):
+            o += O.loglike_dense(s_["law"], ymod[k, off:off + s_["n"]], s_["yobs"], noise[idx[k], 2 * t], noise[idx[k], 2 * t + 1],
+                                 yerr=s_.get("yerr"), rinv=s_.get("rinv"), logdet_r=s_.get("logdet_r", 0.0))
+            off += s_["n"]
+        worst_l = max(worst_l, abs(logL[k] - o) / abs(o))
+    out = {"max_rel_velocity": worst, "velocity_tolerance": 1e-5, "velocity_within_tolerance": bool(worst <= 1e-5),
+           "max_rel_logL_of_the_device_synthetics": worst_l, "logL_of_synthetics_tolerance": 1e-8}
+    if worst_rf is not None:
+        out.update({"max_rf_over_peak": worst_rf, "rf_tolerance": 1e-4})
+    return out
 
 
 def pmc_summary(workload, B):
@@ -617,7 +649,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
                                    d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(), ymod=d_ymod.data_ptr(),
                                    stream=stream)
             torch.cuda.synchronize()
-            out["parity_check"].update(velocity_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], d_ymod, d_err))
+            out["parity_check"].update(synthetics_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_ymod, d_logL, d_err))
         except Exception as ex:
             out["parity_check"] = {"n": 0, "error": repr(ex)}
     if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline and rf_roof:
@@ -664,14 +696,11 @@ def make_summary(out):
     for w in ("c3", "c2g", "c3g", "c4", "c5", "c5_full"):
         if w in out:
             sm[w] = vm(out[w])
-    for w in ("c4", "c5", "c5_full"):
-        d = out.get(w, {}).get("default_search") if isinstance(out.get(w), dict) else None
-        if isinstance(d, dict) and d.get("value") is not None:
-            sm[w + "_fr"] = float("%.4g" % d["value"])
-    fs = out.get("fast_search", {})
-    for w in ("c2", "c3"):
-        if isinstance(fs.get(w), dict) and fs[w].get("value") is not None:
-            sm[w + "_fast"] = vm(fs[w])
+    for name, tag in (("reference_search", "_ref"), ("fast_search", "_fast")):
+        fs = out.get(name, {})
+        for w in ("c2", "c3", "c4", "c5", "c5_full"):
+            if isinstance(fs.get(w), dict) and fs[w].get("value") is not None:
+                sm[w + tag] = float("%.4g" % fs[w]["value"])
     if isinstance(out.get("c3"), dict) and "ratio_to_c2_ms_per_step" in out["c3"]:
         sm["c3/c2"] = float("%.4g" % out["c3"]["ratio_to_c2_ms_per_step"])
     sm["frac_hbm"] = float("%.3g" % out["roofline"]["frac"])
@@ -683,7 +712,8 @@ def make_summary(out):
         sm["rf_frac_fp64"] = float("%.3g" % rf["binding"]["frac"])
     if isinstance(out.get("c5_full"), dict) and "config" in out["c5_full"]:
         sm["c5_full_swaps"] = out["c5_full"]["config"].get("accepted_swaps")
-    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-iterations/s (c4..); _fr = fast_rayleigh search"
+    sm["search"] = out["config"].get("search")
+    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..; search fast_rayleigh); _ref: reference sequence, value only"
     return sm
 
 
@@ -698,9 +728,11 @@ def main():
     ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
                     "--workload c4/c5, 600 inside --workload all)")
     ap.add_argument("--spec-depth", type=int, default=0, help="c4/c5: iterations per evaluation launch (0 = automatic)")
-    ap.add_argument("--search", default="reference", choices=["reference", "fast", "fast_rayleigh"],
-                    help="root refinement of the dispersion search: the reference's sequence (bit-identical velocities, the default "
-                         "and what `value` is measured with) or the engine's short one (bh_engine_set_swd_search: within 1.2e-6 relative)")
+    ap.add_argument("--search", default="fast", choices=["reference", "fast", "fast_rayleigh"],
+                    help="root refinement of the dispersion search (bh_engine_set_swd_search): fast = the engine's default, what "
+                         "`value` is measured with (the reference's brackets, a three-evaluation refinement inside: velocities within "
+                         "1.2e-6 relative of the reference's, north_star's tolerance 1e-5; failure flags the reference's); reference = "
+                         "the reference's own sequence, bit-identical velocities (reported beside under reference_search)")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -766,6 +798,7 @@ def main():
     eng.set_swd_search(args.search)
     out = None
     if args.workload in ("c4", "c5", "c5_full"):
+        eng.set_swd_search("fast_rayleigh" if args.search == "fast" else args.search)   # (the chains' own default, see below)
         out = run_chains(args, eng, rank, world, dist, dev, args.workload, args.chain_steps or args.steps, args.warmup)
     elif args.workload != "all":
         out = run_eval(args, eng, rank, world, dist, dev, args.workload, dryrun)
@@ -783,57 +816,57 @@ def main():
                 blocks[w] = {"error": repr(ex)}
         csteps = args.chain_steps or 600
         chain_workloads = ("c4", "c5") + (("c5_full",) if world == 1 else ())
-        for w in chain_workloads:
+        # (DeviceChains' own default is "fast_rayleigh": Love proposals of a sampler trip the guard of "fast" on 2 % of the models,
+        #  and one guarded model costs a window a second launch -- include/bh_engine.h)
+        eng.set_swd_search("fast_rayleigh" if args.search == "fast" else args.search)
+        try:
+            for w in chain_workloads:
+                try:
+                    blocks[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
+                except Exception as ex:          # the chain blocks must never take the headline number down with them
+                    blocks[w] = {"error": repr(ex)}
+        finally:
+            eng.set_swd_search(args.search)
+        # (the chain blocks above ran with the chains' own default where the line's search is the engine's default)
+        # the same workloads with the OTHER root refinement, reported beside and never as `value`: the reference's sequence
+        # (bit-identical velocities) where the line is measured with the engine's default, the short refinement where the
+        # line was asked for with --search reference
+        alt, alt_name = {}, ("reference" if args.search != "reference" else "fast")
+        if world == 1 or os.environ.get("BH_BENCH_ALT_BLOCK", "0") == "1":   # (a supplement: at N = 1 only)
             try:
-                blocks[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
-            except Exception as ex:          # the chain blocks must never take the headline number down with them
-                blocks[w] = {"error": repr(ex)}
-        # the chains again with the search DeviceChains() uses by default (Rayleigh targets: the short refinement, within 1.2e-6
-        # relative of the reference's bits and with its failure flags; Love targets: the reference's sequence)
-        if args.search == "reference":
-            eng.set_swd_search("fast_rayleigh")
-            try:
-                for w in chain_workloads:
-                    try:
-                        b = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
-                        if rank == 0 and isinstance(blocks.get(w), dict) and b is not None:
-                            blocks[w]["default_search"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "search", "speculation", "kernel_ms_per_launch") if k in b}
-                            blocks[w]["default_search"]["accepted_swaps"] = b["config"].get("accepted_swaps")
-                    except Exception as ex:
-                        if rank == 0 and isinstance(blocks.get(w), dict):
-                            blocks[w]["default_search"] = {"error": repr(ex)}
-            finally:
-                eng.set_swd_search("reference")
-        # the evaluate workloads with the engine's short root refinement (BH_SEARCH_FAST: velocities within 1.2e-6 relative
-        # instead of bit-identical, the reference's failure flags; include/bh_engine.h) -- reported beside, never as `value`
-        fast = {}
-        if args.search == "reference" and (world == 1 or os.environ.get("BH_BENCH_FAST_BLOCK", "0") == "1"):   # (a supplement: at N = 1 only)
-            eng.set_swd_search("fast")
-            try:
+                eng.set_swd_search(alt_name)
                 for w in ("c2", "c3"):
                     g0 = np.array(eng.guard_totals())
-                    fast[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=False)
-                    if fast[w] is not None:
-                        fast[w]["models_rerun_by_the_guard"] = int((np.array(eng.guard_totals()) - g0).sum())
+                    alt[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=False)
+                    if alt[w] is not None and alt_name != "reference":
+                        alt[w]["models_rerun_by_the_guard"] = int((np.array(eng.guard_totals()) - g0).sum())
+                eng.set_swd_search("reference" if alt_name == "reference" else "fast_rayleigh")
+                for w in chain_workloads:
+                    try:
+                        alt[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
+                        if alt[w] is not None:
+                            alt[w]["accepted_swaps"] = alt[w]["config"].get("accepted_swaps")
+                    except Exception as ex:
+                        alt[w] = {"error": repr(ex)}
             except Exception as ex:
-                fast["error"] = repr(ex)
+                alt["error"] = repr(ex)
             finally:
-                eng.set_swd_search("reference")
+                eng.set_swd_search(args.search)
         if rank == 0:
             c3 = blocks["c3"]
             c3["ratio_to_c2_ms_per_step"] = c3["ms_per_step"] / out["ms_per_step"]
             out.update(blocks)
-            if fast:
-                keep = ("value", "unit", "ms_per_step", "ms_per_step_stats", "kernel_ms_per_step", "parity_check", "models_rerun_by_the_guard",
-                        "failed_models_last_step", "error")
-                out["fast_search"] = {"note": "bh_engine_set_swd_search(BH_SEARCH_FAST): same bracket scan as the reference, ~3 evaluations "
-                                              "inside a bracket instead of nevill's 10-12; phase velocities within 1.2e-6 relative of the "
-                                              "reference's (north_star: 1e-5), failure flags the reference's (guard + re-run, "
-                                              "tests/test_gpu_swd_fast.py: 2.3 million models, DESIGN.md 3.1b); parity_check below is against the "
-                                              "oracle's REFERENCE sequence",
-                                      **{w: ({k: b[k] for k in keep if k in b} if isinstance(b, dict) else b) for w, b in fast.items()}}
-                if "value" in fast.get("c2", {}):
-                    out["fast_search"]["c2"]["ratio_to_reference_search"] = fast["c2"]["value"] / out["value"]
+            if alt:
+                keep = ("value", "unit", "ms_per_step", "ms_per_step_stats", "kernel_ms_per_step", "kernel_ms_per_launch", "parity_check",
+                        "models_rerun_by_the_guard", "failed_models_last_step", "search", "speculation", "accepted_swaps", "error")
+                note = ("bh_engine_set_swd_search(BH_SEARCH_REFERENCE): the reference's own sequence of secular-function evaluations "
+                        "(getsol + nevill), velocities bit-identical to surfdisp96 -- what the line's `value` was measured with up to "
+                        "round 3" if alt_name == "reference" else
+                        "bh_engine_set_swd_search(BH_SEARCH_FAST) (chains: BH_SEARCH_FAST_RAYLEIGH): the engine's default search")
+                out[alt_name + "_search"] = {"note": note,
+                                             **{w: ({k: b[k] for k in keep if k in b} if isinstance(b, dict) else b) for w, b in alt.items()}}
+                if isinstance(alt.get("c2"), dict) and alt["c2"].get("value"):
+                    out[alt_name + "_search"]["c2"]["ratio_to_the_lines_value"] = alt["c2"]["value"] / out["value"]
             out["summary"] = make_summary(out)
     if rank == 0 and out is not None:
         if comm is not None:

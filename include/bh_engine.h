@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 6
+#define BH_ABI_VERSION 7
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -85,9 +85,10 @@ int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
  * if it does.  Results do not depend on it. */
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
 /* Root refinement of the dispersion search.
- *   BH_SEARCH_REFERENCE (default): the reference's sequence of secular-function evaluations (getsol + nevill,
- *     surfdisp96.f:390-686), evaluation for evaluation: velocities bit-identical to the reference's.
- *   BH_SEARCH_FAST: the same bracket scan (the same bracket, hence the same root), but inside the bracket ~3 evaluations
+ *   BH_SEARCH_REFERENCE: the reference's sequence of secular-function evaluations (getsol + nevill,
+ *     surfdisp96.f:390-686), evaluation for evaluation: velocities bit-identical to the reference's.  What a replay of
+ *     chains recorded with the reference needs (bayhunter_amd.chains.ChainBatch sets it for its calls).
+ *   BH_SEARCH_FAST (default since ABI 7, when its failure flags became the reference's): the same bracket scan (the same bracket, hence the same root), but inside the bracket ~3 evaluations
  *     (regula falsi, then an inverse-quadratic estimate accepted on a sign change within +-5e-8 relative) instead of
  *     nevill's 10-12, whose stop test is the bracket width.  FUNDAMENTAL-MODE phase-velocity targets only (mode = 1, the
  *     reference's default; targets with higher modes keep the reference sequence: their modes lie close together at short
@@ -101,7 +102,7 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  *     run again with the reference's sequence in a second, small launch of the same call (bh_engine_guard_stats).
  *     A deterministic function of the model (independent of batch and launch plan), but NOT the
  *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
- * Also BH_SWD_SEARCH=fast in the environment at engine creation. */
+ * Also BH_SWD_SEARCH=reference|fast|fast_rayleigh in the environment at engine creation. */
 #define BH_SEARCH_REFERENCE 0
 #define BH_SEARCH_FAST 1
 /* BH_SEARCH_FAST for the Rayleigh phase-velocity targets only; Love targets keep the reference's sequence (with the counted

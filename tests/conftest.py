@@ -37,6 +37,17 @@ def engine():
     return E.default_engine(0)
 
 
+@pytest.fixture(autouse=True)
+def _reference_search(request):
+    """The GPU parity tests compare bits with the reference: every gpu-marked test starts with the process-wide engine on the
+    REFERENCE's root refinement (the engine's own default is the short one, bh_engine.h; the tests of that mode select it
+    themselves and `test_gpu_swd_fast.py::test_default_search_is_the_short_refinement` looks at a fresh engine)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from bayhunter_amd import engine as E
+        E.default_engine(0).set_swd_search("reference")
+    yield
+
+
 def rows(a, nlay):
     """[B, Lmax] padded rows -> list of trimmed 1-D arrays"""
     return [a[i, :nlay[i]] for i in range(len(nlay))]

@@ -107,15 +107,21 @@ def test_ragged_device_batch_any_depth_hint(engine, oracle, hint):
         engine.set_typical_layers(0)
 
 
+@pytest.mark.parametrize("search", ["fast", "reference"])
 @pytest.mark.parametrize("workload", ["c2", "c3"])
-def test_the_bench_path_against_the_oracle(workload):
+def test_the_bench_path_against_the_oracle(workload, search):
     """The exact composition bench.py times (BASELINE configs[1] / [2]): `build_workload` -> `observed_data` ->
     `set_targets` -> `evaluate_batch_dev` on HBM-resident layer-major arrays, device pointers for every output,
-    B = 4096 -- logL, misfits and failure flags of 128 models spread over the batch against the oracle's dense
-    restatement of Targets.py:314-347, at 1e-8 relative."""
+    B = 4096, on a fresh engine -- 128 models spread over the batch against the oracle.  With the reference search: logL,
+    misfits and failure flags against the oracle's dense restatement of Targets.py:314-347, at 1e-8 relative.  With the
+    engine's DEFAULT search (the short refinement): failure flags equal, velocities within north_star's 1e-5 of the
+    reference sequence's (1.2e-6 reached), the RF within 1e-4 of its peak, and logL = the oracle's dense likelihood of the
+    device's own synthetics at 1e-8."""
     import torch
     import bench
     eng = E.Engine(0)
+    assert eng.swd_search() == "fast"          # a fresh engine: the short refinement with its guard
+    eng.set_swd_search(search)
     B, L = 4096, 10
     spec, batches, noise, truth, nrs = bench.build_workload(workload, B, L, seed=20260927)
     bench.observed_data(eng, spec, truth, nrs)
@@ -133,7 +139,17 @@ def test_the_bench_path_against_the_oracle(workload):
     torch.cuda.synchronize()
     chk = bench.parity_check(spec, batches[1], noise, d_logL, d_misf, d_err, n=128)
     assert chk["n"] == 128 and chk["failure_flags_equal"]
-    assert chk["max_rel_logL"] <= 1e-8 and chk["max_rel_misfit"] <= 1e-8, chk
+    if search == "reference":
+        assert chk["max_rel_logL"] <= 1e-8 and chk["max_rel_misfit"] <= 1e-8, chk
+    d_ymod = torch.zeros((B, eng.ldy), dtype=torch.float64, device=dev)
+    eng.evaluate_batch_dev(B, L, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                           B, 1, d_noise.data_ptr(), d_logL.data_ptr(), d_misf.data_ptr(), d_err.data_ptr(), ymod=d_ymod.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    syn = bench.synthetics_check(spec, batches[1], noise, d_ymod, d_logL, d_err, n=128)
+    assert syn["max_rel_velocity"] <= (0.0 if search == "reference" else 2e-6), syn
+    assert syn["max_rel_logL_of_the_device_synthetics"] <= 1e-8, syn
+    assert syn.get("max_rf_over_peak", 0.0) <= 1e-8, syn
     assert int((d_err != 0).sum().item()) < B // 20 and bool(torch.isfinite(d_logL).all().item())
     eng.close()
 

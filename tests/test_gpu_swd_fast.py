@@ -313,9 +313,37 @@ def test_fast_rayleigh_keeps_the_reference_sequence_for_love_targets(engine, ora
         engine.set_swd_search("reference")
 
 
+def test_default_search_is_the_short_refinement(engine, oracle):
+    """A fresh engine takes the guarded short refinement for fundamental-mode phase velocities (the bits of its CPU
+    restatement) and the reference's sequence for everything else (group velocities, higher modes: the reference's bits);
+    the setting is per engine."""
+    from bayhunter_amd import engine as E
+    eng = E.Engine(0)
+    try:
+        assert eng.swd_search() == "fast" and engine.swd_search() == "reference"
+        rs = np.random.RandomState(77)
+        nlay, h, vp, vs, rho = synth_models(rs, 700, 10, lvz_frac=0.25, ragged=True)
+        a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+        per = np.linspace(2, 60, 30)
+        for iwave in (1, 2):
+            v, e = eng.swd_batch(nlay, h, vp, vs, rho, per, iwave, 0)
+            with restatement(oracle):
+                ov, oe, _ = oracle.swd_batch(nlay, *a, per, iwave, 0)
+            rv, re_, _ = oracle.swd_batch(nlay, *a, per, iwave, 0)
+            assert np.array_equal(v, ov) and np.array_equal(e, oe) and np.array_equal(e, re_)
+            both = (v != 0) & (rv != 0)
+            assert np.array_equal(v == 0, rv == 0) and np.max(np.abs(v[both] - rv[both]) / rv[both]) <= 2e-6
+            for kw in (dict(igr=1), dict(igr=0, mode=2)):
+                v, e = eng.swd_batch(nlay, h, vp, vs, rho, per, iwave, kw["igr"], mode=kw.get("mode", 1))
+                rv, re_, _ = oracle.swd_batch(nlay, *a, per, iwave, kw["igr"], mode=kw.get("mode", 1))
+                assert np.array_equal(v, rv) and np.array_equal(e, re_)
+    finally:
+        eng.close()
+
+
 def test_the_switch_is_per_engine_and_validated(engine):
     from bayhunter_amd.engine import EngineError
-    assert engine.swd_search() == "reference"          # the default: the reference's bits
+    assert engine.swd_search() == "reference"          # (set by conftest for every gpu test; a fresh engine: see above)
     with pytest.raises(ValueError):
         engine.set_swd_search("quick")
     engine.set_swd_search("fast")

@@ -23,8 +23,7 @@ ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device("cuda:0")
 bad = 0
 FAST = os.environ.get("FAST", "0") == "1"
-if FAST:
-    eng.set_swd_search("fast")
+eng.set_swd_search("fast" if FAST else "reference")
 if os.environ.get("SCAN", "auto") in ("steps", "counted"):     # (default: the engine's BH_SCAN_AUTO)
     eng.set_swd_scan(os.environ["SCAN"])
 nguard = 0
