@@ -485,7 +485,7 @@ enum : int {
     ST_NEV0 = 2,  // first midpoint inside nevill                    (:582-583)
     ST_NEVL = 3,  // midpoint / Neville estimate, then top of loop   (:586-...)
     ST_NEVF = 4,  // forced midpoint after the estimate left the bracket (:594-598)
-    // the optional short refinement (SearchT<.., FAST = true>; not the reference's sequence, see there)
+    // the short refinement (SearchT<.., FAST = true>; not the reference's sequence, see there)
     ST_FX = 5,    // single point: regula falsi / bisection
     ST_FP1 = 6,   // x - tau (towards c1) of the acceptance pair around the estimate x
     ST_FP2 = 7,   // x + tau (towards c2)
@@ -508,14 +508,14 @@ enum : int {
 // NLO: Neville entries kept in LDS; the orders from NLO on (rarely reached: the order only grows through
 // consecutive interpolation steps) live in a second array (`set_high`, global memory in the lane-per-evaluation
 // kernel, whose residency is bounded by LDS).  NLO = NEV_MAX: everything in LDS, no second array.
-// FAST = true compiles in the engine's OPTIONAL short refinement (bh_engine_set_swd_search), taken by phase-velocity
+// FAST = true compiles in the engine's short refinement (bh_engine_set_swd_search; the engine's default since ABI 7), taken by phase-velocity
 // targets: the bracket scan in steps of dc is the reference's, evaluation for evaluation -- the same bracket, the same
 // root -- but inside the bracket nevill's 10-12 evaluations (its stop test is the bracket WIDTH, which one-sided
 // interpolation steps close slowly) are replaced by ~3: one regula-falsi point, then an inverse-quadratic estimate x
 // through the three known points, accepted as soon as the function changes sign between x - tau and x + tau
 // (tau = 5e-8 |x|; the reference stops at a bracket of 1e-6 c1 and returns one of its ends).  A miss moves the
 // bracket and repeats; bisection from the seventh pass on.  Result: within 1.2e-6 relative of the reference's
-// (measured: tests/test_gpu_swd.py), against north_star's 1e-5; NOT bit-identical, hence off by default.  The sequence
+// (measured: tests/test_gpu_swd_fast.py), against north_star's 1e-5; NOT bit-identical (BH_SEARCH_REFERENCE is).  The sequence
 // of evaluations is a function of the model alone (not of the launch plan): results do not depend on the batch.
 // oracle/swd_oracle.c (refine_root_fast) restates it for the bit-level check of the device.
 // FASTM: 0 = the reference sequence only; 1 = FAST as described (group-velocity targets fall through to the reference

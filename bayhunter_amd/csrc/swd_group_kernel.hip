@@ -170,7 +170,7 @@ __device__ __forceinline__ void wave_sync()
 // WPB = wavefronts per workgroup (they only share the libm tables): 2 by default; 4 when receiver-function workgroups
 // are to run beside the kernel -- a CU's eight wavefronts then hold two copies of the tables instead of four, which is
 // what leaves a CU's LDS room for one RF workgroup (bh_engine.hip: co-resident receiver function).
-// FAST: the build with the optional short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
+// FAST: the build with the short refinement (SearchT<.., FAST>, swd_common.h) for the phase-velocity targets.
 // PROF: the build with the evaluation counters, phase clocks and wavefront trace (launches with A.neval set).
 // ADAPT: a launch of ONE model per wavefront (a chain window, a single model): every wavefront sizes its lane groups and its
 // trials per round for its OWN model -- a lane per finite layer (8 ... 16), as many trials as lanes and the wavefront's LDS
@@ -1004,11 +1004,13 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         any_love = any_love || a.t[t].iwave == 1;
         all_love = all_love && a.t[t].iwave == 1;
     }
-    // a.counted: 1 = wherever a Love target is (BH_SCAN_COUNTED), 2 = where it pays (BH_SCAN_AUTO): launches of Love targets only
-    // with several models per wavefront (B = 4096: 2.06 -> 1.71 ms).  One model per wavefront (the trial lanes already walk
-    // the scan seven steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches (the Rayleigh
-    // wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
-    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && all_love && !adapt && build != 1));
+    // a.counted: 1 = wherever a Love target is (BH_SCAN_COUNTED), 2 = where it pays (BH_SCAN_AUTO): with several models per
+    // wavefront, launches of Love targets only (B = 4096: 2.06 -> 1.71 ms) and Rayleigh + Love launches of the short refinement
+    // (there the LOVE wavefronts set the time: 379 rounds against the Rayleigh wavefronts' 302; counted 149 rounds of twice the
+    // length: c2 2.51 -> 2.30 ms, c3 2.60 -> 2.49).  One model per wavefront (the trial lanes already walk the scan seven
+    // steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches of the reference's sequence (the
+    // Rayleigh wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
+    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && !adapt && (all_love ? build != 1 : build == 2)));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)

@@ -728,17 +728,20 @@ def main():
     ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
                     "--workload c4/c5, 600 inside --workload all)")
     ap.add_argument("--spec-depth", type=int, default=0, help="c4/c5: iterations per evaluation launch (0 = automatic)")
-    ap.add_argument("--search", default="fast", choices=["reference", "fast", "fast_rayleigh"],
+    ap.add_argument("--search", default=None, choices=["reference", "fast", "fast_rayleigh"],
                     help="root refinement of the dispersion search (bh_engine_set_swd_search): fast = the engine's default, what "
                          "`value` is measured with (the reference's brackets, a three-evaluation refinement inside: velocities within "
                          "1.2e-6 relative of the reference's, north_star's tolerance 1e-5; failure flags the reference's); reference = "
-                         "the reference's own sequence, bit-identical velocities (reported beside under reference_search)")
+                         "the reference's own sequence, bit-identical velocities (reported beside under reference_search).  Not given: "
+                         "fast for the evaluate workloads, fast_rayleigh for the chain workloads (DeviceChains' own default)")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rf-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last step (after the timed region)")
     args = ap.parse_args()
+    chain_search = args.search or "fast_rayleigh"
+    args.search = args.search or "fast"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly (`python bench.py --gpus N`): become the launcher -- one rank per GPU under
@@ -798,7 +801,7 @@ def main():
     eng.set_swd_search(args.search)
     out = None
     if args.workload in ("c4", "c5", "c5_full"):
-        eng.set_swd_search("fast_rayleigh" if args.search == "fast" else args.search)   # (the chains' own default, see below)
+        eng.set_swd_search(chain_search)   # (not given: the chains' own default, see below)
         out = run_chains(args, eng, rank, world, dist, dev, args.workload, args.chain_steps or args.steps, args.warmup)
     elif args.workload != "all":
         out = run_eval(args, eng, rank, world, dist, dev, args.workload, dryrun)
@@ -818,7 +821,7 @@ def main():
         chain_workloads = ("c4", "c5") + (("c5_full",) if world == 1 else ())
         # (DeviceChains' own default is "fast_rayleigh": Love proposals of a sampler trip the guard of "fast" on 2 % of the models,
         #  and one guarded model costs a window a second launch -- include/bh_engine.h)
-        eng.set_swd_search("fast_rayleigh" if args.search == "fast" else args.search)
+        eng.set_swd_search(chain_search)
         try:
             for w in chain_workloads:
                 try:

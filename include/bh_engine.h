@@ -125,9 +125,11 @@ int bh_engine_get_swd_search(const bh_engine *e);
  *   BH_SCAN_STEPS: every step evaluated, as the reference does.
  *   BH_SCAN_COUNTED: the counted scan wherever a launch holds a Love target (and the build exists: not in the one-model-per-
  *     wavefront launch that mixes both refinements, BH_SEARCH_FAST_RAYLEIGH).
- *   BH_SCAN_AUTO (default): the counted scan where it is measured to pay -- launches of Love targets only with several models
- *     per wavefront (4096 models: 2.06 -> 1.71 ms), and the lane-per-model kernels.  Where Rayleigh wavefronts set the time
- *     anyway, or the trial lanes already walk the scan seven steps a round, its state machine costs what it saves.
+ *   BH_SCAN_AUTO (default): the counted scan where it is measured to pay -- with several models per wavefront: launches of
+ *     Love targets only (4096 models: 2.06 -> 1.71 ms) and Rayleigh + Love launches of BH_SEARCH_FAST (whose Love wavefronts
+ *     are the long ones: c2 2.51 -> 2.30 ms) --, and the lane-per-model kernels.  Where Rayleigh wavefronts set the time anyway
+ *     (the reference's sequence), or the trial lanes already walk the scan seven steps a round (one model per wavefront), its
+ *     state machine costs what it saves.
  * Results never depend on it.  Rayleigh targets always step (no such count for the P-SV problem here).  Also
  * BH_SWD_SCAN=steps|counted|auto in the environment at engine creation. */
 #define BH_SCAN_STEPS 0

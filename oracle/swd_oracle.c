@@ -453,7 +453,7 @@ static double refine_root(const medium *md, double t, double c1, double c2, doub
     return c3; /* the last point evaluated, not a bracket end (:672) */
 }
 
-/* ---- the engine's OPTIONAL short refinement (bh_engine_set_swd_search(e, 1)) -------------------------------
+/* ---- the engine's short refinement (bh_engine_set_swd_search(e, BH_SEARCH_FAST), its default) -------------------
  * NOT the reference's algorithm: a CPU restatement of bayhunter_amd/csrc/swd_common.h (SearchT, FAST) so that the
  * device's sequence of evaluations in that mode can be checked bit for bit.  The gate of the mode itself is the
  * tolerance against the reference sequence above (north_star: 1e-5 relative on the velocities), see

@@ -102,7 +102,7 @@ def test_oracle_matches_compiled_reference_random(oracle):
 
 
 def test_short_refinement_restatement_stays_within_tolerance_of_the_reference(oracle):
-    """`oracle.swd_search(True)` = the CPU restatement of the engine's OPTIONAL short root refinement
+    """`oracle.swd_search(True)` = the CPU restatement of the engine's short root refinement (its default search)
     (bh_engine_set_swd_search; swd_common.h) -- not the reference's algorithm.  Its gate, on the CPU: phase velocities
     within north_star's 1e-5 relative (achieved: 1.2e-6) of the reference's golden vectors and of the reference
     sequence on random models, the same models failing, fewer evaluations; group velocities untouched."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Does the optional short root refinement (bh_engine_set_swd_search) change what the chains sample?  The same problem
+"""Does the short root refinement (bh_engine_set_swd_search) change what the chains sample?  The same problem
 sampled by N device-resident chains with the reference sequence and by N others (another seed) with the short one;
 posterior summaries compared in units of their Monte-Carlo standard error, as tools/gpu_chains_stat.py does for the
 device step against the reference-order chains.  Dev tool; prints a table.

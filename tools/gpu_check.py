@@ -22,6 +22,7 @@ def synth_models(rs, B, L, lvz_frac=0.1, ragged=False):
 def main():
     out = {}
     eng = E.Engine(0)
+    eng.set_swd_search("reference")   # (bit-level comparison with the oracle's reference sequence)
     rs = np.random.RandomState(11)
     # device libm vs host libm
     x = rs.uniform(0.01, 40, 20000)

@@ -10,6 +10,7 @@ from bayhunter_amd.synth import synth_models
 from oracle import oracle as O
 
 eng = E.Engine(0)
+eng.set_swd_search("reference")     # (the comparison below is against the oracle's reference sequence, bit-level arithmetic)
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad, worst = 0, 0.0
