@@ -313,6 +313,42 @@ def test_fast_rayleigh_keeps_the_reference_sequence_for_love_targets(engine, ora
         engine.set_swd_search("reference")
 
 
+def test_joint_launch_with_the_default_search_matches_the_restatement_whatever_the_scan(engine, oracle):
+    """The launch bench.py's headline times: Rayleigh + Love phase targets of a fused call in ONE launch with the short
+    refinement, where BH_SCAN_AUTO gives the Love wavefronts the counted scan (the <.., FASTM = 2, .., CNTB> build).  Both
+    targets' synthetics carry the bits of the CPU restatement under every scan setting, for batches that several models
+    share a wavefront in (300, 4096) and LVZ-rich ragged models; failure flags the reference's."""
+    from bayhunter_amd import engine as E
+    per = np.linspace(2, 60, 30)
+    yobs = 3.4 + 0.01 * per
+    rs = np.random.RandomState(91)
+    try:
+        engine.set_swd_search("fast")
+        for B, L, lvz in ((300, 10, 0.0), (4096, 10, 0.25), (2500, 12, 0.5)):
+            nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=lvz, ragged=True)
+            a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+            engine.set_targets([dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=2, igr=0),
+                                dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=1, igr=0)])
+            noise = np.tile([0, 0.05] * 2, (B, 1))
+            with restatement(oracle):
+                rv, re_, _ = oracle.swd_batch(nlay, *a, per, 2, 0)
+                lv, le, _ = oracle.swd_batch(nlay, *a, per, 1, 0)
+            fr = oracle.swd_batch(nlay, *a, per, 2, 0)[1] | oracle.swd_batch(nlay, *a, per, 1, 0)[1]
+            ok = (re_ == 0) & (le == 0)
+            assert np.array_equal(ok, fr == 0)
+            first = None
+            for scan in ("auto", "steps", "counted"):
+                engine.set_swd_scan(scan)
+                logL, misf, err, ymod = engine.evaluate_batch(nlay, h, vp, vs, noise, want_ymod=True)
+                assert np.array_equal(err == 0, ok), (B, scan)
+                assert np.array_equal(ymod[ok, :30], rv[ok]) and np.array_equal(ymod[ok, 30:], lv[ok]), (B, scan)
+                first = logL if first is None else first
+                assert np.array_equal(logL, first), (B, scan)
+    finally:
+        engine.set_swd_scan("auto")
+        engine.set_swd_search("reference")
+
+
 def test_default_search_is_the_short_refinement(engine, oracle):
     """A fresh engine takes the guarded short refinement for fundamental-mode phase velocities (the bits of its CPU
     restatement) and the reference's sequence for everything else (group velocities, higher modes: the reference's bits);
