@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Randomised check of the fused forward + likelihood call against the CPU oracle: random target sets
 (dispersion types, P/SV receiver functions), noise laws (uncorrelated, scaled errors, exponential), noise
-values, ragged batches (dev tool; the fixed cases live in tests/)."""
+values, ragged batches (dev tool; the fixed cases live in tests/).
+    python tools/gpu_fuzz_eval.py SEED NCONFIG           the reference's sequence against the oracle's (1e-8 on logL and misfits)
+    FAST=1 python tools/gpu_fuzz_eval.py SEED NCONFIG    the engine's default search (joint launches: short refinement, counted
+                                                         Love scan where BH_SCAN_AUTO picks it) against its CPU restatement, and
+                                                         the failure pattern against the reference sequence's"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,12 +14,14 @@ from bayhunter_amd.synth import synth_models
 from oracle import oracle as O
 
 eng = E.Engine(0)
-eng.set_swd_search("reference")     # (the comparison below is against the oracle's reference sequence, bit-level arithmetic)
+FAST = os.environ.get("FAST", "0") == "1"
+eng.set_swd_search("fast" if FAST else "reference")     # (the comparison below is against the oracle's same sequence, bit-level arithmetic)
+flagdiff = 0
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad, worst = 0, 0.0
 for it in range(ncfg):
-    B = int(rs.choice([1, 9, 64, 130, 400]))
+    B = int(rs.choice([1, 9, 64, 130, 400, 1700, 4096] if FAST else [1, 9, 64, 130, 400]))
     L = int(rs.choice([3, 6, 10, 15, 21]))
     nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.2, ragged=bool(rs.rand() < 0.5))
     if L > 10:
@@ -43,7 +49,11 @@ for it in range(ncfg):
         noise[:, 2 * t + 1] = rs.uniform(0.005, 0.1, B)
     eng.set_targets(spec)
     logL, misf, err = eng.evaluate_batch(nlay, h, vp, vs, noise)
-    oL, om = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
+    with O.swd_search(2 if FAST else 0):
+        oL, om = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
+    if FAST:   # the failure pattern is the reference sequence's
+        rL, _ = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
+        flagdiff += int(((rL <= -1e14) != (logL <= -1e14)).sum())
     relL = np.max(np.abs(logL - oL) / np.maximum(1.0, np.abs(oL)))
     relm = np.max(np.abs(misf - om) / np.maximum(1e-30, np.abs(om)))
     worst = max(worst, relL, relm)
@@ -51,4 +61,7 @@ for it in range(ncfg):
         bad += 1
         print("MISMATCH", it, dict(B=B, L=L, nt=nt), [(s["kind"], s["law"], s["n"]) for s in spec], relL, relm, flush=True)
 print("%d configurations, %d beyond 1e-8, worst relative difference %.2e" % (ncfg, bad, worst))
+if FAST:
+    print("failure patterns differing from the reference sequence's: %d" % flagdiff)
+    bad += flagdiff
 sys.exit(1 if bad else 0)
