@@ -130,6 +130,8 @@ struct SwdMultiArgs {
                        // own model (swd_group_kernel<.., ADAPT>); 0: the caller fixed lanes or trials (experiments)
     int counted;       // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
     int rerun;         // 1: the launch re-runs listed models (SwdTarget::count): plain two-dimensional grid, no SIMD pairing
+    int restart;       // 1: in a launch of one model per wavefront a model the guard fires on starts again with the reference's
+                       //    sequence in its own wavefront (the build with both sequences) instead of being listed for a re-run launch
     SwdTarget t[8];
 };
 int bh_swd_pick_group(int B, int ntargets, int Lmax);
@@ -159,6 +161,7 @@ struct SwdLaunchInfo {
     unsigned workgroups; // of the launch (what SwdMultiArgs::started is advanced by)
     long waves;          // wavefronts that do work
     size_t lds;          // bytes per workgroup
+    int restarts_in_place; // the launch handles guarded models itself (SwdMultiArgs::restart took effect): no re-run launch needed
 };
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
                         SwdPairWork *pair = nullptr);

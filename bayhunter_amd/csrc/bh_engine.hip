@@ -280,7 +280,7 @@ int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
 
 // The guard of the short refinement (SearchT, swd_common.h): work space = BH_MAX_TARGETS counts (16 words) followed by one
 // list of B model indices per target.
-constexpr int GUARD_HEAD = 16;
+constexpr int GUARD_HEAD = 24;
 int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t **lists)
 {
     const size_t need = ((size_t)GUARD_HEAD + (size_t)BH_MAX_TARGETS * (size_t)(B + 4)) * sizeof(int32_t);
@@ -288,7 +288,7 @@ int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t *
         if (e->guard.p) {
             int32_t cum[BH_MAX_TARGETS];
             HIPCHK(e, hipStreamSynchronize(st));
-            HIPCHK(e, hipMemcpy(cum, (int32_t *)e->guard.p + BH_MAX_TARGETS, sizeof(cum), hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(cum, (int32_t *)e->guard.p + 2 * BH_MAX_TARGETS, sizeof(cum), hipMemcpyDeviceToHost));
             for (int t = 0; t < BH_MAX_TARGETS; ++t) e->guard_total[t] += (uint64_t)cum[t];
         }
         e->guard_fresh = true;
@@ -297,8 +297,9 @@ int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t *
     if (rc) return rc;
     *counts = (int32_t *)e->guard.p;
     *lists = (int32_t *)e->guard.p + GUARD_HEAD;
-    // words [0, 8): this call's counts; [8, 16): cumulative since the buffer was made
-    HIPCHK(e, hipMemsetAsync(e->guard.p, 0, (e->guard_fresh ? GUARD_HEAD : BH_MAX_TARGETS) * sizeof(int32_t), st));
+    // words [0, 8): this call's lists' lengths (re-run launch); [8, 16): this call's models restarted in place (group kernel,
+    // one model per wavefront); [16, 24): cumulative since the buffer was made
+    HIPCHK(e, hipMemsetAsync(e->guard.p, 0, (e->guard_fresh ? GUARD_HEAD : 2 * BH_MAX_TARGETS) * sizeof(int32_t), st));
     e->guard_fresh = false;
     return BH_OK;
 }
@@ -312,6 +313,7 @@ int launch_swd_rerun(bh_engine *e, hipStream_t st, const SwdMultiArgs &main, int
     SwdMultiArgs a = main;
     a.fast = 0;
     a.rerun = 1;
+    a.restart = 0;
     a.perm = nullptr;
     a.split = nullptr;
     a.Lcut = a.Lmax;
@@ -555,6 +557,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         for (int t = 0; t < a.ntargets; ++t) nfast += takes_fast(a.t[t]) ? 1 : 0;
         for (int t = 0; t < a.ntargets; ++t) a.t[t].refseq = (nfast > 0 && a.t[t].igr == 0 && !takes_fast(a.t[t])) ? 1 : 0;
         a.fast = nfast > 0 ? 1 : 0;
+        a.restart = 1; // (takes effect in launches of one model per wavefront: see bh_launch_swd_group)
         part[nparts++] = a;
     }
     const bool side_by_side = nparts == 2 && e->aux2 != nullptr;
@@ -599,7 +602,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     if (e->started) e->started_expected += started_by;
     e->last_swd.workgroups = started_by;
-    if (part[0].fast && (rc = launch_swd_rerun(e, st, part[0], gcounts, glists))) {
+    if (part[0].fast && !e->last_swd.restarts_in_place && (rc = launch_swd_rerun(e, st, part[0], gcounts, glists))) {
         ev_end(e, 0, st);
         return rc;
     }
@@ -794,15 +797,15 @@ int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launche
     if (!e) return BH_EINVAL;
     if (rerun_launches) *rerun_launches = e->rerun_launches;
     if (counts || total) {
-        int32_t w[2 * BH_MAX_TARGETS] = {0};
+        int32_t w[3 * BH_MAX_TARGETS] = {0};
         if (e->guard.p && !e->guard_fresh) {
             HIPCHK(e, hipStreamSynchronize(e->stream));
             HIPCHK(e, hipMemcpy(w, e->guard.p, sizeof(w), hipMemcpyDeviceToHost));
         }
         if (counts)
-            for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = e->guard_last ? w[t] : 0;
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = e->guard_last ? w[t] + w[BH_MAX_TARGETS + t] : 0;
         if (total)
-            for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)w[BH_MAX_TARGETS + t];
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)w[2 * BH_MAX_TARGETS + t];
     }
     return BH_OK;
 }

@@ -317,8 +317,16 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
     SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
     S.XS = MPW;
+    // RESTART (one model per wavefront, the build with both sequences, SwdMultiArgs::restart): when the guard of the short
+    // refinement fires, the model starts again right here with the reference's sequence -- what the engine's re-run launch
+    // would do for it afterwards, without the second launch (the guarded models of a sampler's window are its shallow ones:
+    // their second search ends before the window's deep models do).  Same rows, same flags.
+    bool refseq_now = T.refseq != 0, restarted = false;
+    unsigned evals_before = 0u; // (evaluations of the abandoned first search: they count, as the re-run launch's would)
+restart_with_the_reference_sequence:
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, T.refseq != 0);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now);
+    S.evals += evals_before;
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
@@ -689,12 +697,22 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
             tS += t3 - t2c;
         }
     }
+    if (ADAPT && FASTM == 1 && A.restart != 0 && !restarted && __ballot(valid && S.has(S.F_GUARD)) != 0ull) {
+        restarted = true;
+        refseq_now = true;
+        evals_before = S.evals;
+        if (valid && li == 0 && rr == 0 && !spare && T.gcount != nullptr) {
+            atomicAdd(T.gcount + BH_MAX_TARGETS, 1);     // this call: restarted in place
+            atomicAdd(T.gcount + 2 * BH_MAX_TARGETS, 1); // cumulative
+        }
+        goto restart_with_the_reference_sequence;
+    }
     if (board != nullptr) *reinterpret_cast<volatile unsigned *>(board + hw_slot) = (A.stamp << 16) | 0xffffu;
     if (valid && li == 0 && rr == 0 && !spare) {
         T.err[ib] = S.errflag;
         if (FAST && S.has(S.F_GUARD) && T.gcount != nullptr) { // to be run again with the reference's sequence
             T.glist[atomicAdd(T.gcount, 1)] = ib;
-            atomicAdd(T.gcount + BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
+            atomicAdd(T.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
         }
     }
     if (prof) {
@@ -991,7 +1009,12 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         any_refseq = any_refseq || (a.t[t].igr == 0 && a.t[t].refseq);
         any_modes = any_modes || a.t[t].mode > 1;
     }
-    const int build = (a.fast && any_phase) ? ((any_group || any_refseq) ? 1 : 2) : 0;
+    // (one model per wavefront and SwdMultiArgs::restart: the build with both sequences, guarded models restart in place)
+    static const bool no_restart = std::getenv("BH_SWD_NO_RESTART") != nullptr; // experiment switch
+    const bool restart = adapt && a.restart != 0 && a.fast && any_phase && !no_restart;
+    a.restart = restart ? 1 : 0;
+    if (info != nullptr) info->restarts_in_place = restart ? 1 : 0;
+    const int build = (a.fast && any_phase) ? ((any_group || any_refseq || restart) ? 1 : 2) : 0;
     static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
     const bool simple = !any_group && !any_modes && !no_simple;
     a.fast = build;

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
         A.err[ib] = S.errflag;
         if (FAST != 0 && S.has(S.F_GUARD) && A.gcount != nullptr) { // to be run again with the reference's sequence
             A.glist[atomicAdd(A.gcount, 1)] = ib;
-            atomicAdd(A.gcount + BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
+            atomicAdd(A.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
         }
     }
     if (A.neval != nullptr) {

@@ -60,7 +60,7 @@ def auto_spec_depth(nchains, budget=None):
 
 class DeviceChains(object):
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast_rayleigh"):
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast"):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
         torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
         (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
@@ -78,10 +78,12 @@ class DeviceChains(object):
         from the number of chains so that a launch stays in the latency regime (`auto_spec_depth`); 1 = one
         iteration per launch.  Results do not depend on it.
         search: root refinement of the dispersion search in the chains' evaluation launches (Engine.set_swd_search;
-        applied around every launch, the engine's own setting is left as it was).  Default "fast_rayleigh": Rayleigh
-        phase velocities within 1.2e-6 relative of the reference's, the reference's failure flags, Love and group
-        velocities the reference's bits -- what the chains sample does not change
-        (tests/test_gpu_device_chains.py::test_search_modes_sample_the_same_posterior), a window takes 13-22 % less.
+        applied around every launch, the engine's own setting is left as it was).  Default "fast" (the engine's own
+        default): fundamental-mode phase velocities within 1.2e-6 relative of the reference's, the reference's failure
+        flags (a model the guard fires on -- 2 % of a sampler's Love proposals -- starts again with the reference's
+        sequence inside its own wavefront of the window's launch), group velocities the reference's bits -- what the
+        chains sample does not change (tests/test_gpu_device_chains.py::test_search_modes_sample_the_same_posterior),
+        a window takes 22-27 % less.  "fast_rayleigh": the short refinement for the Rayleigh targets only.
         "reference": the reference's bits throughout (what `ChainBatch`, the replay of recorded reference runs, uses);
         None: whatever the engine is set to."""
         import torch

@@ -274,8 +274,9 @@ class Engine(object):
         return {SCAN_STEPS: "steps", SCAN_COUNTED: "counted"}.get(self._L.bh_engine_get_swd_scan(self._h), "auto")
 
     def guard_stats(self):
-        """(models per target of the last dispersion call that the guard of the "fast" search re-ran with the reference's
-        sequence, re-run launches enqueued since the engine was created)"""
+        """(models per target of the last dispersion call that the guard of the "fast" search ran again with the reference's
+        sequence -- in the re-run launch or, one model per wavefront, in place --, re-run launches enqueued since the engine
+        was created)"""
         counts = (C.c_int32 * 8)()
         n = C.c_uint64(0)
         self._check(self._L.bh_engine_guard_stats(self._h, counts, C.byref(n), None))

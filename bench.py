@@ -713,7 +713,7 @@ def make_summary(out):
     if isinstance(out.get("c5_full"), dict) and "config" in out["c5_full"]:
         sm["c5_full_swaps"] = out["c5_full"]["config"].get("accepted_swaps")
     sm["search"] = out["config"].get("search")
-    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..; search fast_rayleigh); _ref: reference sequence, value only"
+    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..); _ref: reference sequence, value only"
     return sm
 
 
@@ -733,14 +733,14 @@ def main():
                          "`value` is measured with (the reference's brackets, a three-evaluation refinement inside: velocities within "
                          "1.2e-6 relative of the reference's, north_star's tolerance 1e-5; failure flags the reference's); reference = "
                          "the reference's own sequence, bit-identical velocities (reported beside under reference_search).  Not given: "
-                         "fast for the evaluate workloads, fast_rayleigh for the chain workloads (DeviceChains' own default)")
+                         "fast")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rf-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last step (after the timed region)")
     args = ap.parse_args()
-    chain_search = args.search or "fast_rayleigh"
+    chain_search = args.search or "fast"   # (DeviceChains' own default)
     args.search = args.search or "fast"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -819,8 +819,6 @@ def main():
                 blocks[w] = {"error": repr(ex)}
         csteps = args.chain_steps or 600
         chain_workloads = ("c4", "c5") + (("c5_full",) if world == 1 else ())
-        # (DeviceChains' own default is "fast_rayleigh": Love proposals of a sampler trip the guard of "fast" on 2 % of the models,
-        #  and one guarded model costs a window a second launch -- include/bh_engine.h)
         eng.set_swd_search(chain_search)
         try:
             for w in chain_workloads:
@@ -843,7 +841,7 @@ def main():
                     alt[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=False)
                     if alt[w] is not None and alt_name != "reference":
                         alt[w]["models_rerun_by_the_guard"] = int((np.array(eng.guard_totals()) - g0).sum())
-                eng.set_swd_search("reference" if alt_name == "reference" else "fast_rayleigh")
+                eng.set_swd_search(alt_name)
                 for w in chain_workloads:
                     try:
                         alt[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
@@ -865,7 +863,7 @@ def main():
                 note = ("bh_engine_set_swd_search(BH_SEARCH_REFERENCE): the reference's own sequence of secular-function evaluations "
                         "(getsol + nevill), velocities bit-identical to surfdisp96 -- what the line's `value` was measured with up to "
                         "round 3" if alt_name == "reference" else
-                        "bh_engine_set_swd_search(BH_SEARCH_FAST) (chains: BH_SEARCH_FAST_RAYLEIGH): the engine's default search")
+                        "bh_engine_set_swd_search(BH_SEARCH_FAST): the engine's default search")
                 out[alt_name + "_search"] = {"note": note,
                                              **{w: ({k: b[k] for k in keep if k in b} if isinstance(b, dict) else b) for w, b in alt.items()}}
                 if isinstance(alt.get("c2"), dict) and alt["c2"].get("value"):

@@ -99,17 +99,20 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
  *     flag and the period from which a failed model's row is zero are the REFERENCE's: where the reference's own outcome
  *     hinges on a 1e-6 shift of its scan grid (a root and its mirror image around a half-space velocity closer together
  *     than a scan step) a guard detects the situation with one or two probe evaluations and the model is
- *     run again with the reference's sequence in a second, small launch of the same call (bh_engine_guard_stats).
+ *     run again with the reference's sequence -- in a second, small launch of the same call, or, in launches of one model
+ *     per wavefront, right away in the model's own wavefront (bh_engine_guard_stats counts both).
  *     A deterministic function of the model (independent of batch and launch plan), but NOT the
  *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
  * Also BH_SWD_SEARCH=reference|fast|fast_rayleigh in the environment at engine creation. */
 #define BH_SEARCH_REFERENCE 0
 #define BH_SEARCH_FAST 1
 /* BH_SEARCH_FAST for the Rayleigh phase-velocity targets only; Love targets keep the reference's sequence (with the counted
- * scan).  For launches of one model per wavefront -- a sampler's windows, single models --, where ONE guarded model costs the
- * call a second launch as long as a whole root search: the guard fires on ~2 % of a transdimensional sampler's Love proposals
- * (periods out to 60 s over models a few layers deep: the Love root creeps up to the half-space velocity) and on < 1e-5 of
- * its Rayleigh proposals (bench.py c4 / c5).  Rayleigh and Love targets of a call then run as two launches side by side. */
+ * scan).  The guard fires on ~2 % of a transdimensional sampler's Love proposals (periods out to 60 s over models a few layers
+ * deep: the Love root creeps up to the half-space velocity) and on < 1e-5 of its Rayleigh proposals (bench.py c4 / c5); this
+ * mode avoids those re-runs.  Since launches of one model per wavefront -- a sampler's windows, single models -- let a guarded
+ * model start again with the reference's sequence inside its own wavefront (no second launch; the guarded models of a window
+ * are its shallow ones and are done before its deep ones), BH_SEARCH_FAST is the faster of the two for samplers as well
+ * (c4 4.6 -> 5.2e4, c5 1.65 -> 1.83e5 chain-iterations/s) and what bayhunter_amd.DeviceChains takes. */
 #define BH_SEARCH_FAST_RAYLEIGH 2
 int bh_engine_set_swd_search(bh_engine *e, int search);
 int bh_engine_get_swd_search(const bh_engine *e);

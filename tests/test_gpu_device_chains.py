@@ -310,7 +310,7 @@ def test_posterior_statistics_match_reference_order_chains():
 
 
 def test_search_modes_sample_the_same_posterior():
-    """The chains' default search ("fast_rayleigh": Rayleigh roots within 1.2e-6 of the reference's instead of its bits) does
+    """The chains' default search ("fast": roots within 1.2e-6 of the reference's instead of its bits) does
     not change what they sample: the same problem sampled by 768 device chains with the reference's sequence and by 768
     others (other seeds) with the default; posterior summaries -- logL, number of nuclei, vp/vs, the three free noise
     parameters, vs at five depths -- agree within Monte-Carlo error (pairs of runs of ONE mode scatter up to 2.6 standard
@@ -338,13 +338,13 @@ def test_search_modes_sample_the_same_posterior():
         return np.concatenate(([likes.mean(), n.mean(), vpvs.mean(), noise[:, 1].mean(), noise[:, 2].mean(), noise[:, 3].mean()],
                                v.mean(axis=0)))
 
-    out = {"reference": [], "fast_rayleigh": []}
-    for search, seeds in (("reference", (77, 79, 81)), ("fast_rayleigh", (83, 85, 87))):
+    out = {"reference": [], "fast": []}
+    for search, seeds in (("reference", (77, 79, 81)), ("fast", (83, 85, 87))):
         for seed in seeds:
             dc = DeviceChains(targets(), N, init, priors, seed=seed, search=search).run()
             s = dc.samples("p2")
             out[search] += [summaries(s["models"][:, c], s["likes"][:, c], s["noise"][:, c], s["vpvs"][:, c]) for c in range(N)]
-    R, F = np.array(out["reference"]), np.array(out["fast_rayleigh"])
+    R, F = np.array(out["reference"]), np.array(out["fast"])
     z = (F.mean(axis=0) - R.mean(axis=0)) / np.sqrt(R.var(axis=0, ddof=1) / R.shape[0] + F.var(axis=0, ddof=1) / F.shape[0])
     assert np.all(np.abs(z) < 4.0), z
 

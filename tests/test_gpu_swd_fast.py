@@ -349,6 +349,36 @@ def test_joint_launch_with_the_default_search_matches_the_restatement_whatever_t
         engine.set_swd_search("reference")
 
 
+def test_guarded_models_restart_inside_their_own_wavefront_in_one_model_per_wavefront_launches(fast, oracle):
+    """A launch of one model per wavefront (a sampler's window, a small batch) takes the build with both sequences; a model the
+    guard fires on starts again with the reference's sequence in the same wavefront -- no re-run launch.  Thin models observed
+    out to 60 s (the guard fires on a fifth of them): the rows and flags of the restatement (which runs such a model a second
+    time with the reference's sequence), evaluation for evaluation; the guard statistics count the restarts."""
+    rs = np.random.RandomState(733)
+    per = np.linspace(2, 60, 30)
+    for B, L in ((120, 4), (300, 6)):
+        nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.2, ragged=True)
+        a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
+        for iwave in (1, 2):
+            launches0 = fast.guard_stats()[1]
+            fast.set_instrumentation(False, True)
+            try:
+                v, e = fast.swd_batch(nlay, h, vp, vs, rho, per, iwave, 0)
+                n = fast.last_neval()
+            finally:
+                fast.set_instrumentation(False, False)
+            counts, launches = fast.guard_stats()[:2]
+            oracle.swd_guarded_count(reset=True)
+            with restatement(oracle):
+                ov, oe, on = oracle.swd_batch(nlay, *a, per, iwave, 0)
+            og = oracle.swd_guarded_count(reset=True)
+            assert np.array_equal(v, ov) and np.array_equal(e, oe) and n == on, (B, L, iwave)
+            assert sum(counts) == og, (counts, og)
+            assert launches == launches0                    # in place: no re-run launch was enqueued
+            if iwave == 1 and L == 4:
+                assert og > 0                               # (the case is there to exercise the restart)
+
+
 def test_default_search_is_the_short_refinement(engine, oracle):
     """A fresh engine takes the guarded short refinement for fundamental-mode phase velocities (the bits of its CPU
     restatement) and the reference's sequence for everything else (group velocities, higher modes: the reference's bits);
