@@ -141,7 +141,8 @@ int bh_engine_get_swd_search(const bh_engine *e);
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
- * dispersion call that its guard sent back to the reference's sequence; *rerun_launches (may be NULL) = re-run launches
+ * dispersion call that its guard sent back to the reference's sequence (listed for the re-run launch, or restarted in place
+ * in a launch of one model per wavefront); *rerun_launches (may be NULL) = re-run launches
  * enqueued since the engine was created; total[t] (BH_MAX_TARGETS entries; may be NULL) = guarded models of the t-th dispersion
  * target of the calls since the engine was created.
  * Synchronises the engine's stream when counts or total is given. */
