@@ -2,21 +2,23 @@
 """bench.py -- forward-model + logL evaluations per second on N MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|c2|c3|c4|c5|c5_full|c2g|c3g] [--batch B]
-                    [--search reference|fast|fast_rayleigh]
+                    [--search reference|fast|fast_rayleigh] [--full] [--out bench_full.json]
 
-The default (--workload all) prints the c2 line -- the configuration the metric is quoted on -- and, inside the same
-JSON line, the other BASELINE configs as blocks timed the same way right after it: "c3" (configs[2], with an
-`rf_roofline` block for the receiver-function kernels measured alone on that configuration), "c2g" / "c3g" (the second
-runs of SURVEY.md 8(d)), "c4" and "c5" (configs[3] / [4] per-GPU shares: device-resident chains, chain-iterations/s, with
-the chains' default search), "c5_full" (configs[4] whole on one GPU, exchange sweeps inside the timed region; N = 1 only),
-"reference_search" (c2, c3 and the chains again with BH_SEARCH_REFERENCE, N = 1 only) and, as the LAST key, a "summary" of at
-most 600 characters with every value, ms per step and roofline fraction.
+Rank 0 prints ONE COMPACT JSON line (a few KB; tests/test_host_logic.py holds it under 8 KB): the c2 headline -- the
+configuration the metric is quoted on -- with `roofline`, `cpu_baseline`, a five-key `parity_check` and a `summary` of
+[value, ms/step] for the other BASELINE configs timed the same way right after it (c3 = configs[2], c2g / c3g = the second
+runs of SURVEY.md 8(d), c4 / c5 / c5_full = configs[3] / [4]: device-resident chains, chain-iterations/s).  Everything
+else every block measured goes to the file named by `full_record` (default bench_full.json beside this script).
+
+--full adds what the default run leaves out to stay under a minute: the same workloads again with the other dispersion
+search ("reference_search"), the receiver-function kernels alone ("rf_roofline"), the oracle port as a second CPU baseline
+and the sweep over CPU pool sizes.
 
 The line is measured with the engine's DEFAULT dispersion search (--search fast, bh_engine.h: the reference's brackets, a
 three-evaluation refinement inside them; velocities within 1.2e-6 relative of the reference's -- north_star's tolerance is
 1e-5 --, failure flags the reference's); `parity_check` states the velocities' largest relative difference against the
-oracle's restatement of the REFERENCE's sequence with that tolerance.  --search reference measures everything with the
-reference's own sequence (bit-identical velocities; the line of rounds 1-3) and reports the short one beside ("fast_search").
+oracle's restatement of the REFERENCE's sequence.  --search reference measures with the reference's own sequence
+(bit-identical velocities).
 
 A "step" is ONE pass of the hot path over one batch of B synthetic candidate models that are
 already resident in HBM: `bh_evaluate_batch` (C ABI, memspace = device) = every registered
@@ -38,13 +40,11 @@ Workloads (BASELINE.json configs):
 N > 1: one process per GPU (torchrun), independent batches per rank, no data-path collective
 (the path shards by model) -> "scaling": "weak"; barrier + max-over-ranks timing.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the Rayleigh dispersion
-kernel `swd_group_kernel`, Rayleigh + Love wavefronts in one launch): achieved = algorithmic bytes per launch / its average launch duration
-measured with HIP events on the launch stream during the timed region.  `cpu_baseline` is the
-reference's own Fortran / C++ (oracle/_ref, built from /root/reference where it exists; kind "reference")
-driven by a process pool on this box's host cores on a bounded sample of the same workload;
-`cpu_baseline_port` is the oracle (the bit-exact CPU restatement, OpenMP) on the same sample -- the two
-agree within a few per cent.  Without oracle/_ref the port is the baseline (kind "port").
+`roofline` is for the dominant kernel (the dispersion kernel `swd_group_kernel`, Rayleigh + Love wavefronts in one
+launch): achieved = algorithmic bytes per launch / its average launch duration measured with HIP events on the launch
+stream during the timed region.  `cpu_baseline` is the reference's own Fortran / C++ (oracle/_ref, built from
+/root/reference where it exists; kind "reference") driven by a process pool on this box's host cores on a bounded sample
+of the same workload; without oracle/_ref the oracle (the bit-exact CPU restatement, OpenMP) is the baseline (kind "port").
 """
 import argparse
 import json
@@ -176,9 +176,18 @@ def host_cpu_limits():
     return out
 
 
+def allowed_cpus():
+    """The CPUs this process may use: min(scheduler affinity, cgroup quota), at most 64."""
+    lim = host_cpu_limits()
+    n = lim.get("sched_affinity") or lim["os_cpu_count"] or 1
+    if lim.get("cgroup_cpu_quota"):
+        n = min(n, max(1, int(round(lim["cgroup_cpu_quota"]))))
+    return int(max(1, min(n, 64)))
+
+
 def cpu_baseline_reference(spec, batch, noise, workload, worker_counts=None):
-    """The compiled reference on this box's host cores (process pool), bounded to ~20 s of CPU work.
-    worker_counts: the pool sizes to probe (default: 8 ... os.cpu_count())."""
+    """The compiled reference on this box's host cores (process pool), bounded to ~15-20 s of CPU work.
+    worker_counts: the pool sizes to probe (default: one pool of allowed_cpus() workers; --full sweeps)."""
     global _REF_JOB
     import multiprocessing as mp
     nlay, h, vp, vs, rho = batch
@@ -205,11 +214,19 @@ def cpu_baseline_reference(spec, batch, noise, workload, worker_counts=None):
                 best_dt = dt if best_dt is None else min(best_dt, dt)
             return per * nproc / best_dt
 
-    cands = sorted({c for c in (worker_counts or (16, 32, 64, 128, ncpu)) if c <= ncpu}) or [ncpu]
-    probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
-    best = max(probe, key=probe.get)
-    n = int(max(4 * best, min(20.0 / per_model, 6.0 * probe[best])))
+    if worker_counts is None:     # default: ONE pool of as many workers as this process may use (affinity / cgroup quota)
+        worker_counts = (allowed_cpus(),)
+    cands = sorted({c for c in worker_counts if c <= ncpu}) or [ncpu]
+    if len(cands) > 1:
+        probe = {c: rate(c, max(2 * c, int(0.3 * c / per_model / 4))) for c in cands}
+        best = max(probe, key=probe.get)
+        n = int(max(4 * best, min(20.0 / per_model, 6.0 * probe[best])))
+    else:
+        best = cands[0]
+        probe = {}
+        n = int(max(4 * best, 15.0 / per_model))                      # ~15 s of CPU work
     value = rate(best, n, reps=2)
+    probe.setdefault(best, value)
     return {"value": value, "unit": "evals/s", "cores": best, "kind": "reference", "host_cpus": host_cpu_limits(),
             "rate_by_workers": {str(c): probe[c] for c in sorted(probe)},
             "sample": "%d models of the %s batch: forward models by the reference's own surfdisp96.f / rfmini compiled with "
@@ -502,7 +519,7 @@ def rf_roofline(eng, spec, d_batch, B, L, dev, reps=20):
             "rf_per_s": B / (ms * 1e-3)}
 
 
-def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True, light_cpu=False, rf_roof=True):
+def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True, rf_roof=True):
     """One evaluate workload (c2 / c3 / c2g / c3g): untimed clock warm-up, `--warmup` steps, then EXACTLY `--steps`
     steps between barrier + synchronize on both sides, max over ranks.  Returns the result block on rank 0."""
     import torch
@@ -595,8 +612,9 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
             **pmc_stamp(pmc, swd_ms_per_launch),
-            "traffic_note": "7 x the algorithmic bytes, none of it model data: the wavefronts' progress board (a word per hardware "
-                            "wavefront slot, polled every 8 rounds; 14 MB with BH_SWD_NO_BOARD=1) -- ~10 GB/s, a thousandth of the HBM peak",
+            "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+            "traffic_note": "what exceeds the algorithmic bytes is not model data: the wavefronts' progress board (a word per hardware "
+                            "wavefront slot, polled every 8 rounds) -- ~10 GB/s, a thousandth of the HBM peak",
             "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
             "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
@@ -652,7 +670,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
             out["parity_check"].update(synthetics_check(spec, batches[(args.warmup + args.steps - 1) % NPOOL], noise, d_ymod, d_logL, d_err))
         except Exception as ex:
             out["parity_check"] = {"n": 0, "error": repr(ex)}
-    if any(s["kind"] == E.TARGET_RF for s in spec) and not args.no_rf_roofline and rf_roof:
+    if any(s["kind"] == E.TARGET_RF for s in spec) and args.full and not args.no_rf_roofline and rf_roof:
         try:
             out["rf_roofline"] = rf_roofline(eng, spec, d_batches[0], B, L, dev)
         except Exception as ex:
@@ -665,7 +683,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
             have_ref = refshim.available() and workload in ("c2", "c3", "c2g")
         except Exception:
             pass
-        if not (light_cpu and have_ref):     # (inside --workload all the c3 block times the reference only: run time)
+        if args.full or not have_ref:        # the oracle port: the baseline where oracle/_ref is absent, beside it with --full
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, workload)
             except Exception as ex:  # the baseline must never take the GPU number down with it
@@ -674,20 +692,24 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
         if have_ref:
             try:
                 # north_star: "next to the reference CPU Fortran path timed on the same box's host cores":
-                # the reference's own compiled code is the baseline, the port is kept beside it
-                ref = cpu_baseline_reference(spec, batches[0], noise, workload, (16, 32, 64, 96) if light_cpu else None)
+                # the reference's own compiled code is the baseline, the port is kept beside it (--full)
+                ref = cpu_baseline_reference(spec, batches[0], noise, workload, (16, 32, 64, 128, os.cpu_count() or 1) if args.full else None)
                 if "cpu_baseline" in out:
                     out["cpu_baseline_port"] = out["cpu_baseline"]
                 out["cpu_baseline"] = ref
             except Exception as ex:
                 out["cpu_baseline_reference_error"] = repr(ex)
+                if "cpu_baseline" not in out:
+                    try:
+                        out["cpu_baseline"] = cpu_baseline(spec, batches[0], noise, workload)
+                    except Exception as ex2:
+                        out["cpu_baseline"] = {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex2,)}
         out["cpu_baseline_wall_s"] = time.perf_counter() - t_cpu
     return out
 
 
 def make_summary(out):
-    """<= 600 characters, the LAST key of the line (the driver keeps the tail of long lines): every workload's value and
-    ms per step, c3 / c2, both roofline fractions."""
+    """Every workload's [value, ms per step], c3 / c2, both roofline fractions: a few hundred characters."""
     def vm(b, nd=4):
         if not isinstance(b, dict) or b.get("value") is None:
             return None
@@ -710,11 +732,79 @@ def make_summary(out):
     if isinstance(rf, dict) and "frac" in rf:
         sm["rf_frac_hbm"] = float("%.3g" % rf["frac"])
         sm["rf_frac_fp64"] = float("%.3g" % rf["binding"]["frac"])
-    if isinstance(out.get("c5_full"), dict) and "config" in out["c5_full"]:
-        sm["c5_full_swaps"] = out["c5_full"]["config"].get("accepted_swaps")
+    for w in ("c5", "c5_full"):
+        if isinstance(out.get(w), dict) and "config" in out[w]:
+            sm[w + "_swaps"] = out[w]["config"].get("accepted_swaps")
     sm["search"] = out["config"].get("search")
-    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..); _ref: reference sequence, value only"
+    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..)"
     return sm
+
+
+LINE_LIMIT = 8000      # the driver parses the line out of an 8 KB tail of stdout (BENCH_r04: a 24.6 KB line was not parsed)
+
+
+def _sig(x, nd=6):
+    """Numbers to `nd` significant digits (the line is a record, not an archive: the archive is bench_full.json)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (float, np.floating)):
+        return float("%.*g" % (nd, float(x))) if np.isfinite(x) else None
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _sig(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full, full_path=None):
+    """The ONE line rank 0 prints: the contract's keys, `roofline` (+ binding), `cpu_baseline`, a five-key `parity_check`
+    and the summary -- a whitelist, so that whatever the blocks grow by lands in the full record and never in the line."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data", "error"))
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "batch_per_gpu", "layers", "periods", "targets", "search", "parallelism",
+                                 "chains_per_gpu", "accepted_swaps"))
+    roof = full.get("roofline")
+    if isinstance(roof, dict):
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel",
+                         "kernel_ms_per_launch", "algorithmic_bytes_per_launch", "pmc_stale"))
+        if isinstance(roof.get("binding"), dict):
+            r["binding"] = _pick(roof["binding"], ("bound", "achieved", "peak", "unit", "frac", "valu_busy", "active_lane_frac"))
+        line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        line["cpu_baseline"] = c
+    pc = full.get("parity_check")
+    if isinstance(pc, dict):
+        line["parity_check"] = _pick(pc, ("n", "failure_flags_equal", "max_rel_velocity", "velocity_tolerance",
+                                          "max_rel_logL_of_the_device_synthetics", "max_abs_logL", "error"))
+    for k in ("kernel_ms_per_step", "rank_ms_per_step", "collective_check", "speculation"):
+        if k in full:
+            v = full[k]
+            if k == "rank_ms_per_step":
+                v = _pick(v, ("min", "max"))
+            if k == "speculation":
+                v = _pick(v, ("depth", "evaluation_launches", "iterations_per_launch", "ms_per_launch"))
+            line[k] = v
+    if full_path:
+        line["full_record"] = full_path
+    if "summary" in full:
+        line["summary"] = full["summary"]
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:      # cannot happen with the whitelist above; if it ever does, the contract's keys survive
+        for k in ("summary", "kernel_ms_per_step", "speculation", "parity_check"):
+            line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
 
 
 def main():
@@ -723,19 +813,18 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="all", choices=["all", "c2", "c3", "c2g", "c3g", "c4", "c5", "c5_full"],
-                    help="all (default): the c2 line (headline) carrying c3, c4 and c5 blocks; or one workload")
+                    help="all (default): the c2 line (headline) with the other configs in its summary; or one workload")
     ap.add_argument("--chains", type=int, default=0, help="c4/c5: chains per GPU (default 8 / 64)")
     ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
                     "--workload c4/c5, 600 inside --workload all)")
     ap.add_argument("--spec-depth", type=int, default=0, help="c4/c5: iterations per evaluation launch (0 = automatic)")
     ap.add_argument("--search", default=None, choices=["reference", "fast", "fast_rayleigh"],
                     help="root refinement of the dispersion search (bh_engine_set_swd_search): fast = the engine's default, what "
-                         "`value` is measured with (the reference's brackets, a three-evaluation refinement inside: velocities within "
-                         "1.2e-6 relative of the reference's, north_star's tolerance 1e-5; failure flags the reference's); reference = "
-                         "the reference's own sequence, bit-identical velocities (reported beside under reference_search).  Not given: "
-                         "fast")
+                         "`value` is measured with; reference = the reference's own sequence, bit-identical velocities")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
+    ap.add_argument("--full", action="store_true", help="also: the other search, the RF kernels alone, the port baseline, the CPU pool sweep")
+    ap.add_argument("--out", default=os.path.join(REPO, "bench_full.json"), help="where the full record of every block is written")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rf-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last step (after the timed region)")
@@ -799,6 +888,7 @@ def main():
     from bayhunter_amd import engine as E
     eng = E.Engine(local_rank)
     eng.set_swd_search(args.search)
+    t_start = time.perf_counter()
     out = None
     if args.workload in ("c4", "c5", "c5_full"):
         eng.set_swd_search(chain_search)   # (not given: the chains' own default, see below)
@@ -806,15 +896,14 @@ def main():
     elif args.workload != "all":
         out = run_eval(args, eng, rank, world, dist, dev, args.workload, dryrun)
     else:
-        # the headline line (c2, the configuration the metric is quoted on) carrying the other BASELINE configs as blocks:
-        # c3 = configs[2] (same --steps / --warmup, its own timed region), c4 / c5 = configs[3] / [4] per-GPU shares
+        # the headline (c2, the configuration the metric is quoted on); the other BASELINE configs as blocks of the full
+        # record and [value, ms/step] pairs of the line's summary: c3 = configs[2] (same --steps / --warmup, its own timed
+        # region), c4 / c5 = configs[3] / [4] per-GPU shares
         out = run_eval(args, eng, rank, world, dist, dev, "c2", dryrun)
         blocks = {}
-        blocks["c3"] = run_eval(args, eng, rank, world, dist, dev, "c3", dryrun, light_cpu=True)
-        # the "second runs" of SURVEY.md 8(d): group velocities, Gauss law (no CPU leg)
-        for w in ("c2g", "c3g"):
+        for w in ("c3", "c2g", "c3g"):       # configs[2] and the "second runs" of SURVEY.md 8(d) (no CPU leg)
             try:
-                blocks[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=False)
+                blocks[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=(w == "c3"))
             except Exception as ex:
                 blocks[w] = {"error": repr(ex)}
         csteps = args.chain_steps or 600
@@ -828,12 +917,9 @@ def main():
                     blocks[w] = {"error": repr(ex)}
         finally:
             eng.set_swd_search(args.search)
-        # (the chain blocks above ran with the chains' own default where the line's search is the engine's default)
-        # the same workloads with the OTHER root refinement, reported beside and never as `value`: the reference's sequence
-        # (bit-identical velocities) where the line is measured with the engine's default, the short refinement where the
-        # line was asked for with --search reference
+        # --full: the same workloads with the OTHER root refinement, reported beside and never as `value`
         alt, alt_name = {}, ("reference" if args.search != "reference" else "fast")
-        if world == 1 or os.environ.get("BH_BENCH_ALT_BLOCK", "0") == "1":   # (a supplement: at N = 1 only)
+        if args.full and (world == 1 or os.environ.get("BH_BENCH_ALT_BLOCK", "0") == "1"):   # (a supplement: at N = 1 only)
             try:
                 eng.set_swd_search(alt_name)
                 for w in ("c2", "c3"):
@@ -845,8 +931,6 @@ def main():
                 for w in chain_workloads:
                     try:
                         alt[w] = run_chains(args, eng, rank, world, dist, dev, w, csteps, max(100, csteps // 2))
-                        if alt[w] is not None:
-                            alt[w]["accepted_swaps"] = alt[w]["config"].get("accepted_swaps")
                     except Exception as ex:
                         alt[w] = {"error": repr(ex)}
             except Exception as ex:
@@ -855,28 +939,26 @@ def main():
                 eng.set_swd_search(args.search)
         if rank == 0:
             c3 = blocks["c3"]
-            c3["ratio_to_c2_ms_per_step"] = c3["ms_per_step"] / out["ms_per_step"]
+            if isinstance(c3, dict) and c3.get("ms_per_step"):
+                c3["ratio_to_c2_ms_per_step"] = c3["ms_per_step"] / out["ms_per_step"]
             out.update(blocks)
             if alt:
-                keep = ("value", "unit", "ms_per_step", "ms_per_step_stats", "kernel_ms_per_step", "kernel_ms_per_launch", "parity_check",
-                        "models_rerun_by_the_guard", "failed_models_last_step", "search", "speculation", "accepted_swaps", "error")
-                note = ("bh_engine_set_swd_search(BH_SEARCH_REFERENCE): the reference's own sequence of secular-function evaluations "
-                        "(getsol + nevill), velocities bit-identical to surfdisp96 -- what the line's `value` was measured with up to "
-                        "round 3" if alt_name == "reference" else
-                        "bh_engine_set_swd_search(BH_SEARCH_FAST): the engine's default search")
-                out[alt_name + "_search"] = {"note": note,
-                                             **{w: ({k: b[k] for k in keep if k in b} if isinstance(b, dict) else b) for w, b in alt.items()}}
-                if isinstance(alt.get("c2"), dict) and alt["c2"].get("value"):
-                    out[alt_name + "_search"]["c2"]["ratio_to_the_lines_value"] = alt["c2"]["value"] / out["value"]
+                out[alt_name + "_search"] = alt
             out["summary"] = make_summary(out)
     if rank == 0 and out is not None:
         if comm is not None:
             out["collective_check"] = comm
-        if "summary" in out:                # (the summary stays the LAST key of the line)
-            out["summary"] = out.pop("summary")
+        out["bench_wall_s"] = time.perf_counter() - t_start
+        full_path = None
+        try:
+            with open(args.out, "w") as f:
+                json.dump(out, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else repr(o))
+            full_path = os.path.relpath(args.out, REPO) if os.path.abspath(args.out).startswith(REPO) else args.out
+        except OSError:
+            pass
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, full_path), flush=True)
         os.dup2(2, 1)
     if world > 1:
         dist.barrier()

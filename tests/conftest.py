@@ -42,10 +42,15 @@ def _reference_search(request):
     """The GPU parity tests compare bits with the reference: every gpu-marked test starts with the process-wide engine on the
     REFERENCE's root refinement (the engine's own default is the short one, bh_engine.h; the tests of that mode select it
     themselves and `test_gpu_swd_fast.py::test_default_search_is_the_short_refinement` looks at a fresh engine)."""
-    if request.node.get_closest_marker("gpu") is not None:
-        from bayhunter_amd import engine as E
-        E.default_engine(0).set_swd_search("reference")
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from bayhunter_amd import engine as E
+    eng = E.default_engine(0)
+    before = eng.swd_search()
+    eng.set_swd_search("reference")
     yield
+    eng.set_swd_search(before)       # (what a test selected does not leak into the next one)
 
 
 def rows(a, nlay):

@@ -175,3 +175,35 @@ def test_weighted_values_repeat_rows_like_the_reference():
     assert np.array_equal(wn, noise[rows]) and np.array_equal(wv, vpvs[rows])
     assert ModelMatrix.get_weightedvalues(w, likes=likes)[0] is None
     assert np.array_equal(ModelMatrix.get_weightedvalues(w, misfits=[1., 2., 3.])[2], np.array([1., 1., 3., 3., 3.]))
+
+
+def test_bench_line_stays_compact_and_parseable():
+    """bench.py prints ONE line the driver parses out of an 8 KB tail of stdout (BENCH_r04: a 24.6 KB line was not parsed):
+    the line builder on a canned full record (round 4's 24.6 KB record, blown up further) stays under 8000 bytes and keeps
+    the contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench_default_final.json")))
+    full["some_future_block"] = {"k%d" % i: "x" * 100 for i in range(500)}       # whatever the blocks grow by stays out
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    text = bench.compact_line(full, "bench_full.json")
+    assert "\n" not in text and len(text) < bench.LINE_LIMIT and len(text) < 4096
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check", "summary", "full_record"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["config"]["workload"].startswith("joint Rayleigh+Love")
+    assert line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["binding"]["frac"] > 0
+    assert line["cpu_baseline"]["cores"] == 16 and line["cpu_baseline"]["kind"] == "reference"
+    assert len(line["parity_check"]) <= 6 and line["parity_check"]["failure_flags_equal"] is True
+    # an N > 1 line carries the collective check and the per-rank spread and obeys the same limit
+    full["collective_check"] = {"backend": "nccl", "world_size": 8, "ranks_seen_by_all_reduce": 8, "rccl_ranks": 8, "devices": 8}
+    full["rank_ms_per_step"] = {"min": 2.2, "max": 2.4, "all": [2.3] * 8}
+    line8 = json.loads(bench.compact_line(full, None))
+    assert line8["collective_check"]["rccl_ranks"] == 8 and "all" not in line8["rank_ms_per_step"]
+    assert len(bench.compact_line(full, None)) < 4096
