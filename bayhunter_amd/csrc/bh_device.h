@@ -130,6 +130,7 @@ struct SwdMultiArgs {
                        // own model (swd_group_kernel<.., ADAPT>); 0: the caller fixed lanes or trials (experiments)
     int counted;       // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
     int rerun;         // 1: the launch re-runs listed models (SwdTarget::count): plain two-dimensional grid, no SIMD pairing
+    int prescan;       // 1: scans look ahead over their grid with the certified-sign evaluation (SearchT<.., PRE>; same bits)
     int restart;       // 1: in a launch of one model per wavefront a model the guard fires on starts again with the reference's
                        //    sequence in its own wavefront (the build with both sequences) instead of being listed for a re-run launch
     SwdTarget t[8];
@@ -218,3 +219,6 @@ struct LikeKernelArgs {
 void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream);
 
 void bh_launch_probe(int op, int n, const double *in, double *out, hipStream_t stream);
+// the certified-sign evaluation (swd_csign.h) of n (omega, c) points of ONE model (mdl: h, vp, vs, rho, nlay floats each):
+// out = [val n][bound n][certified n]
+void bh_launch_csign_probe(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out, hipStream_t stream);

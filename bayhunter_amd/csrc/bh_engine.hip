@@ -77,6 +77,7 @@ struct bh_engine {
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
+    int swd_prescan = 1; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits)
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
@@ -447,7 +448,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         e->guard_last = any_fast;
         if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
-        ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan;
+        ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan; ra.prescan = e->swd_prescan;
         if (any_fast) {
             if (!e->board.p) {
                 if ((rc = ensure(e, e->board, (size_t)BH_BOARD_WORDS * sizeof(unsigned)))) return rc;
@@ -530,6 +531,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         return t.igr == 0 && t.mode <= 1 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && t.iwave == BH_WAVE_RAYLEIGH));
     };
     a.counted = e->swd_scan;
+    a.prescan = e->swd_prescan;
     for (int t = 0; t < a.ntargets; ++t) {
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
         if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
@@ -744,6 +746,7 @@ int bh_engine_create(int device, bh_engine **out)
     if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
     if (const char *g = std::getenv("BH_SWD_SEARCH"))
         e->swd_search = (g[0] == 'f' || g[0] == '1') ? ((std::strstr(g, "rayleigh") != nullptr) ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (g[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_REFERENCE);
+    if (const char *g = std::getenv("BH_SWD_PRESCAN")) e->swd_prescan = (g[0] == '0') ? 0 : 1;
     if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == '0') ? BH_SCAN_STEPS : ((g[0] == 'c' || g[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
     if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
         e->love_inlook = std::atoi(g);
@@ -791,6 +794,14 @@ int bh_engine_set_swd_scan(bh_engine *e, int scan)
     return BH_OK;
 }
 int bh_engine_get_swd_scan(const bh_engine *e) { return e ? e->swd_scan : 0; }
+
+int bh_engine_set_swd_prescan(bh_engine *e, int on)
+{
+    if (!e) return BH_EINVAL;
+    e->swd_prescan = on ? 1 : 0;
+    return BH_OK;
+}
+int bh_engine_get_swd_prescan(const bh_engine *e) { return e ? e->swd_prescan : 0; }
 
 int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches, uint64_t *total)
 {
@@ -1361,6 +1372,37 @@ int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out)
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(out, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return BH_OK;
+}
+
+int bh_probe_csign(bh_engine *e, int iwave, int nlay, const float *h, const float *vp, const float *vs, const float *rho,
+                   int n, const double *omega, const double *c, double *val, double *bound, int32_t *certified)
+{
+    if (!e || n < 0 || nlay < 2 || nlay > 100 || !h || !vp || !vs || !rho || !omega || !c || !val || !bound || !certified ||
+        (iwave != BH_WAVE_LOVE && iwave != BH_WAVE_RAYLEIGH))
+        return BH_EINVAL;
+    if (n == 0) return BH_OK;
+    int rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    // in: [4 * nlay floats, padded to doubles][omega n][c n]; out: [val n][bound n][certified n (as doubles)]
+    const size_t mwords = ((size_t)4 * nlay + 1) / 2;
+    if ((rc = ensure(e, e->probe_in, (mwords + (size_t)2 * n) * sizeof(double)))) return rc;
+    if ((rc = ensure(e, e->probe_out, (size_t)3 * n * sizeof(double)))) return rc;
+    char *in = (char *)e->probe_in.p;
+    const float *src[4] = {h, vp, vs, rho};
+    for (int k = 0; k < 4; ++k)
+        HIPCHK(e, hipMemcpyAsync(in + (size_t)k * nlay * sizeof(float), src[k], (size_t)nlay * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    double *din = (double *)e->probe_in.p + mwords;
+    HIPCHK(e, hipMemcpyAsync(din, omega, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(din + n, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    bh_launch_csign_probe(iwave, nlay, (const float *)e->probe_in.p, n, din, din + n, (double *)e->probe_out.p, e->stream);
+    HIPCHK(e, hipGetLastError());
+    std::vector<double> tmp((size_t)n);
+    HIPCHK(e, hipMemcpyAsync(val, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(bound, (double *)e->probe_out.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(tmp.data(), (double *)e->probe_out.p + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; ++i) certified[i] = tmp[(size_t)i] != 0.0 ? 1 : 0;
     return BH_OK;
 }
 

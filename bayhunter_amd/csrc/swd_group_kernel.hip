@@ -39,6 +39,26 @@ namespace {
 // only pins the compiler's ordering.  Look-ahead, Love's in-group trials, the processing order and the
 // two depth classes of ragged batches are described at their code.
 // =================================================================================================
+// The certified-sign evaluation of ONE grid point by one lane (swd_csign.h), OUT OF LINE: it needs ~160 registers of its own,
+// the round loop around it keeps ~200 live; as a call the loop's values stay in their registers (or are saved around the call
+// by the calling convention) and the loop itself is compiled as before.  The model is read from the wavefront's LDS region:
+// mdl = byte offset of its [4][Lmax][MPW] float block inside the workgroup's dynamic LDS, col = the model's column.
+// Returns bit 0 = certified, bit 1 = the value is negative.
+__device__ __attribute__((noinline)) int csign_point(int ifunc, int mdl, int rows_x_mpw, int mpw, int col, int mmax, int llw, double omega, double c)
+{
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    const float *m0 = reinterpret_cast<const float *>(smem_all + mdl);
+    ModelLdsRt md;
+    md.S = mpw;
+    md.d = m0 + col;
+    md.a = m0 + rows_x_mpw + col;
+    md.b = m0 + 2 * rows_x_mpw + col;
+    md.rho = m0 + 3 * rows_x_mpw + col;
+    double v, bd;
+    const bool cert = (ifunc == 2) ? csign::rayleigh(md, mmax, llw, omega, c, v, bd) : csign::love(md, mmax, llw, omega, c, v, bd);
+    return (cert ? 1 : 0) | ((v < 0.0) ? 2 : 0);
+}
+
 constexpr int CA_STRIDE = 26;
 constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used): up to 4 trials share a row
 
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
 
     constexpr bool FAST = FASTM != 0;
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
-    SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
+    SearchT<0, NEV_MAX, FASTM, SIMPLE, true> S;
     S.XS = MPW;
     // RESTART (one model per wavefront, the build with both sequences, SwdMultiArgs::restart): when the guard of the short
     // refinement fires, the model starts again right here with the reference's sequence -- what the engine's re-run launch
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     unsigned evals_before = 0u; // (evaluations of the abandoned first search: they count, as the re-run launch's would)
 restart_with_the_reference_sequence:
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, A.prescan != 0);
     S.evals += evals_before;
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
@@ -372,6 +392,72 @@ restart_with_the_reference_sequence:
             else __builtin_amdgcn_s_setprio(1);
         }
         ++nrounds;
+        // ---- the certified-sign scan (SearchT, swd_csign.h): models that start a period's search look ahead over the scan's
+        // grid, one lane per grid point (the lanes of the model: LPM points a look), until a grid point is not proven to
+        // have the start value's sign; then they land two steps before it, or decline (the reference's steps).
+        if (__ballot(S.active && S.st == ST_PRE) != 0ull) {
+            const long long tp0 = prof ? clock64() : 0;
+            const int pidx = spare ? 0 : lane - g * LPM; // this lane's grid point inside a look (spare lanes: clones of lane 0)
+            const unsigned long long mine = (LPM >= 64) ? ~0ull : (((1ull << LPM) - 1ull) << (g * LPM)); // this model's lanes
+            bool pending = S.active && S.st == ST_PRE, landing = false, neg0 = false;
+            // (what the look-ahead needs of the search state)
+            const double p_c1 = S.c1, p_om = S.omega, p_cm = S.cm, p_hi = S.betmxd + S.dc, p_clow = S.clow, p_vsafe = S.vsafe;
+            const bool p_first = S.ifirst == 1, p_neg1st = signs_differ(S.del1st, 0.0);
+            double gi = p_c1;
+            for (int i = 0; i < pidx; ++i) gi = gi + S.dc;
+            int base = 0, jj = 0;
+            unsigned npts = 0;
+            while (__ballot(pending) != 0ull) {
+                
+                const int cs_ = csign_point(ifunc, (int)(reinterpret_cast<unsigned char *>(mdl) - smem_all), Lmax * MPW, MPW, g, mmax, llw, p_om, gi);
+                const bool cert = (cs_ & 1) != 0;
+
+                const bool neg = (cs_ & 2) != 0;
+                const bool c0 = __shfl((int)cert, g * LPM) != 0, n0 = __shfl((int)neg, g * LPM) != 0;
+                if (pending && base == 0) { // the first look: the start value's proven sign decides the direction
+                    neg0 = n0;
+                    if (!(c0 && (p_first || n0 == p_neg1st))) pending = false; // (declined: SearchT::pre_upward)
+                }
+                const int idx = base + pidx;
+                // (SearchT::pre_plain: may the scan simply step on at this grid point?)
+                const bool ok = cert && neg == neg0 && (idx == 0 || (!(gi < p_cm || gi >= p_hi) && gi > p_clow && gi < p_vsafe)) && idx < S.pre_max_points;
+                const unsigned long long bad = ~__ballot(ok) & mine;
+                if (pending) {
+                    ++npts;
+                    if (bad != 0ull) {
+                        jj = base + (int)__builtin_ctzll(bad) - g * LPM;
+                        pending = false;
+                        landing = true;
+                    } else {
+                        base += LPM;
+                        for (int i = 0; i < LPM; ++i) gi = gi + S.dc;
+                    }
+                }
+            }
+            if (S.active && S.st == ST_PRE) {
+                if (landing && jj >= 3) {
+                    double gm2 = S.c1;
+                    for (int i = 0; i < jj - 2; ++i) gm2 = gm2 + S.dc;
+                    S.pre_land(gm2, gm2 + S.dc, neg0);
+                } else {
+                    S.pre_decline();
+                }
+            }
+            if (prof) {
+                const bool rep = valid && !spare;
+                unsigned long long np = rep ? npts : 0u, nl = (rep && pidx == 0 && landing && jj >= 3) ? 1u : 0u;
+                for (int off = 32; off > 0; off >>= 1) {
+                    np += __shfl_xor(np, off);
+                    nl += __shfl_xor(nl, off);
+                }
+                if (lane == 0) {
+                    atomicAdd(A.neval + 12, np);                                       // certified-sign evaluations
+                    atomicAdd(A.neval + 13, nl);                                       // landings
+                    atomicAdd(A.neval + 14, 1ull);                                     // wavefront-rounds with a look-ahead
+                    atomicAdd(A.neval + 15, (unsigned long long)(clock64() - tp0));    // their wave-cycles
+                }
+            }
+        }
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (prof) t0 = clock64();
         const double omg = S.omega;

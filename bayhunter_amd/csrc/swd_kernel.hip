@@ -642,3 +642,33 @@ double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, 
     return best;
 }
 
+
+// ---- probe of the certified-sign evaluation (tests: bit-equality with oracle/csign_oracle.c) ----
+namespace {
+struct ModelGlobalF { // the model's float arrays in global memory, the accessors of ModelLds
+    const float *d, *a, *b, *rho;
+    __device__ __forceinline__ float Df(int m) const { return d[m]; }
+    __device__ __forceinline__ float Af(int m) const { return a[m]; }
+    __device__ __forceinline__ float Bf(int m) const { return b[m]; }
+    __device__ __forceinline__ double D(int m) const { return (double)d[m]; }
+    __device__ __forceinline__ double A(int m) const { return (double)a[m]; }
+    __device__ __forceinline__ double Bv(int m) const { return (double)b[m]; }
+    __device__ __forceinline__ double R(int m) const { return (double)rho[m]; }
+};
+__global__ void csign_probe_kernel(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    ModelGlobalF md{mdl, mdl + nlay, mdl + 2 * nlay, mdl + 3 * nlay};
+    const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
+    double v, bd;
+    const bool ok = (iwave == 2) ? csign::rayleigh(md, nlay, llw, omega[i], c[i], v, bd) : csign::love(md, nlay, llw, omega[i], c[i], v, bd);
+    out[i] = v;
+    out[n + i] = bd;
+    out[2 * (size_t)n + i] = ok ? 1.0 : 0.0;
+}
+} // namespace
+void bh_launch_csign_probe(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(csign_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, iwave, nlay, mdl, n, omega, c, out);
+}

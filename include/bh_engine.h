@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 7
+#define BH_ABI_VERSION 8
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -140,6 +140,16 @@ int bh_engine_get_swd_search(const bh_engine *e);
 #define BH_SCAN_AUTO 2
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
+
+/* The certified-sign scan (on by default; results are bit-identical either way).  getsol's bracket scan
+ * (surfdisp96.f:437-460) consumes only the SIGN of the secular function at its grid points; with this on, a search first
+ * evaluates the grid ahead with a cheap evaluation of the same recursion that carries an error bound (one lane per grid
+ * point), and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's -- the
+ * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
+ * step-by-step scan, with 2-3 reference-exact evaluations per scan instead of ~15.  Applies to both root refinements, all
+ * targets of the lanes-per-model kernel (batches below ~16 000 models per call).  0: every step evaluated. */
+int bh_engine_set_swd_prescan(bh_engine *e, int on);
+int bh_engine_get_swd_prescan(const bh_engine *e);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
  * dispersion call that its guard sent back to the reference's sequence (listed for the re-run launch, or restarted in place
  * in a launch of one model per wavefront); *rerun_launches (may be NULL) = re-run launches
@@ -341,6 +351,11 @@ int bh_chain_accept_window(void *stream, const bh_chain_config *cfg, const bh_ch
  * sin / cos / exp through the kernels' glibc-exact restatement (csrc/bh_libm.h).  Used by the tests to document how far the
  * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
 int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
+/* Diagnostic: the certified-sign evaluation (see bh_engine_set_swd_prescan) of n (omega, c) points of one model of nlay
+ * layers (host float arrays): val = the surface value under the per-layer max-norm scaling, bound = its error bound,
+ * certified = |val| > 2 bound.  tests/test_gpu_csign.py compares the three with oracle/csign_oracle.c bit for bit. */
+int bh_probe_csign(bh_engine *e, int iwave, int nlay, const float *h, const float *vp, const float *vs, const float *rho,
+                   int n, const double *omega, const double *c, double *val, double *bound, int32_t *certified);
 
 /* Instrumentation (off by default; bench.py and the tests turn it on).
  *   timing:   HIP events are recorded on the stream the kernels are launched on, around each

@@ -24,7 +24,7 @@ def test_library_built_and_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), "missing export %s" % name
     assert sorted(E.EXPORTED_SYMBOLS) == decl
-    assert lib.bh_abi_version() == 7
+    assert lib.bh_abi_version() == 8
 
 
 def test_python_constants_mirror_the_header():

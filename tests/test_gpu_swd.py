@@ -253,6 +253,7 @@ def test_lookahead_does_not_change_results(engine, G, J):
     vp[0, :8] = 1.5
     vs[:, 8:12] *= 0.2                   # and some that fail the search
     per = np.linspace(1.5, 70, 35)
+    engine.set_swd_prescan(False)        # (evaluation counts are compared; the certified-sign scan: test_gpu_csign.py)
     try:
         for iwave, igr in REFS.values():
             for mode in (1, 3):
@@ -267,6 +268,7 @@ def test_lookahead_does_not_change_results(engine, G, J):
                 assert np.array_equal(v1, v2) and np.array_equal(e1, e2), (iwave, igr, mode)
                 assert n1 == n2 and n1 > 0
     finally:
+        engine.set_swd_prescan(True)
         engine.set_swd_group(0)
         engine.set_swd_lookahead(0)
         engine.set_instrumentation(False, False)
