@@ -77,7 +77,7 @@ struct bh_engine {
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
-    int swd_prescan = 1; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits)
+    int swd_prescan = 0; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits; off by default: DESIGN.md 3.1c)
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)

@@ -57,6 +57,14 @@ using ModelLds = ModelLdsT<BH_WAVE>;
 struct ModelLdsRt { // same, with the column count known only at run time
     const float *d, *a, *b, *rho;
     int S;
+    // the certified-sign evaluation's per-layer reciprocals (csign::rcp_fast of the binary32 values), [4][rows][S]: 1/a, 1/b,
+    // 1/rho, 1/d; LS = rows * S
+    const double *inv = nullptr;
+    int LS = 0;
+    __device__ __forceinline__ double IA(int m) const { return inv[m * S]; }
+    __device__ __forceinline__ double IB(int m) const { return inv[LS + m * S]; }
+    __device__ __forceinline__ double IR(int m) const { return inv[2 * LS + m * S]; }
+    __device__ __forceinline__ double ID(int m) const { return inv[3 * LS + m * S]; }
     __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
     __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
     __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }

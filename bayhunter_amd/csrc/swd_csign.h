@@ -90,16 +90,19 @@ __device__ __forceinline__ double expneg_fast(double x)
 struct Wave {
     double cs, w, x, ex, W, X, s;
 };
-__device__ __forceinline__ void wave_terms(double vel, double c, double oc, double dpth, Wave &o)
+// ivel = 1 / vel, idpth = 1 / dpth as rcp_fast gives them (the group kernel keeps them in LDS per layer)
+__device__ __forceinline__ void wave_terms(double vel, double ivel, double c, double oc, double dpth, double idpth, Wave &o)
 {
     const double sa = vel - c;
-    const double ia = oc * rcp_fast(vel);
-    const double r2 = (ia * ia) * ((vel + c) * fabs(sa));
+    const double ia = oc * ivel;
+    const double vc = vel + c;
+    const double r2 = (ia * ia) * (vc * fabs(sa));
     const double rr = rsqrt_fast(r2);
     const double r = r2 * rr;
     const double p = r * dpth;
     const double pm = fmax(p, 1.0), pn = fmin(p, 1.0);
-    const double cn = (2.0 * U64) * ((vel + c) * rcp_fast(fabs(sa))) * (pm + 1.0);
+    const double via = vc * ia; // (a + c) / |a - c| = ((a + c) ia)^2 / r2
+    const double cn = (2.0 * U64) * ((via * via) * (rr * rr)) * (pm + 1.0);
     double sn, cs, s, ex = 0.0;
     if (sa < 0.0) { // c above the layer velocity: propagating
         sincos_fast(fmin(p, 9.0e4), sn, cs);
@@ -111,7 +114,7 @@ __device__ __forceinline__ void wave_terms(double vel, double c, double oc, doub
         sn = (1.0 - fac) * 0.5;
         o.x = r * sn;
         ex = p;
-        s = (__builtin_fma(20.0, pm, 8.0) + 2.0 * rcp_fast(pn)) * U64 + cn;
+        s = (__builtin_fma(20.0, pm, 8.0) + 2.0 * fmax(1.0, rr * idpth)) * U64 + cn;
     }
     if (!(p < 9.0e4)) s = __builtin_inf(); // (beyond the reduction's range: never certified)
     o.cs = cs;
@@ -136,9 +139,11 @@ __device__ __forceinline__ bool rayleigh(const MD &md, int mmax, int llw, double
     double e0, e1, e2, e3, e4, p0, p1, p2, p3, p4;
     { // half-space vector (surfdisp96.f:800-808)
         const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1), rh = md.R(mmax - 1);
-        const double ia = oc * rcp_fast(ah), ib = oc * rcp_fast(bh);
+        const double ia = oc * md.IA(mmax - 1), ib = oc * md.IB(mmax - 1);
         const double ra2 = (ia * ia) * ((ah + c) * fabs(ah - c)), rb2 = (ib * ib) * ((bh + c) * fabs(bh - c));
-        const double ra = ra2 * rsqrt_fast(ra2), rb = rb2 * rsqrt_fast(rb2);
+        const double rsa = rsqrt_fast(ra2), rsb = rsqrt_fast(rb2);
+        const double ra = ra2 * rsa, rb = rb2 * rsb;
+        const double via = (ah + c) * ia, vib = (bh + c) * ib;
         const double t = bh * iom;
         const double gammk = 2.0 * t * t, gam = gammk * k2, gamm1 = gam - 1.0, g1 = gam + 1.0;
         const double rarb = ra * rb;
@@ -148,7 +153,7 @@ __device__ __forceinline__ bool rayleigh(const MD &md, int mmax, int llw, double
         e3 = rh * rb;
         e4 = k2 - rarb;
         const double ku = 64.0 * U64;
-        const double ka = ku + (2.0 * U64) * ((ah + c) * rcp_fast(fabs(ah - c))), kb = ku + (2.0 * U64) * ((bh + c) * rcp_fast(fabs(bh - c)));
+        const double ka = ku + (2.0 * U64) * ((via * via) * (rsa * rsa)), kb = ku + (2.0 * U64) * ((vib * vib) * (rsb * rsb));
         p0 = rh * rh * (ku * (g1 * g1) + (ka + kb) * (gam * gammk * rarb));
         p1 = ka * (rh * ra);
         p2 = rh * (ku * g1 + (ka + kb) * (gammk * rarb));
@@ -158,9 +163,10 @@ __device__ __forceinline__ bool rayleigh(const MD &md, int mmax, int llw, double
     bool usable = true;
     for (int m = mmax - 2; m >= 0; --m) {
         const double am = md.A(m), bm = md.Bv(m), rh = md.R(m), dm = md.D(m);
+        const double idm = md.ID(m);
         Wave P, Q;
-        wave_terms(am, c, oc, dm, P);
-        wave_terms(bm, c, oc, dm, Q);
+        wave_terms(am, md.IA(m), c, oc, dm, idm, P);
+        wave_terms(bm, md.IB(m), c, oc, dm, idm, Q);
         const double t = bm * iom;
         const double gammk = 2.0 * t * t, gam = gammk * k2;
         const double exa = P.ex + Q.ex;
@@ -172,7 +178,7 @@ __device__ __forceinline__ bool rayleigh(const MD &md, int mmax, int llw, double
         const double XY = X * Y, XZ = X * Z, WY = W * Y, WZ = W * Z;
         const double gamm1 = gam - 1.0, twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1, gm1sq = gamm1 * gamm1;
         const double g1 = gam + 1.0, tw1 = gam + g1, gg1 = gam * g1, g1sq = g1 * g1;
-        const double rho2 = rh * rh, ir = rcp_fast(rh), ir2 = ir * ir;
+        const double rho2 = rh * rh, ir = md.IR(m), ir2 = ir * ir;
         const double a0pq = a0 - cpcq;
         const double k4 = k2 * k2;
         // compound matrix (dnka, surfdisp96.f:1024-1068): ca[j][i] as cJI with J, I = 1..5
@@ -279,21 +285,24 @@ __device__ __forceinline__ bool love(const MD &md, int mmax, int llw, double ome
     double e1, e2, p1, p2;
     {
         const double bh = md.Bv(mmax - 1), rh = md.R(mmax - 1);
-        const double ibh = rcp_fast(bh);
+        const double ibh = md.IB(mmax - 1);
         const double ib = oc * ibh;
         const double rb2 = (ib * ib) * ((bh + c) * fabs(bh - c));
-        const double rb = rb2 * rsqrt_fast(rb2);
+        const double rsb = rsqrt_fast(rb2);
+        const double rb = rb2 * rsb;
+        const double vib = (bh + c) * ib;
         e1 = rh * rb;
         e2 = ibh * ibh;
-        p1 = (16.0 * U64 + (2.0 * U64) * ((bh + c) * rcp_fast(fabs(bh - c)))) * e1;
+        p1 = (16.0 * U64 + (2.0 * U64) * ((vib * vib) * (rsb * rsb))) * e1;
         p2 = 8.0 * U64 * e2;
     }
     bool usable = true;
     for (int m = mmax - 2; m >= 0; --m) {
         const double bm = md.Bv(m), rh = md.R(m), dm = md.D(m);
+        const double ibm = md.IB(m);
         Wave Q;
-        wave_terms(bm, c, oc, dm, Q);
-        const double xmu = rh * bm * bm, ixmu = rcp_fast(xmu);
+        wave_terms(bm, ibm, c, oc, dm, md.ID(m), Q);
+        const double xmu = rh * bm * bm, ixmu = md.IR(m) * ibm * ibm;
         const double lam = Q.s + 24.0 * U64;
         const double A = xmu * Q.x, Bq = Q.w * ixmu;
         const double MA = xmu * Q.X, MB = Q.W * ixmu;

@@ -42,14 +42,17 @@ namespace {
 // The certified-sign evaluation of ONE grid point by one lane (swd_csign.h), OUT OF LINE: it needs ~160 registers of its own,
 // the round loop around it keeps ~200 live; as a call the loop's values stay in their registers (or are saved around the call
 // by the calling convention) and the loop itself is compiled as before.  The model is read from the wavefront's LDS region:
-// mdl = byte offset of its [4][Lmax][MPW] float block inside the workgroup's dynamic LDS, col = the model's column.
+// mdl / inv = byte offsets of its [4][Lmax][MPW] float block and of the [4][Lmax][MPW] block of per-layer reciprocals inside the
+// workgroup's dynamic LDS, col = the model's column.
 // Returns bit 0 = certified, bit 1 = the value is negative.
-__device__ __attribute__((noinline)) int csign_point(int ifunc, int mdl, int rows_x_mpw, int mpw, int col, int mmax, int llw, double omega, double c)
+__device__ __attribute__((noinline)) int csign_point(int ifunc, int mdl, int inv, int rows_x_mpw, int mpw, int col, int mmax, int llw, double omega, double c)
 {
     extern __shared__ __align__(16) unsigned char smem_all[];
     const float *m0 = reinterpret_cast<const float *>(smem_all + mdl);
     ModelLdsRt md;
     md.S = mpw;
+    md.inv = reinterpret_cast<const double *>(smem_all + inv) + col;
+    md.LS = rows_x_mpw;
     md.d = m0 + col;
     md.a = m0 + rows_x_mpw + col;
     md.b = m0 + 2 * rows_x_mpw + col;
@@ -204,7 +207,10 @@ constexpr int ADAPT_MAX_TRIALS = 8;
 // size, scalar registers), so it is compiled into the launches where it pays -- one model per wavefront (ADAPT: a single
 // model, the chains' windows), launches of Love targets only -- and not where Rayleigh wavefronts set the time anyway
 // (c2: Rayleigh + Love at B = 4096: 3.37 ms without, 3.47 with; the Rayleigh wavefront alone on its SIMD takes 3.06).
-template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB>
+// PREK: the build with the certified-sign scan (SearchT<.., PRE>, the look-ahead at the top of the round loop).  Its out-of-line
+// evaluation takes the kernel to 256 registers, so it is a build of its own, launched only when the scan is asked for
+// (bh_engine_set_swd_prescan; the general builds of launches with several models per wavefront).
+template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB, bool PREK = false>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -293,6 +299,9 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
     unsigned char *after = reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15);
     double *cpl = reinterpret_cast<double *>(after); // [2][Kmax][MPW], only if a target has mode > 1
+    // The certified-sign scan's per-layer reciprocals 1/a, 1/b, 1/rho, 1/d, [4][Lmax][MPW]: they live in the parked-layer rows,
+    // which are free between two rounds (4 Lmax <= 26 J (Lmax - 1) for every Lmax >= 2), and are formed anew at every look-ahead.
+    double *inv = ca;
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
     // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
 
     constexpr bool FAST = FASTM != 0;
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
-    SearchT<0, NEV_MAX, FASTM, SIMPLE, true> S;
+    SearchT<0, NEV_MAX, FASTM, SIMPLE, PREK> S;
     S.XS = MPW;
     // RESTART (one model per wavefront, the build with both sequences, SwdMultiArgs::restart): when the guard of the short
     // refinement fires, the model starts again right here with the reference's sequence -- what the engine's re-run launch
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     unsigned evals_before = 0u; // (evaluations of the abandoned first search: they count, as the re-run launch's would)
 restart_with_the_reference_sequence:
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, A.prescan != 0);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, PREK && A.prescan != 0);
     S.evals += evals_before;
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
@@ -395,45 +404,64 @@ restart_with_the_reference_sequence:
         // ---- the certified-sign scan (SearchT, swd_csign.h): models that start a period's search look ahead over the scan's
         // grid, one lane per grid point (the lanes of the model: LPM points a look), until a grid point is not proven to
         // have the start value's sign; then they land two steps before it, or decline (the reference's steps).
-        if (__ballot(S.active && S.st == ST_PRE) != 0ull) {
+        if (PREK && __ballot(S.active && S.st == ST_PRE) != 0ull) {
             const long long tp0 = prof ? clock64() : 0;
-            const int pidx = spare ? 0 : lane - g * LPM; // this lane's grid point inside a look (spare lanes: clones of lane 0)
-            const unsigned long long mine = (LPM >= 64) ? ~0ull : (((1ull << LPM) - 1ull) << (g * LPM)); // this model's lanes
+            // Two roles per lane.  OWNER: the lane carries the search state of model g (all LPM lanes of the model alike) and
+            // keeps the look-ahead's bookkeeping for it.  EVALUATOR: the lane evaluates one grid point of model gp -- the
+            // wavefront's 64 lanes are dealt out PL = 64 / MPW per model, whatever the lane groups of the rounds are.
+            const int PL = BH_WAVE / MPW;
+            const bool ev_on = lane / PL < MPW;
+            const int gp = ev_on ? lane / PL : 0, pidx = ev_on ? lane - gp * PL : 0;
+            const int src = gp * LPM;                                                    // a lane that owns model gp
+            const unsigned long long mine = ((PL >= 64) ? ~0ull : ((1ull << PL) - 1ull)) << (g * PL); // the evaluators of MY model
             bool pending = S.active && S.st == ST_PRE, landing = false, neg0 = false;
-            // (what the look-ahead needs of the search state)
-            const double p_c1 = S.c1, p_om = S.omega, p_cm = S.cm, p_hi = S.betmxd + S.dc, p_clow = S.clow, p_vsafe = S.vsafe;
-            const bool p_first = S.ifirst == 1, p_neg1st = signs_differ(S.del1st, 0.0);
-            double gi = p_c1;
-            for (int i = 0; i < pidx; ++i) gi = gi + S.dc;
             int base = 0, jj = 0;
             unsigned npts = 0;
+            // what the evaluation needs of model gp's search (SearchT::pre_plain, pre_upward)
+            const double q_om = __shfl(S.omega, src), q_cm = __shfl(S.cm, src), q_hi = __shfl(S.betmxd, src) + S.dc,
+                         q_clow = __shfl(S.clow, src), q_vsafe = __shfl(S.vsafe, src);
+            const int q_mmax = __shfl(mmax, src), q_llw = __shfl(llw, src);
+            const bool p_first = S.ifirst == 1, p_neg1st = signs_differ(S.del1st, 0.0);
+            double gi = __shfl(S.c1, src);
+            for (int i = 0; i < pidx; ++i) gi = gi + S.dc;
+            const int o_mdl = (int)(reinterpret_cast<unsigned char *>(mdl) - smem_all), o_inv = (int)(reinterpret_cast<unsigned char *>(inv) - smem_all);
+            for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) { // the per-layer reciprocals (see `inv`)
+                inv[0 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[1 * Lmax * MPW + idx]);
+                inv[1 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[2 * Lmax * MPW + idx]);
+                inv[2 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[3 * Lmax * MPW + idx]);
+                inv[3 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[0 * Lmax * MPW + idx]);
+            }
+            wave_sync();
             while (__ballot(pending) != 0ull) {
-                
-                const int cs_ = csign_point(ifunc, (int)(reinterpret_cast<unsigned char *>(mdl) - smem_all), Lmax * MPW, MPW, g, mmax, llw, p_om, gi);
-                const bool cert = (cs_ & 1) != 0;
-
-                const bool neg = (cs_ & 2) != 0;
-                const bool c0 = __shfl((int)cert, g * LPM) != 0, n0 = __shfl((int)neg, g * LPM) != 0;
-                if (pending && base == 0) { // the first look: the start value's proven sign decides the direction
+                const int cs_ = csign_point(ifunc, o_mdl, o_inv, Lmax * MPW, MPW, gp, q_mmax, q_llw, q_om, gi);
+                const bool cert = (cs_ & 1) != 0, neg = (cs_ & 2) != 0;
+                // owner: the start value's proven sign decides the direction (first look)
+                const bool c0 = __shfl((int)cert, g * PL) != 0, n0 = __shfl((int)neg, g * PL) != 0;
+                if (pending && base == 0) {
                     neg0 = n0;
-                    if (!(c0 && (p_first || n0 == p_neg1st))) pending = false; // (declined: SearchT::pre_upward)
+                    if (!(c0 && (p_first || n0 == p_neg1st))) pending = false; // (declined)
                 }
-                const int idx = base + pidx;
-                // (SearchT::pre_plain: may the scan simply step on at this grid point?)
-                const bool ok = cert && neg == neg0 && (idx == 0 || (!(gi < p_cm || gi >= p_hi) && gi > p_clow && gi < p_vsafe)) && idx < S.pre_max_points;
+                // evaluator: is my point proven to have the start value's sign, and may the scan simply step on there?
+                const int idx = __shfl(base, src) + pidx;
+                const bool nz = __shfl((int)neg0, src) != 0;
+                const bool ok = cert && neg == nz && (idx == 0 || (!(gi < q_cm || gi >= q_hi) && gi > q_clow && gi < q_vsafe)) && idx < S.pre_max_points;
                 const unsigned long long bad = ~__ballot(ok) & mine;
+                bool more = false;
                 if (pending) {
                     ++npts;
                     if (bad != 0ull) {
-                        jj = base + (int)__builtin_ctzll(bad) - g * LPM;
+                        jj = base + (int)__builtin_ctzll(bad) - g * PL;
                         pending = false;
                         landing = true;
                     } else {
-                        base += LPM;
-                        for (int i = 0; i < LPM; ++i) gi = gi + S.dc;
+                        base += PL;
+                        more = true;
                     }
                 }
+                if (__shfl((int)more, src) != 0)
+                    for (int i = 0; i < PL; ++i) gi = gi + S.dc;
             }
+            wave_sync(); // (the rounds' phase A writes the rows the reciprocals were read from)
             if (S.active && S.st == ST_PRE) {
                 if (landing && jj >= 3) {
                     double gm2 = S.c1;
@@ -444,8 +472,8 @@ restart_with_the_reference_sequence:
                 }
             }
             if (prof) {
-                const bool rep = valid && !spare;
-                unsigned long long np = rep ? npts : 0u, nl = (rep && pidx == 0 && landing && jj >= 3) ? 1u : 0u;
+                const bool rep = valid && li == 0 && rr == 0 && !spare;
+                unsigned long long np = rep ? npts * (unsigned)PL : 0u, nl = (rep && landing && jj >= 3) ? 1u : 0u;
                 for (int off = 32; off > 0; off >>= 1) {
                     np += __shfl_xor(np, off);
                     nl += __shfl_xor(nl, off);
@@ -1119,14 +1147,21 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // length: c2 2.51 -> 2.30 ms, c3 2.60 -> 2.49).  One model per wavefront (the trial lanes already walk the scan seven
     // steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches of the reference's sequence (the
     // Rayleigh wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
-    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && !adapt && (all_love ? build != 1 : build == 2)));
+    // (BH_SCAN_AUTO with the certified-sign scan on: that scan serves Love as well -- one look instead of jump + index search)
+    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && a.prescan == 0 && !adapt && (all_love ? build != 1 : build == 2)));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
 #define BH_GROUP_LAUNCH_ADAPT(FM, PR) do { if (cntb) BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, true); else BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, false); } while (0)
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
-    if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
+    const bool prek = a.prescan != 0 && !adapt && !cntb && wpb == GROUP_WPB;
+    a.prescan = prek ? 1 : 0;
+    if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel)
+        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+    } else if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
         static std::atomic<unsigned long long> big_lds{0};
         if (lds > WG_LDS_CAP) {
             const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false, false>),

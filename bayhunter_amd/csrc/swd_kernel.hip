@@ -654,6 +654,10 @@ struct ModelGlobalF { // the model's float arrays in global memory, the accessor
     __device__ __forceinline__ double A(int m) const { return (double)a[m]; }
     __device__ __forceinline__ double Bv(int m) const { return (double)b[m]; }
     __device__ __forceinline__ double R(int m) const { return (double)rho[m]; }
+    __device__ __forceinline__ double IA(int m) const { return csign::rcp_fast((double)a[m]); }
+    __device__ __forceinline__ double IB(int m) const { return csign::rcp_fast((double)b[m]); }
+    __device__ __forceinline__ double IR(int m) const { return csign::rcp_fast((double)rho[m]); }
+    __device__ __forceinline__ double ID(int m) const { return csign::rcp_fast((double)d[m]); }
 };
 __global__ void csign_probe_kernel(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out)
 {

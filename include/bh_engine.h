@@ -141,13 +141,15 @@ int bh_engine_get_swd_search(const bh_engine *e);
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
 
-/* The certified-sign scan (on by default; results are bit-identical either way).  getsol's bracket scan
+/* The certified-sign scan (OFF by default; results are bit-identical either way).  getsol's bracket scan
  * (surfdisp96.f:437-460) consumes only the SIGN of the secular function at its grid points; with this on, a search first
  * evaluates the grid ahead with a cheap evaluation of the same recursion that carries an error bound (one lane per grid
  * point), and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's -- the
  * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
  * step-by-step scan, with 2-3 reference-exact evaluations per scan instead of ~15.  Applies to both root refinements, all
- * targets of the lanes-per-model kernel (batches below ~16 000 models per call).  0: every step evaluated. */
+ * target types, in launches with several models per wavefront (a few hundred to ~16 000 models per call); elsewhere the
+ * setting is ignored.  Off by default because, measured on MI355X, the look-ahead costs the vector issue slots the skipped
+ * rounds would have used; kept as a tested option. */
 int bh_engine_set_swd_prescan(bh_engine *e, int on);
 int bh_engine_get_swd_prescan(const bh_engine *e);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent

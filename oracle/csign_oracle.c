@@ -113,17 +113,20 @@ typedef struct {
     double W, X, s;      /* envelopes of w and x, error level */
 } wave_t;
 
-static void wave_terms(double vel, double c, double oc, double dpth, wave_t *o)
+static void wave_terms(double vel, double ivel, double c, double oc, double dpth, double idpth, wave_t *o)
 {
     const double sa = vel - c;
-    const double ia = oc * rcp_fast(vel);
-    const double r2 = (ia * ia) * ((vel + c) * fabs(sa));
+    const double ia = oc * ivel;
+    const double vc = vel + c;
+    const double r2 = (ia * ia) * (vc * fabs(sa));
     const double rr = rsqrt_fast(r2);
     const double r = r2 * rr;
     const double p = r * dpth;
     const double pm = fmax(p, 1.0), pn = fmin(p, 1.0);
-    /* the REFERENCE forms k - k_a by subtraction: its r carries the relative error u (a + c) / |a - c| of that cancellation */
-    const double cn = (2.0 * U64) * ((vel + c) * rcp_fast(fabs(sa))) * (pm + 1.0);
+    /* the REFERENCE forms k - k_a by subtraction: its r carries the relative error u (a + c) / |a - c| of that cancellation
+     * ((a + c) / |a - c| = ((a + c) ia)^2 / r2, without another division) */
+    const double via = vc * ia;
+    const double cn = (2.0 * U64) * ((via * via) * (rr * rr)) * (pm + 1.0);
     double sn, cs, s, ex = 0.0;
     if (sa < 0.0) { /* c above the layer velocity: propagating */
         sincos_fast(fmin(p, 9.0e4), &sn, &cs);
@@ -135,7 +138,7 @@ static void wave_terms(double vel, double c, double oc, double dpth, wave_t *o)
         sn = (1.0 - fac) * 0.5;
         o->x = r * sn;
         ex = p;
-        s = (fma(20.0, pm, 8.0) + 2.0 * rcp_fast(pn)) * U64 + cn;
+        s = (fma(20.0, pm, 8.0) + 2.0 * fmax(1.0, rr * idpth)) * U64 + cn; /* (2 / min(p, 1), 1 / p = (1 / r)(1 / d)) */
     }
     if (!(p < 9.0e4)) s = INFINITY; /* (beyond the reduction's range: never certified) */
     o->cs = cs;
@@ -164,7 +167,9 @@ static int rayleigh_cs(double omega, double c, const float *d, const float *a, c
         const double ah = (double)a[mmax - 1], bh = (double)b[mmax - 1], rh = (double)rho[mmax - 1];
         const double ia = oc * rcp_fast(ah), ib = oc * rcp_fast(bh);
         const double ra2 = (ia * ia) * ((ah + c) * fabs(ah - c)), rb2 = (ib * ib) * ((bh + c) * fabs(bh - c));
-        const double ra = ra2 * rsqrt_fast(ra2), rb = rb2 * rsqrt_fast(rb2);
+        const double rsa = rsqrt_fast(ra2), rsb = rsqrt_fast(rb2);
+        const double ra = ra2 * rsa, rb = rb2 * rsb;
+        const double via = (ah + c) * ia, vib = (bh + c) * ib;
         const double t = bh * iom;
         const double gammk = 2.0 * t * t, gam = gammk * k2, gamm1 = gam - 1.0, g1 = gam + 1.0;
         const double rarb = ra * rb;
@@ -174,7 +179,7 @@ static int rayleigh_cs(double omega, double c, const float *d, const float *a, c
         e[3] = rh * rb;
         e[4] = k2 - rarb;
         const double ku = 64.0 * U64; /* + the reference's cancellation in k - k_a, k - k_b (see wave_terms) */
-        const double ka = ku + (2.0 * U64) * ((ah + c) * rcp_fast(fabs(ah - c))), kb = ku + (2.0 * U64) * ((bh + c) * rcp_fast(fabs(bh - c)));
+        const double ka = ku + (2.0 * U64) * ((via * via) * (rsa * rsa)), kb = ku + (2.0 * U64) * ((vib * vib) * (rsb * rsb));
         eps[0] = rh * rh * (ku * (g1 * g1) + (ka + kb) * (gam * gammk * rarb));
         eps[1] = ka * (rh * ra);
         eps[2] = rh * (ku * g1 + (ka + kb) * (gammk * rarb));
@@ -183,9 +188,10 @@ static int rayleigh_cs(double omega, double c, const float *d, const float *a, c
     }
     for (int m = mmax - 2; m >= 0; --m) {
         const double am = (double)a[m], bm = (double)b[m], rh = (double)rho[m], dm = (double)d[m];
+        const double idm = rcp_fast(dm); /* (the device keeps 1 / a, 1 / b, 1 / rho, 1 / d of every layer in LDS: the same values) */
         wave_t P, Q;
-        wave_terms(am, c, oc, dm, &P);
-        wave_terms(bm, c, oc, dm, &Q);
+        wave_terms(am, rcp_fast(am), c, oc, dm, idm, &P);
+        wave_terms(bm, rcp_fast(bm), c, oc, dm, idm, &Q);
         const double t = bm * iom;
         const double gammk = 2.0 * t * t, gam = gammk * k2;
         const double exa = P.ex + Q.ex;
@@ -296,17 +302,20 @@ static int love_cs(double omega, double c, const float *d, const float *b, const
         const double ibh = rcp_fast(bh);
         const double ib = oc * ibh;
         const double rb2 = (ib * ib) * ((bh + c) * fabs(bh - c));
-        const double rb = rb2 * rsqrt_fast(rb2);
+        const double rsb = rsqrt_fast(rb2);
+        const double rb = rb2 * rsb;
+        const double vib = (bh + c) * ib;
         e1 = rh * rb;
         e2 = ibh * ibh;
-        p1 = (16.0 * U64 + (2.0 * U64) * ((bh + c) * rcp_fast(fabs(bh - c)))) * e1; /* (the reference's cancellation in k - k_b) */
+        p1 = (16.0 * U64 + (2.0 * U64) * ((vib * vib) * (rsb * rsb))) * e1; /* (the reference's cancellation in k - k_b) */
         p2 = 8.0 * U64 * e2;
     }
     for (int m = mmax - 2; m >= 0; --m) {
         const double bm = (double)b[m], rh = (double)rho[m], dm = (double)d[m];
+        const double ibm = rcp_fast(bm);
         wave_t Q;
-        wave_terms(bm, c, oc, dm, &Q);
-        const double xmu = rh * bm * bm, ixmu = rcp_fast(xmu);
+        wave_terms(bm, ibm, c, oc, dm, rcp_fast(dm), &Q);
+        const double xmu = rh * bm * bm, ixmu = rcp_fast(rh) * ibm * ibm;
         const double lam = Q.s + 24.0 * U64;
         const double A = xmu * Q.x, Bq = Q.w * ixmu;
         const double MA = xmu * Q.X, MB = Q.W * ixmu;

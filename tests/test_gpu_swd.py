@@ -268,7 +268,7 @@ def test_lookahead_does_not_change_results(engine, G, J):
                 assert np.array_equal(v1, v2) and np.array_equal(e1, e2), (iwave, igr, mode)
                 assert n1 == n2 and n1 > 0
     finally:
-        engine.set_swd_prescan(True)
+        engine.set_swd_prescan(False)
         engine.set_swd_group(0)
         engine.set_swd_lookahead(0)
         engine.set_instrumentation(False, False)

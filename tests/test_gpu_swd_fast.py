@@ -33,7 +33,7 @@ def fast(engine):
     finally:
         engine.set_swd_search("reference")
         engine.set_swd_scan("auto")
-        engine.set_swd_prescan(True)
+        engine.set_swd_prescan(False)
 
 
 class restatement:
@@ -138,7 +138,7 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
             assert (n1 < 0.8 * n0) if iwave == 1 else (n1 == n0)
     finally:
         engine.set_swd_scan("auto")
-        engine.set_swd_prescan(True)
+        engine.set_swd_prescan(False)
         engine.set_instrumentation(False, False)
 
 
