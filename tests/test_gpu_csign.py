@@ -41,7 +41,7 @@ def test_device_evaluation_equals_the_cpu_restatement_bit_for_bit(engine, oracle
 @pytest.mark.parametrize("search", ["reference", "fast"])
 def test_same_bits_with_and_without_the_certified_scan(engine, oracle, search):
     rs = np.random.RandomState(5)
-    nlay, h, vp, vs, rho = synth_models(rs, 1500, 12, lvz_frac=0.3, ragged=True)
+    nlay, h, vp, vs, rho = synth_models(rs, 6000, 12, lvz_frac=0.3, ragged=True)   # (several models per wavefront: where the scan applies)
     vs[0, :8] = 0.0                      # a few models with a water layer on top (never certified)
     vp[0, :8] = 1.5
     vs[:, 8:12] *= 0.2                   # and some that fail the search
@@ -73,7 +73,7 @@ def test_same_bits_with_and_without_the_certified_scan(engine, oracle, search):
 def test_certified_scan_does_not_depend_on_the_launch_plan(engine, G, J):
     """Lanes per model and trials per round decide how many grid points one look covers -- not what the search returns."""
     rs = np.random.RandomState(77)
-    nlay, h, vp, vs, rho = synth_models(rs, 300, 12, lvz_frac=0.3, ragged=True)
+    nlay, h, vp, vs, rho = synth_models(rs, 3000, 12, lvz_frac=0.3, ragged=True)
     vs[:, 8:12] *= 0.2
     per = np.linspace(1.5, 70, 35)
     try:
