@@ -184,6 +184,11 @@ struct RfKernelArgs {
     double *coef;  // workspace [B][bh_rf_coef_doubles(Lmax)]
     double *rf;    // [B][ldr]
     int ldr;
+    // fused likelihood (bh_evaluate_batch without synthetics, nocorr / exponential law): instead of the trace the synthesis
+    // kernel writes, per model, the four sums the likelihood needs of it -- sum d^2, sum d_i d_(i+1), d_0, d_(n-1), d = trace -
+    // yobs, formed in like_kernel's own order (same bits) -- to sums[B][4]; null: the trace is written
+    const double *yobs;
+    double *sums;
     int lds_min;   // lower bound of the synthesis kernel's LDS request in bytes (0 = what the trace needs), see bh_engine.hip
     int no_realc;  // experiment switch: 1 = always the general (complex-coefficient) recursion
     int coef_small; // 1: the 96-register build of the coefficient kernel (fused call: resident beside the dispersion wavefronts)
@@ -202,6 +207,7 @@ struct LikeTargetDev {
     double logdet_extra;                     // ln prod(scaled err) (law 1) or ln|R| (law 3)
     const double *quad;                      // law 3: [B][nsplit] column-slab partial sums of d^T R^-1 d
     int nsplit;                              //        (gauss_kernel.hip); null -> in-kernel mat-vec
+    const double *pre;                       // laws 0 / 2: [B][4] sums formed by the forward kernel (RfKernelArgs::sums); null -> from ymod
 };
 int bh_gauss_nsplit(int B, int n);
 void bh_launch_gauss_quad(int B, int n, int ldy, const double *ymod, const double *yobs,

@@ -26,6 +26,8 @@ struct TargetHost {
     bh_target_desc d{};
     int off = 0; // column offset in a ymod row
     DevBuf x, yobs, yerr_scaled, rinv, quad;
+    DevBuf sums;       // receiver function, fused likelihood: [B][4] sums of the last call (RfKernelArgs::sums)
+    bool fused = false; // this call's likelihood of the target comes from `sums` (set per call by bh_evaluate_batch)
     DevBuf x60, vel60; // > 60 periods: the 60-point grid the forward model runs on + its output
     int kfwd = 0;      // periods the forward model computes (n, or 60 when n > 60)
     double logdet_extra = 0.0;
@@ -618,7 +620,8 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
 
 int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
               ptrdiff_t sb, double p, double gauss, int nsamp, double fsamp, double tshift,
-              double nsv, int waveno, int nkeep, double *rf, int ldr, bool beside_swd = false)
+              double nsv, int waveno, int nkeep, double *rf, int ldr, bool beside_swd = false, const double *yobs = nullptr,
+              double *sums = nullptr)
 {
     if (B == 0) return BH_OK;
     int rc;
@@ -629,6 +632,7 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     a.sl = sl; a.sb = sb;
     a.p_s_per_deg = p; a.gauss = gauss; a.fsamp = fsamp; a.tshift = tshift; a.nsv = nsv;
     a.coef = (double *)e->coef.p; a.rf = rf; a.ldr = ldr;
+    a.yobs = yobs; a.sums = sums; // (fused likelihood: the sums instead of the trace)
     // Beside a dispersion launch (fused call, second stream): the synthesis workgroups must not take wave slots before
     // the dispersion kernel's wavefronts are resident -- that kernel counts on all of them being co-resident (one round
     // of wavefronts; displaced ones wait for a whole lifetime: 3.6 -> 7 ms measured when the 17.7 KB workgroups of
@@ -662,6 +666,7 @@ int prepare_like_target(bh_engine *e, hipStream_t st, int B, int ldy, const doub
     L.logdet_extra = T.logdet_extra;
     L.quad = nullptr;
     L.nsplit = 0;
+    L.pre = T.fused ? (const double *)T.sums.p : nullptr;
     if (T.d.law == BH_LAW_GAUSS && !e->no_mfma) {
         const int nsplit = bh_gauss_nsplit(B, T.d.n);
         int rc = ensure(e, T.quad, (size_t)B * nsplit * sizeof(double));
@@ -1279,9 +1284,17 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         if (d.kind == BH_TARGET_SWD && T.kfwd != d.n)
             bh_launch_interp(B, T.kfwd, (const double *)T.x60.p, (const double *)T.vel60.p, T.kfwd, d.n,
                              (const double *)T.x.p, ymod_d + T.off, ldy, st);
+        T.fused = false;
         if (d.kind != BH_TARGET_RF) continue;
+        // Fused likelihood ("write nothing if the likelihood is fused"): the caller did not ask for the
+        // synthetics and the target's law needs only sums over the trace -- the synthesis kernel forms them from the samples
+        // in LDS (like_kernel's order: the same bits) and writes four numbers per model instead of the trace.
+        static const bool no_fuse = std::getenv("BH_RF_NO_FUSE") != nullptr; // experiment switch
+        T.fused = !ymod && !no_fuse && (d.law == BH_LAW_NOCORR || d.law == BH_LAW_EXP) && std::getenv("BH_RF_THREADS") == nullptr;
+        if (T.fused && (rc = ensure(e, T.sums, (size_t)B * 4 * sizeof(double)))) return rc;
         rc = launch_rf(e, rst, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
-                       d.nsv, d.waveno, d.n, ymod_d + T.off, ldy, fork);
+                       d.nsv, d.waveno, d.n, ymod_d + T.off, ldy, fork, T.fused ? (const double *)T.yobs.p : nullptr,
+                       T.fused ? (double *)T.sums.p : nullptr);
         if (rc) return rc;
     }
     if (fork) {
@@ -1342,8 +1355,10 @@ int bh_loglike_batch(bh_engine *e, int memspace, void *stream, int B, const doub
         la.err_t = (const int32_t *)e->err_t.p;
     }
     call_begin(e, st);
-    for (int t = 0; t < nt; ++t)
+    for (int t = 0; t < nt; ++t) {
+        e->targets[(size_t)t].fused = false; // (the caller's synthetics, not sums of an earlier fused call)
         if ((rc = prepare_like_target(e, st, B, ldy, la.ymod, e->targets[(size_t)t], la.t[t]))) return rc;
+    }
     ev_begin(e, 2, st);
     bh_launch_like(la, st);
     ev_end(e, 2, st);

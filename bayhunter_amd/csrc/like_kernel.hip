@@ -47,6 +47,14 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
         const double corr = A.noise[(size_t)ib * 2 * A.nt + 2 * t];
         const double sigma = A.noise[(size_t)ib * 2 * A.nt + 2 * t + 1];
         double s0 = 0.0, s1 = 0.0, sw = 0.0;
+        double d0 = 0.0, dn = 0.0;
+        if (T.pre != nullptr) { // the forward kernel formed the sums (fused likelihood, RfKernelArgs::sums): nothing to read of ymod
+            const double *pre = T.pre + (size_t)ib * 4;
+            s0 = pre[0];
+            s1 = pre[1];
+            d0 = pre[2];
+            dn = pre[3];
+        } else {
         for (int i = tid; i < n; i += 256) {
             const double d = ym[i] - T.yobs[i];
             s0 += d * d;
@@ -66,7 +74,14 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
                 sw += acc * dl[i];
             }
         }
-        if (n <= 64 && !(T.law == 3 && T.quad == nullptr)) {
+        if (T.law == 2) {
+            d0 = ym[0] - T.yobs[0];
+            dn = ym[n - 1] - T.yobs[n - 1];
+        }
+        }
+        if (T.pre != nullptr) {
+            // (already reduced)
+        } else if (n <= 64 && !(T.law == 3 && T.quad == nullptr)) {
             // a short target (a dispersion curve beside a long receiver function): its samples all sit in the first
             // wavefront, the other three would only add zeros -- no barrier (same bits as block_sum); only thread 0's
             // values are used below
@@ -88,7 +103,6 @@ __global__ __launch_bounds__(256) void like_kernel(LikeKernelArgs A)
             phi = sw / s2;
             logdet += T.logdet_extra;
         } else if (T.law == 2) {
-            const double d0 = ym[0] - T.yobs[0], dn = ym[n - 1] - T.yobs[n - 1];
             // get_corr_inv (Targets.py:131-137): d[0] = d[-1] = 1 -- for n == 1 both hit the
             // same element, so the edge correction must not be applied twice
             const double edge = (n > 1) ? (d0 * d0 + dn * dn) : (d0 * d0);
@@ -137,7 +151,14 @@ __global__ __launch_bounds__(256) void like_small_kernel(LikeKernelArgs A)
         const double *ym = y + T.off;
         const double corr = A.noise[(size_t)ib * 2 * A.nt + 2 * t];
         const double sigma = A.noise[(size_t)ib * 2 * A.nt + 2 * t + 1];
-        double s0 = 0.0, s1 = 0.0, sw = 0.0;
+        double s0 = 0.0, s1 = 0.0, sw = 0.0, d0 = 0.0, dn = 0.0;
+        if (T.pre != nullptr) { // the forward kernel formed the sums (fused likelihood, RfKernelArgs::sums)
+            const double *pre = T.pre + (size_t)ib * 4;
+            s0 = pre[0];
+            s1 = pre[1];
+            d0 = pre[2];
+            dn = pre[3];
+        } else {
         if (lane < n) {
             const double d = ym[lane] - T.yobs[lane];
             s0 += d * d;
@@ -151,6 +172,11 @@ __global__ __launch_bounds__(256) void like_small_kernel(LikeKernelArgs A)
             for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
         if (T.law == 1 || T.law == 3)
             for (int off = 32; off > 0; off >>= 1) sw += __shfl_xor(sw, off);
+        if (T.law == 2) {
+            d0 = ym[0] - T.yobs[0];
+            dn = ym[n - 1] - T.yobs[n - 1];
+        }
+        }
         const double s2 = sigma * sigma;
         double phi, logdet = (2.0 * n) * log(sigma);
         if (T.law == 0) {
@@ -159,7 +185,6 @@ __global__ __launch_bounds__(256) void like_small_kernel(LikeKernelArgs A)
             phi = sw / s2;
             logdet += T.logdet_extra;
         } else if (T.law == 2) {
-            const double d0 = ym[0] - T.yobs[0], dn = ym[n - 1] - T.yobs[n - 1];
             const double edge = (n > 1) ? (d0 * d0 + dn * dn) : (d0 * d0);
             const double r2 = corr * corr;
             phi = ((1.0 + r2) * s0 - r2 * edge - 2.0 * corr * s1) / (s2 * (1.0 - r2));

@@ -739,6 +739,63 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
     }
     const double scale = 1.0 / (double)N;
     const int shift = 32 - logm;
+    if (A.sums != nullptr && nthr == 256) {
+        // Fused likelihood: the kept samples never leave the CU.  The sums are formed exactly as like_kernel forms them
+        // from a stored trace -- thread t takes samples t, t + 256, ... in order, a butterfly per wavefront, the four
+        // wavefronts' values added in order -- with every product and sum rounded on its own (BH_NOFUSE pins a value to a
+        // register between two operations: this file is compiled with contraction on, HIP's __dmul_rn / __dadd_rn are plain
+        // operators, and `#pragma clang fp contract(off)` did not keep the backend from fusing here): the same bits.
+        const int n = A.nkeep;
+#define BH_RF_SAMPLE(i) (scale * (((i) & 1) ? z[(int)(__brev((unsigned)((i) >> 1)) >> shift)].y : z[(int)(__brev((unsigned)((i) >> 1)) >> shift)].x))
+#define BH_NOFUSE(x) asm volatile("" : "+v"(x))
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = tid; i < n; i += 256) {
+            double yi = BH_RF_SAMPLE(i);
+            BH_NOFUSE(yi);
+            double d = yi - A.yobs[i];
+            BH_NOFUSE(d);
+            double dd = d * d;
+            BH_NOFUSE(dd);
+            s0 = s0 + dd;
+            if (i + 1 < n) {
+                double yj = BH_RF_SAMPLE(i + 1);
+                BH_NOFUSE(yj);
+                double dj = yj - A.yobs[i + 1];
+                BH_NOFUSE(dj);
+                double pj = d * dj;
+                BH_NOFUSE(pj);
+                s1 = s1 + pj;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 = s0 + __shfl_xor(s0, off);
+            s1 = s1 + __shfl_xor(s1, off);
+        }
+        if (n > 64) { // (like_kernel: block_sum; up to 64 samples only the first wavefront's value counts)
+            double *red = reinterpret_cast<double *>(tw0); // (the twiddle tables are dead by now: 64 complex numbers)
+            __syncthreads();
+            if ((tid & 63) == 0) {
+                red[tid >> 6] = s0;
+                red[4 + (tid >> 6)] = s1;
+            }
+            __syncthreads();
+            s0 = red[0] + red[1] + red[2] + red[3];
+            s1 = red[4] + red[5] + red[6] + red[7];
+        }
+        if (tid == 0) {
+            double *o = A.sums + (size_t)ib * 4;
+            double y0 = BH_RF_SAMPLE(0), yn = BH_RF_SAMPLE(n - 1);
+            BH_NOFUSE(y0);
+            BH_NOFUSE(yn);
+            o[0] = s0;
+            o[1] = s1;
+            o[2] = y0 - A.yobs[0];
+            o[3] = yn - A.yobs[n - 1];
+        }
+#undef BH_RF_SAMPLE
+#undef BH_NOFUSE
+        return;
+    }
     double *out = A.rf + (size_t)ib * A.ldr;
     for (int m = tid; 2 * m < A.nkeep; m += nthr) {
         const double2 v = z[(int)(__brev((unsigned)m) >> shift)];

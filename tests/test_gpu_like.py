@@ -127,3 +127,26 @@ def test_fused_target_with_more_than_60_periods(engine):
         d = g["y_p80"][:, ir][ok] - yobs
         ref = -0.5 * (per.size * np.log(2 * np.pi) + 2 * per.size * np.log(0.05)) - 0.5 * np.sum(d * d, axis=1) / 0.05 ** 2
         assert np.max(np.abs(logL[ok] - ref) / np.abs(ref)) <= 1e-12
+
+
+@pytest.mark.parametrize("law", [E.LAW_NOCORR, E.LAW_EXP])
+@pytest.mark.parametrize("n,nsamp,fsamp", [(1024, 2048, 20.0), (201, 512, 5.0), (48, 128, 4.0), (1, 128, 4.0), (2, 128, 4.0), (8192, 16384, 50.0)])
+def test_fused_receiver_function_likelihood_has_the_bits_of_the_unfused_one(engine, law, n, nsamp, fsamp):
+    """bh_evaluate_batch without synthetics asked for: the receiver function's samples never leave the CU -- the synthesis
+    kernel forms the sums the nocorr / exponential law needs in like_kernel's own order (RfKernelArgs::sums).  logL and
+    misfits are bit-identical to the call that writes the trace and reads it back (synthetics asked for), for traces up to
+    64 samples (one wavefront's reduction), longer ones, and the 1- and 2-sample edge cases of the exponential law."""
+    from bayhunter_amd.synth import synth_models
+    rs = np.random.RandomState(n)
+    B = 96
+    nlay, h, vp, vs, rho = synth_models(rs, B, 10, ragged=True)
+    per = np.linspace(2, 40, 20)
+    engine.set_targets([
+        {"kind": E.TARGET_SWD, "law": E.LAW_NOCORR, "n": per.size, "x": per, "yobs": 3.4 + 0.01 * per, "iwave": 2, "igr": 0},
+        {"kind": E.TARGET_RF, "law": law, "n": n, "yobs": rs.normal(0, 0.05, n), "waveno": 0, "nsamp": nsamp, "p": 6.4,
+         "gauss": 2.0, "fsamp": fsamp, "tshift": 5.0}])
+    noise = np.column_stack([np.zeros(B), rs.uniform(0.01, 0.05, B), rs.uniform(0.3, 0.8, B), rs.uniform(0.005, 0.05, B)])
+    L1, m1, e1 = engine.evaluate_batch(nlay, h, vp, vs, noise)                         # fused
+    L2, m2, e2, y2 = engine.evaluate_batch(nlay, h, vp, vs, noise, want_ymod=True)     # the trace written and read back
+    assert np.array_equal(e1, e2) and np.array_equal(L1, L2) and np.array_equal(m1, m2)
+    assert np.all(np.isfinite(L1[e1 == 0]))
