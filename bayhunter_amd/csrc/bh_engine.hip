@@ -15,6 +15,69 @@
 #include <string>
 #include <vector>
 
+#include "bh_tuning.h"
+#include <cstring>
+#include <mutex>
+
+// ---- the experiment switches (bh_tuning.h) ----
+namespace {
+BhTuning g_tuning;
+std::once_flag g_tuning_once;
+int tuning_value(const char *env, const char *txt, int dflt)
+{
+    if (!txt) return dflt;
+    if (!std::strcmp(env, "BH_SWD_SEARCH")) return (txt[0] == 'f' || txt[0] == '1') ? ((std::strstr(txt, "ray") || txt[0] == '2') ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (txt[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_REFERENCE);
+    if (!std::strcmp(env, "BH_SWD_SCAN")) return (txt[0] == 's' || txt[0] == '0') ? BH_SCAN_STEPS : ((txt[0] == 'c' || txt[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
+    char *end = nullptr;
+    const long v = std::strtol(txt, &end, 10);
+    if (end == txt) return 1; // a flag set to some text
+    return (int)v;
+}
+void tuning_parse()
+{
+#ifndef BH_NO_EXPERIMENTS
+#define X(field, env, dflt, doc) g_tuning.field = tuning_value(env, std::getenv(env), dflt);
+    BH_TUNING_TABLE(X)
+#undef X
+    // bounds: a switch can cost time, never memory safety
+    if (g_tuning.rf_lds_gated < 0 || g_tuning.rf_lds_gated > 160 * 1024) g_tuning.rf_lds_gated = 0;
+    if (g_tuning.rf_lds_beside > 160 * 1024) g_tuning.rf_lds_beside = -1;
+    if (g_tuning.swd_love_inlook < 0 || g_tuning.swd_love_inlook > 4) g_tuning.swd_love_inlook = 0;
+    if (g_tuning.swd_wpb != 4) g_tuning.swd_wpb = 2;
+    g_tuning.rf_beside_prio &= 3;
+#endif
+    g_tuning.under_pmc = std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr ? 1 : 0;
+}
+} // namespace
+const BhTuning &bh_tuning()
+{
+    std::call_once(g_tuning_once, tuning_parse);
+    return g_tuning;
+}
+int bh_tuning_set(const char *name, int value)
+{
+#ifdef BH_NO_EXPERIMENTS
+    (void)name; (void)value;
+    return -1;
+#else
+    (void)bh_tuning();
+    if (!name) return -1;
+#define X(field, env, dflt, doc) if (!std::strcmp(name, #field)) { g_tuning.field = value; return 0; }
+    BH_TUNING_TABLE(X)
+#undef X
+    return -1;
+#endif
+}
+int bh_tuning_get(const char *name, int *value)
+{
+    const BhTuning &t = bh_tuning();
+    if (!name || !value) return -1;
+#define X(field, env, dflt, doc) if (!std::strcmp(name, #field)) { *value = t.field; return 0; }
+    BH_TUNING_TABLE(X)
+#undef X
+    return -1;
+}
+
 namespace {
 
 struct DevBuf {
@@ -375,7 +438,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     // narrower lane groups cost a second pass over the layers and seven instead of four trials per round more transitions:
     // measured on windows of 1016 models of 3-9 layers in arrays of 21 (c4): 1.50 ms without the hint, 1.70-1.83 ms with it.
     const int typ_given = m.typ_layers > 0 ? m.typ_layers : e->hint_layers;
-    static const bool hint_always = std::getenv("BH_SWD_HINT_ALWAYS") != nullptr; // experiment switch
+    const bool hint_always = bh_tuning().swd_hint_always != 0;
     const int typ_layers = ((long)nlive * B <= 2048 && !hint_always) ? 0 : typ_given;
     int iw[BH_MAX_TARGETS], look[BH_MAX_TARGETS], G = 1;
     {
@@ -415,7 +478,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             wmin = (t == 0 || w < wmin) ? w : wmin;
             wmax = w > wmax ? w : wmax;
         }
-    static const int pair_min = std::getenv("BH_SWD_PAIR_MINWAVES") ? std::atoi(std::getenv("BH_SWD_PAIR_MINWAVES")) : -1;
+    const int pair_min = bh_tuning().swd_pair_minwaves;
     const bool use_pair = B > 1 && !e->no_order && !e->as_given && !e->no_pair && G > 1 && nlive == 2 && bh_pair_order_fits(B) &&
                           plan_waves >= (pair_min >= 0 ? pair_min : 7 * (long)e->pairwork.ncu) && (pair_min >= 0 || 2 * wmax >= 3 * wmin) &&
                           !(typ_layers > 0 && typ_layers + 2 < Lmax);
@@ -542,7 +605,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     a.prio_low = e->swd_prio_low_now;
     a.adapt_ok = (e->force_group == 0 && e->force_look == 0 && e->look_r == 0 && e->look_l == 0) ? 1 : 0;
     {
-        static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
+        const bool dbg = bh_tuning().debug_plan != 0;
         if (dbg) {
             std::fprintf(stderr, "[bh] dispersion plan B=%d Lmax=%d: lanes per model %d, typical layers %d (hint %d), Lcut %d%s, pairing %d; trials per round:",
                          B, Lmax, G, m.typ_layers, e->hint_layers, Lcut, split ? " (two depth classes)" : "", (int)use_pair);
@@ -641,12 +704,12 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     // (with the start gate of bh_evaluate_batch in force the LDS floor is not needed: RF workgroups are dispatched
     // after every dispersion wavefront is resident and only take what finished wavefronts have freed)
     a.lds_min = (beside_swd && !e->rf_coresident_now && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
-    {   // experiment switch: LDS floor of the synthesis workgroups of a GATED fused call (fewer of them per CU at a time)
-        static const int gated_floor = std::getenv("BH_RF_LDS_GATED") ? std::atoi(std::getenv("BH_RF_LDS_GATED")) : 0;
+    {   // (bh_tuning.h: LDS floor of the synthesis workgroups of a GATED fused call -- fewer of them per CU at a time)
+        const int gated_floor = bh_tuning().rf_lds_gated;
         if (beside_swd && e->rf_gated_now && gated_floor > 0) a.lds_min = gated_floor;
     }
     a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
-    a.coef_small = (beside_swd && e->rf_gated_now && std::getenv("BH_RF_COEF_BIG") == nullptr) ? 1 : 0;
+    a.coef_small = (beside_swd && e->rf_gated_now && bh_tuning().rf_coef_big == 0) ? 1 : 0;
     ev_begin(e, 1, st);
     const int lrc = bh_launch_rf(a, st);
     ev_end(e, 1, st);
@@ -719,25 +782,26 @@ int bh_engine_create(int device, bh_engine **out)
         delete e;
         return BH_EHIP;
     }
-    if (std::getenv("BH_NO_OVERLAP")) e->overlap_rf = false;
-    if (const char *g = std::getenv("BH_RF_LDS_BESIDE")) e->rf_lds_beside_swd = std::atoi(g);
-    if (std::getenv("BH_RF_BESIDE")) e->rf_beside = true;
-    if (std::getenv("BH_SWD_NO_PAIR")) e->no_pair = true;
+    const BhTuning &tun = bh_tuning(); // (the experiment switches: parsed once per process, bh_tuning.h)
+    if (tun.no_overlap) e->overlap_rf = false;
+    if (tun.rf_lds_beside >= 0) e->rf_lds_beside_swd = tun.rf_lds_beside;
+    if (tun.rf_beside) e->rf_beside = true;
+    if (tun.swd_no_pair) e->no_pair = true;
     {
         hipDeviceProp_t prop;
         e->pairwork.ncu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
     }
-    if (const char *g = std::getenv("BH_SWD_WPB")) e->swd_wpb_default = e->swd_wpb_now = (std::atoi(g) == 4) ? 4 : 2;
-    if (const char *g = std::getenv("BH_RF_BESIDE_PRIO")) e->rf_beside_prio = std::atoi(g) & 3;
-    if (const char *g = std::getenv("BH_SWD_PRIO_LOW")) e->swd_prio_low = std::atoi(g) != 0 ? 1 : 0;
+    e->swd_wpb_default = e->swd_wpb_now = tun.swd_wpb;
+    e->rf_beside_prio = tun.rf_beside_prio;
+    if (tun.swd_prio_low >= 0) e->swd_prio_low = tun.swd_prio_low != 0 ? 1 : 0;
     {   // the counter the dispersion kernel's workgroups bump at start; hipStreamWaitValue32 polls it from the RF stream
         int can = 0;
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device);
-        if (std::getenv("BH_NO_STARTED")) can = 0; // experiment switch
+        if (tun.no_started) can = 0;
         // rocprofv3 --pmc (counter collection) runs the dispatches of ALL queues one at a time; the RF stream's wait
         // packet then never sees the dispersion kernel start (measured: bench.py --workload c3 hangs under --pmc, runs
         // under --kernel-trace).  The gate is a scheduling aid only: off in that mode.
-        if (std::getenv("ROCPROF_COUNTER_COLLECTION")) can = 0;
+        if (tun.under_pmc) can = 0;
         // plain device memory: the wait packet polls it just as well, and atomics on signal memory
         // (hipMallocSignalMemory) cost the dispersion kernel 1 ms per launch (976 workgroups, one atomic each)
         if (can && hipMalloc((void **)&e->started, 8) != hipSuccess) e->started = nullptr;
@@ -747,20 +811,16 @@ int bh_engine_create(int device, bh_engine **out)
         }
         (void)hipGetLastError();
     }
-    if (const char *g = std::getenv("BH_SWD_GROUP")) e->force_group = std::atoi(g);
-    if (const char *g = std::getenv("BH_SWD_LOOKAHEAD")) e->force_look = std::atoi(g);
-    if (const char *g = std::getenv("BH_SWD_SEARCH"))
-        e->swd_search = (g[0] == 'f' || g[0] == '1') ? ((std::strstr(g, "rayleigh") != nullptr) ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (g[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_REFERENCE);
-    if (const char *g = std::getenv("BH_SWD_PRESCAN")) e->swd_prescan = (g[0] == '0') ? 0 : 1;
-    if (const char *g = std::getenv("BH_SWD_SCAN")) e->swd_scan = (g[0] == 's' || g[0] == '0') ? BH_SCAN_STEPS : ((g[0] == 'c' || g[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
-    if (const char *g = std::getenv("BH_SWD_LOVE_INLOOK")) {
-        e->love_inlook = std::atoi(g);
-        if (e->love_inlook < 0 || e->love_inlook > 4) e->love_inlook = 0;
-    }
-    if (const char *g = std::getenv("BH_SWD_LOOK_R")) e->look_r = std::atoi(g);
-    if (const char *g = std::getenv("BH_SWD_LOOK_L")) e->look_l = std::atoi(g);
-    if (std::getenv("BH_NO_MFMA")) e->no_mfma = true;
-    if (std::getenv("BH_NO_ORDER")) e->no_order = true;
+    e->force_group = tun.swd_group;
+    e->force_look = tun.swd_lookahead;
+    if (tun.swd_search >= 0) e->swd_search = tun.swd_search;
+    if (tun.swd_prescan >= 0) e->swd_prescan = tun.swd_prescan != 0 ? 1 : 0;
+    if (tun.swd_scan >= 0) e->swd_scan = tun.swd_scan;
+    e->love_inlook = tun.swd_love_inlook;
+    e->look_r = tun.swd_look_r;
+    e->look_l = tun.swd_look_l;
+    if (tun.no_mfma) e->no_mfma = true;
+    if (tun.no_order) e->no_order = true;
     *out = e;
     return BH_OK;
 }
@@ -799,6 +859,19 @@ int bh_engine_set_swd_scan(bh_engine *e, int scan)
     return BH_OK;
 }
 int bh_engine_get_swd_scan(const bh_engine *e) { return e ? e->swd_scan : 0; }
+
+int bh_engine_set_tuning(bh_engine *e, const char *name, int value)
+{
+    if (!e) return BH_EINVAL;
+    if (bh_tuning_set(name, value) != 0) return fail(e, BH_EINVAL, "unknown experiment switch (csrc/bh_tuning.h), or a build with BH_NO_EXPERIMENTS");
+    return BH_OK;
+}
+int bh_engine_get_tuning(bh_engine *e, const char *name, int *value)
+{
+    if (!e) return BH_EINVAL;
+    if (bh_tuning_get(name, value) != 0) return fail(e, BH_EINVAL, "unknown experiment switch (csrc/bh_tuning.h)");
+    return BH_OK;
+}
 
 int bh_engine_set_swd_prescan(bh_engine *e, int on)
 {
@@ -1131,7 +1204,6 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     e->targets.swap(tmp);
     e->nt = nt;
     e->ldy = off;
-    if (const char *g = std::getenv("BH_LDY_PAD")) e->ldy += std::atoi(g); // experiment switch: wider rows of synthetics (host callers: want_ymod unsupported with it)
     e->err_t_nt = e->err_t_B = -1;
     return BH_OK;
 }
@@ -1187,7 +1259,7 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     call_begin(e, st);
     // per-target failure flags [nt][B]: the dispersion kernels write every entry of their target's row on every call,
     // nothing writes the rows of the other targets -- they are zeroed once per (nt, B) layout, not once per call
-    static const bool always_zero = std::getenv("BH_ERR_MEMSET") != nullptr; // experiment switch
+    const bool always_zero = bh_tuning().err_memset != 0;
     if (always_zero || e->err_t_nt != nt || e->err_t_B != B) {
         HIPCHK(e, hipMemsetAsync(e->err_t.p, 0, (size_t)nt * B * sizeof(int32_t), st));
         e->err_t_nt = nt;
@@ -1258,7 +1330,7 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     e->rf_coresident_now = false;
     e->rf_gated_now = false;
     if (want_gate && e->last_swd.workgroups > 0) {
-        e->rf_gated_now = std::getenv("BH_RF_KEEP_FLOOR") == nullptr;
+        e->rf_gated_now = bh_tuning().rf_keep_floor == 0;
         size_t rf_lds = 0;
         for (int t = 0; t < nt; ++t)
             if (e->targets[(size_t)t].d.kind == BH_TARGET_RF) {
@@ -1267,7 +1339,7 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
             }
         // more than one dispersion wavefront per SIMD (else the usual build finds room by itself), and the LDS fits
         e->rf_coresident_now = want_beside && e->last_swd.waves > 1024 && 2 * e->last_swd.lds + rf_lds <= BH_RF_MAX_LDS;
-        static const bool dbg = std::getenv("BH_DEBUG_PLAN") != nullptr;
+        const bool dbg = bh_tuning().debug_plan != 0;
         if (dbg)
             std::fprintf(stderr, "[bh] fused call B=%d: dispersion launch %u workgroups, %ld wavefronts, %zu B LDS per workgroup; RF LDS %zu B; "
                          "co-resident RF: %d\n", B, e->last_swd.workgroups, e->last_swd.waves, e->last_swd.lds, rf_lds, (int)e->rf_coresident_now);
@@ -1289,8 +1361,7 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
         // Fused likelihood ("write nothing if the likelihood is fused"): the caller did not ask for the
         // synthetics and the target's law needs only sums over the trace -- the synthesis kernel forms them from the samples
         // in LDS (like_kernel's order: the same bits) and writes four numbers per model instead of the trace.
-        static const bool no_fuse = std::getenv("BH_RF_NO_FUSE") != nullptr; // experiment switch
-        T.fused = !ymod && !no_fuse && (d.law == BH_LAW_NOCORR || d.law == BH_LAW_EXP) && std::getenv("BH_RF_THREADS") == nullptr;
+        T.fused = !ymod && bh_tuning().rf_no_fuse == 0 && (d.law == BH_LAW_NOCORR || d.law == BH_LAW_EXP) && bh_tuning().rf_threads != 128;
         if (T.fused && (rc = ensure(e, T.sums, (size_t)B * 4 * sizeof(double)))) return rc;
         rc = launch_rf(e, rst, B, Lmax, m, sl, sb, d.p_s_per_deg, d.gauss, d.nsamp, d.fsamp, d.tshift,
                        d.nsv, d.waveno, d.n, ymod_d + T.off, ldy, fork, T.fused ? (const double *)T.yobs.p : nullptr,

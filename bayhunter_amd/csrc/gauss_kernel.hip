@@ -15,6 +15,7 @@
 // the MFMAs of the current one run (register double buffer).  Column slabs are summed later in a
 // fixed order by like_kernel, so the result does not depend on scheduling (no atomics).
 #include "bh_device.h"
+#include "bh_tuning.h"
 #include <cstdlib>
 
 namespace {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(512) void gauss_quad_kernel_128(int B, int n, int l
 // the 128 x 128 form pays where its grid fills the chip: at least one workgroup for every second CU
 static bool use_big_tiles(int B, int n)
 {
-    static const int force = std::getenv("BH_GAUSS_TILE") ? std::atoi(std::getenv("BH_GAUSS_TILE")) : 0; // experiment switch: 64 / 128
+    const int force = bh_tuning().gauss_tile; // (bh_tuning.h: 64 / 128)
     if (force == 64) return false;
     if (force == 128) return true;
     return (long)((B + BM - 1) / BM) * ((n + BN - 1) / BN) >= 128;

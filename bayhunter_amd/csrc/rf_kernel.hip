@@ -22,6 +22,7 @@
 //                       four workgroups per CU);
 //                       only the first nkeep real samples are written (rfmini_modrf.py:142).
 #include "bh_device.h"
+#include "bh_tuning.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -833,10 +834,10 @@ size_t bh_rf_lds_bytes(int nsamp)
 int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
 {
     RfKernelArgs a = a_in;
-    a.no_realc = std::getenv("BH_RF_NO_REALC") != nullptr ? 1 : 0; // experiment switches
-    a.no_rot = std::getenv("BH_RF_NO_ROT") != nullptr ? 1 : 0;
-    const char *tv = std::getenv("BH_RF_THREADS");
-    const int nthr = (tv != nullptr && std::atoi(tv) == 128) ? 128 : 256;
+    const BhTuning &tun = bh_tuning(); // (experiment switches, bh_tuning.h)
+    a.no_realc = tun.rf_no_realc != 0 ? 1 : 0;
+    a.no_rot = tun.rf_no_rot != 0 ? 1 : 0;
+    const int nthr = (tun.rf_threads == 128) ? 128 : 256;
     const int half = a.nsamp / 2;
     int logm = 0;
     while ((1 << logm) < half) ++logm;
@@ -865,14 +866,13 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     // Such bins are set to zero instead of being computed (the reference computes them and multiplies by ~0).  With
     // a = 2.5, 20 Hz, nsamp 2048 that is every bin above 5.0 Hz: 510 of 1025 are computed, 8 passes of 64 lanes per model
     // (round 2 cut at 1e-30: 678 bins, 11 passes).  tests/test_gpu_rf.py compares with the uncut transform (1e-13).
-    const bool no_cut = std::getenv("BH_RF_NO_CUT") != nullptr; // experiment switch, read per launch (tests toggle it)
+    const bool no_cut = tun.rf_no_cut != 0; // (tests flip it with bh_engine_set_tuning)
     const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
     const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
-    const char *wv = std::getenv("BH_RF_WAVES");
     if (a.beside)
         hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
-    else if (wv != nullptr && std::atoi(wv) == 3)
+    else if (tun.rf_waves == 3)
         hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else
         hipLaunchKernelGGL(rf_synth_kernel, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);

@@ -4,6 +4,7 @@
 // glibc-exact sincos / exp; hoisted out of the loop they cost more registers than the kernel has.
 #include "../../include/bh_engine.h"
 #include "bh_device.h"
+#include "bh_tuning.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -359,10 +360,16 @@ restart_with_the_reference_sequence:
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
     // on omega and the model only, not on the trial phase velocity -> recomputed when omega changes
+    // (the build with both sequences AND the counted scan has no registers to keep them in: formed anew every round there)
+    constexpr bool CACHE = !(CNTB && FASTM == 1);
     double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
     const bool prof = PROF && (A.neval != nullptr);
+    // (the phase clocks are a development aid; the one-model-per-wavefront build with both sequences and the counted scan has
+    //  no registers for them)
     long long tA = 0, tB = 0, tS = 0, t0 = 0, t1c = 0, t2c = 0;
-    const unsigned long long w_start = prof ? wall_clock64() : 0ull, c_start = prof ? clock64() : 0ull;
+    constexpr bool CLK = PROF && !(ADAPT && CNTB && FASTM == 1);
+    const bool clocks = CLK && (A.neval != nullptr);
+    const unsigned long long w_start = clocks ? wall_clock64() : 0ull, c_start = clocks ? clock64() : 0ull;
     unsigned int nrounds = 0;
     // Two wavefronts share a SIMD; at equal priority the hardware serves the OLDER one first (MI355X_MICROARCH.md,
     // "two waves per SIMD"): the older runs its rounds in ~13 k cycles, the younger in ~17 k, finishes 30 % later and
@@ -487,7 +494,7 @@ restart_with_the_reference_sequence:
             }
         }
         // All lanes take part in the evaluation (finished models compute on stale values).
-        if (prof) t0 = clock64();
+        if (clocks) t0 = clock64();
         const double omg = S.omega;
         const int cb = rr * JL + (li % JL); // the trial this lane carries through the recursion
         // (Rayleigh wavefronts take the instantiations without the counted scan -- `ifunc` is uniform per wavefront)
@@ -499,7 +506,7 @@ restart_with_the_reference_sequence:
             double omega = omg;
             if (omega < 1.0e-4) omega = 1.0e-4;
             const double wvno2 = wvno * wvno;
-            if (omega != c_omega) {
+            if (!CACHE || omega != c_omega) {
                 c_omega = omega;
                 if (li <= mmax - 2) {
                     const double am = md.A(li), bm = md.Bv(li);
@@ -565,7 +572,7 @@ restart_with_the_reference_sequence:
                 e[4] = wvno2 - ra * rb;
             }
             wave_sync();
-            if (prof) t1c = clock64();
+            if (clocks) t1c = clock64();
             // ---- phase B: the sequential recursion, bottom-up over the parked layers -----------
             {
                 double e0[5] = {e[0], e[1], e[2], e[3], e[4]};
@@ -600,7 +607,7 @@ restart_with_the_reference_sequence:
             wave_sync();
         } else {
             const double omega = omg;
-            if (omega != c_omega) {
+            if (!CACHE || omega != c_omega) {
                 c_omega = omega;
                 if (li <= mmax - 2) c_xkb = omega / md.Bv(li);
                 const double beta1 = md.Bv(mmax - 1);
@@ -660,7 +667,7 @@ restart_with_the_reference_sequence:
                 lc.reset(wvno > xkb);
             }
             wave_sync();
-            if (prof) t1c = clock64();
+            if (clocks) t1c = clock64();
             {
                 const double s1 = e1, s2 = e2;
                 const LoveCount lc0 = lc;
@@ -680,7 +687,7 @@ restart_with_the_reference_sequence:
             if (CNTB) nv = lc.packed(e1, e2);
             wave_sync();
         }
-        if (prof) t2c = clock64();
+        if (clocks) t2c = clock64();
         auto consume = [&](auto cnt_tag) {
             constexpr bool CNT = decltype(cnt_tag)::value;
         // Every lane of the model can read all J (velocity, value) pairs; the search consumes them for
@@ -804,7 +811,7 @@ restart_with_the_reference_sequence:
         };
         if (!CNTB || ifunc == 2) consume(std::false_type{});
         else consume(std::integral_constant<bool, CNTB>{});
-        if (prof) {
+        if (clocks) {
             const long long t3 = clock64();
             tA += t1c - t0;
             tB += t2c - t1c;
@@ -844,11 +851,13 @@ restart_with_the_reference_sequence:
             atomicAdd(A.neval + (ifunc == 2 ? 10 : 11), lps);
             // development aid: wave-cycles per phase, [1..3] Rayleigh A/B/state, [4..6] Love
             const int o = (ifunc == 2) ? 1 : 4;
-            atomicAdd(A.neval + o, (unsigned long long)tA);
-            atomicAdd(A.neval + o + 1, (unsigned long long)tB);
-            atomicAdd(A.neval + o + 2, (unsigned long long)tS);
+            if (clocks) {
+                atomicAdd(A.neval + o, (unsigned long long)tA);
+                atomicAdd(A.neval + o + 1, (unsigned long long)tB);
+                atomicAdd(A.neval + o + 2, (unsigned long long)tS);
+            }
             const unsigned long long widx = atomicAdd(A.neval + 7, 1ull);
-            if (widx < BH_TRACE_WAVES) { // development aid: one record per wavefront (tools/gpu_trace.py)
+            if (clocks && widx < BH_TRACE_WAVES) { // development aid: one record per wavefront (tools/gpu_trace.py)
                 unsigned long long *r = A.neval + BH_COUNTER_WORDS + 4 * widx;
                 unsigned hwid, xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -955,7 +964,8 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
         maxmode = a0.t[t].mode > maxmode ? a0.t[t].mode : maxmode;
     }
-    static const int redundant = (std::getenv("BH_SWD_REDUNDANT") ? 0x100 : 0) | (std::getenv("BH_SWD_NO_BOARD") ? 0x400 : 0) | (std::getenv("BH_SWD_NO_FAIR") ? 0x800 : 0); // experiment switches
+    const BhTuning &tun = bh_tuning(); // (experiment switches, bh_tuning.h)
+    const int redundant = (tun.swd_redundant ? 0x100 : 0) | (tun.swd_no_board ? 0x400 : 0) | (tun.swd_no_fair ? 0x800 : 0);
     SwdMultiArgs a = a0;
     const bool two = a0.split != nullptr && a0.Lcut < a0.Lmax;
     if (!two) a.split = nullptr;
@@ -1026,7 +1036,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     }
     dim3 grid((nwaves + wpb - 1) / wpb, a.ntargets, two ? 2 : 1);
     a.wg_n0 = a.wg_n1 = 0;
-    static const bool no_mix = std::getenv("BH_SWD_NO_MIX") != nullptr; // experiment switch
+    const bool no_mix = tun.swd_no_mix != 0;
     if (a.ntargets == 2 && !two && !no_mix && !a.rerun) { // two targets, one depth class: interleave their wavefronts (see the kernel)
         int n[2];
         for (int t = 0; t < 2; ++t) {
@@ -1092,7 +1102,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // One model per wavefront for every target (a chain window, a single model), one class, the usual targets: every wavefront
     // sizes its lane groups and trials for its own model (ADAPT, see the kernel) within the region all wavefronts can be
     // resident with.
-    static const bool no_adapt = std::getenv("BH_SWD_NO_ADAPT") != nullptr; // experiment switch
+    const bool no_adapt = tun.swd_no_adapt != 0;
     // (capacity up to 32 rows: at least two trials fit the region; deeper arrays keep the launcher's own choice of fewer, wider
     // lane groups in a larger region)
     bool adapt = a.adapt_ok && !no_adapt && !two && wpb == GROUP_WPB && a.Lmax <= 32 && a.Lmax >= 2;
@@ -1124,12 +1134,12 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         any_modes = any_modes || a.t[t].mode > 1;
     }
     // (one model per wavefront and SwdMultiArgs::restart: the build with both sequences, guarded models restart in place)
-    static const bool no_restart = std::getenv("BH_SWD_NO_RESTART") != nullptr; // experiment switch
+    const bool no_restart = tun.swd_no_restart != 0;
     const bool restart = adapt && a.restart != 0 && a.fast && any_phase && !no_restart;
     a.restart = restart ? 1 : 0;
     if (info != nullptr) info->restarts_in_place = restart ? 1 : 0;
     const int build = (a.fast && any_phase) ? ((any_group || any_refseq || restart) ? 1 : 2) : 0;
-    static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
+    const bool no_simple = tun.swd_no_simple != 0;
     const bool simple = !any_group && !any_modes && !no_simple;
     a.fast = build;
     const dim3 block(BH_WAVE * wpb);
@@ -1148,7 +1158,9 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches of the reference's sequence (the
     // Rayleigh wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
     // (BH_SCAN_AUTO with the certified-sign scan on: that scan serves Love as well -- one look instead of jump + index search)
-    const bool cntb = any_love && wpb == GROUP_WPB && (a.counted == 1 || (a.counted == 2 && a.prescan == 0 && !adapt && (all_love ? build != 1 : build == 2)));
+    // (not in a launch of several models per wavefront that mixes both refinements: that build would spill; one model per
+    //  wavefront -- the chains' windows -- has it)
+    const bool cntb = any_love && wpb == GROUP_WPB && !(build == 1 && !adapt) && (a.counted == 1 || (a.counted == 2 && a.prescan == 0 && !adapt && (all_love ? build != 1 : build == 2)));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
@@ -1186,7 +1198,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     } else if (build == 2) {
         BH_GROUP_LAUNCH(GROUP_WPB, 2, false, true);
     } else if (build == 1) {
-        BH_GROUP_LAUNCH(GROUP_WPB, 1, false, true);
+        BH_GROUP_LAUNCH_(GROUP_WPB, 1, false, true, false, false);
     } else if (simple) {
         if (counted) BH_GROUP_LAUNCH(GROUP_WPB, 0, true, true);
         else BH_GROUP_LAUNCH(GROUP_WPB, 0, true, false);

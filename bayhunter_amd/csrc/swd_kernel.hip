@@ -30,6 +30,7 @@
 //     restatements of the host libm the reference links (bh_libm.h): results are bit-identical.
 #include "../../include/bh_engine.h"
 #include "bh_device.h"
+#include "bh_tuning.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -493,8 +494,8 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     int J = 1;
     while (2 * J <= a.look && 2 * J <= 16) J *= 2; // largest power of two <= look
     b.look = J;
-    static const int no_fair = std::getenv("BH_SWD_NO_FAIR") ? 1 : 0; // experiment switches
-    static const int slice = std::getenv("BH_SWD_SLICE") ? std::atoi(std::getenv("BH_SWD_SLICE")) : 0;
+    const int no_fair = bh_tuning().swd_no_fair ? 1 : 0; // (experiment switches, bh_tuning.h)
+    const int slice = bh_tuning().swd_slice;
     b.fair = (no_fair || a.fair < 0) ? 0 : (slice > 0 ? slice : (a.fair > 0 ? a.fair : 16));
     const int mpw = BH_WAVE / J;
     const int waves = (a.B + mpw - 1) / mpw;
@@ -505,7 +506,7 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
     const size_t lds = LANE_TAB_PAD + (two ? 2 : 1) * wb;
     const dim3 grid(two ? (waves + 1) / 2 : waves), block((two ? 2 : 1) * BH_WAVE);
     // (wave type, look-ahead, wavefronts per workgroup, refinement) -> instantiation
-    static const bool no_simple = std::getenv("BH_SWD_NO_SIMPLE") != nullptr; // experiment switch
+    const bool no_simple = bh_tuning().swd_no_simple != 0;
     // Measured (c2 batches, with / without): reference sequence -3 % at B = 16 384 (4 trial lanes per model) but +4 % at
     // 65 536 and +6 % at 131 072 (one lane per model: the Love build drops to 165 registers there, a third wavefront per SIMD
     // upsets the Rayleigh / Love pairs the time-sliced priorities are tuned for); short refinement -3 % at 65 536.

@@ -111,6 +111,8 @@ def load_library():
     L.bh_engine_get_swd_search.argtypes = [vp]
     L.bh_engine_set_swd_scan.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_scan.argtypes = [vp]
+    L.bh_engine_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
+    L.bh_engine_get_tuning.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.bh_engine_set_swd_prescan.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_prescan.argtypes = [vp]
     L.bh_engine_guard_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -137,7 +139,7 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
@@ -149,7 +151,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -451,6 +453,15 @@ class Engine(object):
         self._check(self._L.bh_loglike_batch(self._h, HOST, None, B, _ptr(ymod), _ptr(fail), _ptr(noise),
                                              _ptr(logL), _ptr(misf), _ptr(err)))
         return logL, misf, err
+
+    def set_tuning(self, name, value):
+        """An experiment switch of the library (csrc/bh_tuning.h; process-wide, never changes a result)."""
+        self._check(self._L.bh_engine_set_tuning(self._h, name.encode(), int(value)))
+
+    def tuning(self, name):
+        v = C.c_int(0)
+        self._check(self._L.bh_engine_get_tuning(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_swd_prescan(self, on):
         """The certified-sign scan (include/bh_engine.h: bh_engine_set_swd_prescan; on by default, bit-identical results)."""

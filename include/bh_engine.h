@@ -84,74 +84,56 @@ int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
  * lanes, the velocities the search will most probably ask for next and hands them over if and only
  * if it does.  Results do not depend on it. */
 int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
-/* Root refinement of the dispersion search.
- *   BH_SEARCH_REFERENCE: the reference's sequence of secular-function evaluations (getsol + nevill,
- *     surfdisp96.f:390-686), evaluation for evaluation: velocities bit-identical to the reference's.  What a replay of
- *     chains recorded with the reference needs (bayhunter_amd.chains.ChainBatch sets it for its calls).
- *   BH_SEARCH_FAST (default since ABI 7, when its failure flags became the reference's): the same bracket scan (the same bracket, hence the same root), but inside the bracket ~3 evaluations
- *     (regula falsi, then an inverse-quadratic estimate accepted on a sign change within +-5e-8 relative) instead of
- *     nevill's 10-12, whose stop test is the bracket width.  FUNDAMENTAL-MODE phase-velocity targets only (mode = 1, the
- *     reference's default; targets with higher modes keep the reference sequence: their modes lie close together at short
- *     periods, pairs of roots inside one scan step, and which of them a scan finds hinges on the last bits of the previous
- *     mode's root; group-velocity targets keep
- *     the reference sequence: a group velocity is a difference quotient of two roots and amplifies their scatter a
- *     hundredfold).  Velocities within 1.2e-6 relative of the reference's (north_star's tolerance: 1e-5).  The failure
- *     flag and the period from which a failed model's row is zero are the REFERENCE's: where the reference's own outcome
- *     hinges on a 1e-6 shift of its scan grid (a root and its mirror image around a half-space velocity closer together
- *     than a scan step) a guard detects the situation with one or two probe evaluations and the model is
- *     run again with the reference's sequence -- in a second, small launch of the same call, or, in launches of one model
- *     per wavefront, right away in the model's own wavefront (bh_engine_guard_stats counts both).
- *     A deterministic function of the model (independent of batch and launch plan), but NOT the
- *     reference's bits: chains replayed against the reference need BH_SEARCH_REFERENCE.
- * Also BH_SWD_SEARCH=reference|fast|fast_rayleigh in the environment at engine creation. */
+/* Root refinement of the dispersion search (surfdisp96.f:390-686).
+ *   BH_SEARCH_REFERENCE  the reference's sequence of secular-function evaluations (getsol + nevill), evaluation for
+ *                        evaluation: velocities and failure flags bit-identical to the reference's.
+ *   BH_SEARCH_FAST       (the default) the reference's bracket scan -- the same bracket, hence the same root -- and inside the
+ *                        bracket three evaluations instead of nevill's ten to twelve.  GUARANTEES: velocities within 1e-5
+ *                        relative of the reference's (achieved: 1.2e-6); the failure flag and the period from which a failed
+ *                        model's row is zero are the reference's (a model whose outcome could hinge on the last bits of a
+ *                        root is detected and run again with the reference's sequence inside the same call;
+ *                        bh_engine_guard_stats counts them); the result is a function of the model alone (not of the batch
+ *                        or the launch).  NOT the reference's bits.  Applies to fundamental-mode phase-velocity targets;
+ *                        group-velocity targets and targets with higher modes always take the reference's sequence.
+ *   BH_SEARCH_FAST_RAYLEIGH  BH_SEARCH_FAST for Rayleigh targets, BH_SEARCH_REFERENCE for Love targets.
+ * A replay against chains recorded with the reference needs BH_SEARCH_REFERENCE. */
 #define BH_SEARCH_REFERENCE 0
 #define BH_SEARCH_FAST 1
-/* BH_SEARCH_FAST for the Rayleigh phase-velocity targets only; Love targets keep the reference's sequence (with the counted
- * scan).  The guard fires on ~2 % of a transdimensional sampler's Love proposals (periods out to 60 s over models a few layers
- * deep: the Love root creeps up to the half-space velocity) and on < 1e-5 of its Rayleigh proposals (bench.py c4 / c5); this
- * mode avoids those re-runs.  Since launches of one model per wavefront -- a sampler's windows, single models -- let a guarded
- * model start again with the reference's sequence inside its own wavefront (no second launch; the guarded models of a window
- * are its shallow ones and are done before its deep ones), BH_SEARCH_FAST is the faster of the two for samplers as well
- * (c4 4.6 -> 5.2e4, c5 1.65 -> 1.83e5 chain-iterations/s) and what bayhunter_amd.DeviceChains takes. */
 #define BH_SEARCH_FAST_RAYLEIGH 2
 int bh_engine_set_swd_search(bh_engine *e, int search);
 int bh_engine_get_swd_search(const bh_engine *e);
-/* The bracket scan of Love targets (all search modes).
- *   getsol's scan (surfdisp96.f:437-460) looks for the first step of its grid c1 + i dc over which the secular function
- *   changes sign, one evaluation per step.  For Love waves the number of sign changes below a trial velocity can be read
- *   off the very recursion that evaluates the function (Sturm's oscillation theorem for the SH problem: zeros of the
- *   displacement in the layers, csrc/swd_common.h LoveCount), so two evaluations certify that none of the steps between
- *   them shows a sign change -- they are skipped -- or that exactly one does -- it is located by a search over the step
- *   index.  The grid points are the reference's (repeated additions of dc), the bracket handed to the refinement is the
- *   reference's, hence every bit of the result: same velocities, same failure flags, a third of the scan's evaluations
- *   (c2 Love: 927 -> 470 evaluations per model; with BH_SEARCH_FAST 673 -> 216).
- *   BH_SCAN_STEPS: every step evaluated, as the reference does.
- *   BH_SCAN_COUNTED: the counted scan wherever a launch holds a Love target (and the build exists: not in the one-model-per-
- *     wavefront launch that mixes both refinements, BH_SEARCH_FAST_RAYLEIGH).
- *   BH_SCAN_AUTO (default): the counted scan where it is measured to pay -- with several models per wavefront: launches of
- *     Love targets only (4096 models: 2.06 -> 1.71 ms) and Rayleigh + Love launches of BH_SEARCH_FAST (whose Love wavefronts
- *     are the long ones: c2 2.51 -> 2.30 ms) --, and the lane-per-model kernels.  Where Rayleigh wavefronts set the time anyway
- *     (the reference's sequence), or the trial lanes already walk the scan seven steps a round (one model per wavefront), its
- *     state machine costs what it saves.
- * Results never depend on it.  Rayleigh targets always step (no such count for the P-SV problem here).  Also
- * BH_SWD_SCAN=steps|counted|auto in the environment at engine creation. */
+/* The bracket scan of Love targets (any root refinement).  Results never depend on this setting.
+ * getsol's scan (surfdisp96.f:437-460) evaluates every step of its grid until the secular function changes sign.  For Love
+ * waves the number of sign changes below a trial velocity is read off the recursion that evaluates the function (a Sturm
+ * count), so two evaluations prove that the steps between them hold no sign change (they are skipped) or exactly one (it is
+ * located by a search over the step index).  Grid points, bracket and every bit after it are the reference's.
+ *   BH_SCAN_STEPS    every step evaluated, as the reference does.
+ *   BH_SCAN_COUNTED  the counted scan wherever a launch holds a Love target -- except launches of several models per
+ *                    wavefront that mix both root refinements (that kernel build does not carry it).
+ *   BH_SCAN_AUTO     (default) the counted scan in the launches where it is measured to pay.
+ * Rayleigh targets always step. */
 #define BH_SCAN_STEPS 0
 #define BH_SCAN_COUNTED 1
 #define BH_SCAN_AUTO 2
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
 
-/* The certified-sign scan (OFF by default; results are bit-identical either way).  getsol's bracket scan
- * (surfdisp96.f:437-460) consumes only the SIGN of the secular function at its grid points; with this on, a search first
+/* The certified-sign scan (OFF by default).  Results never depend on this setting.
+ * getsol's bracket scan consumes only the SIGN of the secular function at its grid points.  With this on, a search first
  * evaluates the grid ahead with a cheap evaluation of the same recursion that carries an error bound (one lane per grid
- * point), and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's -- the
+ * point) and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's; the
  * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
- * step-by-step scan, with 2-3 reference-exact evaluations per scan instead of ~15.  Applies to both root refinements, all
- * target types, in launches with several models per wavefront (a few hundred to ~16 000 models per call); elsewhere the
- * setting is ignored.  Off by default because, measured on MI355X, the look-ahead costs the vector issue slots the skipped
- * rounds would have used; kept as a tested option. */
+ * step-by-step scan.  Applies to both root refinements and all target types in launches of several models per wavefront
+ * (a few thousand models per call); ignored elsewhere.  DESIGN.md 3.1c has the measurement that keeps it off. */
 int bh_engine_set_swd_prescan(bh_engine *e, int on);
 int bh_engine_get_swd_prescan(const bh_engine *e);
+
+/* Experiment switches (csrc/bh_tuning.h lists them: name, environment variable, default, meaning).  They change scheduling
+ * and launch geometry, never a result.  The table is filled once per process from the environment; this call changes one
+ * entry for the calls that follow (process-wide).  BH_EINVAL for an unknown name, and always in a build with
+ * -DBH_NO_EXPERIMENTS.  Not needed by a caller that only wants results. */
+int bh_engine_set_tuning(bh_engine *e, const char *name, int value);
+int bh_engine_get_tuning(bh_engine *e, const char *name, int *value);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
  * dispersion call that its guard sent back to the reference's sequence (listed for the re-run launch, or restarted in place
  * in a launch of one model per wavefront); *rerun_launches (may be NULL) = re-run launches

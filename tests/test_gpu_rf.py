@@ -58,19 +58,21 @@ def test_quality_factors_and_nsv(engine, oracle):
         assert np.max(np.abs(rf[b] - o)) <= TOL * np.abs(o).max()
 
 
-def test_spectral_cutoff_changes_nothing_and_nonfinite_models_stay_nonfinite(engine, oracle, monkeypatch):
+def test_spectral_cutoff_changes_nothing_and_nonfinite_models_stay_nonfinite(engine, oracle):
     """bins the Gauss low-pass puts below 1e-30 are not computed (rf_kernel.hip).  (1) With and without the
-    cut-off (BH_RF_NO_CUT) the traces agree to 1e-13 of the peak on random models, for the c3 filter (a third of the bins
+    cut-off (experiment switch rf_no_cut) the traces agree to 1e-13 of the peak on random models, for the c3 filter (a third of the bins
     cut) and the tutorial's (three quarters).  (2) The reference computes every bin, so a model whose coefficients are
     not finite gives an all-NaN trace there; the cut-off must not turn it into a finite one: same NaN rows as the oracle."""
     rs = np.random.RandomState(77)
     nlay, h, vp, vs, rho = synth_models(rs, 64, 12, lvz_frac=0.3, ragged=True)
     for gauss, nsamp, fsamp, nkeep in ((2.5, 2048, 20.0, 1024), (1.0, 512, 5.0, 201)):
-        monkeypatch.delenv("BH_RF_NO_CUT", raising=False)
+        engine.set_tuning("rf_no_cut", 0)
         cut = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, gauss, nsamp, fsamp, 5.0, 0, nkeep)
-        monkeypatch.setenv("BH_RF_NO_CUT", "1")
-        full = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, gauss, nsamp, fsamp, 5.0, 0, nkeep)
-        monkeypatch.delenv("BH_RF_NO_CUT")
+        engine.set_tuning("rf_no_cut", 1)       # (an experiment switch of the library, csrc/bh_tuning.h)
+        try:
+            full = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, gauss, nsamp, fsamp, 5.0, 0, nkeep)
+        finally:
+            engine.set_tuning("rf_no_cut", 0)
         assert np.isfinite(full).all()
         assert np.max(np.abs(cut - full) / np.abs(full).max(axis=1, keepdims=True)) <= 1e-13
     # broken models: an infinite velocity, a NaN density, a zero S velocity in the crust

@@ -311,3 +311,24 @@ def test_broken_models_are_failed_in_band(engine, oracle):
     finally:
         engine.set_swd_group(0)
         engine.set_swd_lookahead(0)
+
+
+def test_experiment_switches_are_a_table_with_an_api(engine):
+    """csrc/bh_tuning.h: the library's experiment switches are parsed once per process; bh_engine_set_tuning changes one by name,
+    unknown names are refused, and none of them changes a result (here: the progress board and the SIMD-pairing order)."""
+    from bayhunter_amd.engine import EngineError
+    assert engine.tuning("rf_no_cut") == 0 and engine.tuning("swd_wpb") == 2
+    with pytest.raises(EngineError):
+        engine.set_tuning("no_such_switch", 1)
+    rs = np.random.RandomState(3)
+    nlay, h, vp, vs, rho = synth_models(rs, 4096, 10, lvz_frac=0.1)
+    per = np.linspace(2, 60, 30)
+    v0, e0 = engine.swd_batch(nlay, h, vp, vs, rho, per, 2, 0)
+    for name in ("swd_no_board", "swd_no_fair", "swd_no_simple"):
+        engine.set_tuning(name, 1)
+        try:
+            assert engine.tuning(name) == 1
+            v1, e1 = engine.swd_batch(nlay, h, vp, vs, rho, per, 2, 0)
+        finally:
+            engine.set_tuning(name, 0)
+        assert np.array_equal(v0, v1) and np.array_equal(e0, e1), name

@@ -19,4 +19,4 @@ for f in (sys.argv[1:] or ["swd_group_kernel.hip", "swd_kernel.hip"]):
         else:
             cur[k.split(" ")[0]] = v
             if k.startswith("LDS"):
-                print("%-70s VGPR %3s SGPR %3s scratch %4s occ %s" % (cur["name"][:70], cur.get("VGPRs"), cur.get("SGPRs"), cur.get("ScratchSize"), cur.get("Occupancy")))
+                print("%-62s VGPR %3s SGPR %3s scratch %4s occ %s" % (cur["name"].replace(" ", "")[:62], cur.get("VGPRs"), cur.get("SGPRs"), cur.get("ScratchSize"), cur.get("Occupancy")))
