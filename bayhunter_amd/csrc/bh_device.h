@@ -79,6 +79,7 @@ struct SwdKernelArgs {
     double *nev_high; // work array [bh_swd_nev_high_doubles(B, look)]: Neville orders the kernel does not keep in LDS
     int fast;         // 1: the build with the short refinement (SearchT<.., FAST>; phase-velocity targets take it)
     int counted;      // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
+    int farith;       // 1: a launch of the short refinement (fundamental-mode phase velocities) computes with the fast arithmetic (swd_fa.h)
     int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
 };
 
@@ -131,6 +132,8 @@ struct SwdMultiArgs {
     int counted;       // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
     int rerun;         // 1: the launch re-runs listed models (SwdTarget::count): plain two-dimensional grid, no SIMD pairing
     int prescan;       // 1: scans look ahead over their grid with the certified-sign evaluation (SearchT<.., PRE>; same bits)
+    int farith;        // 1: launches in which every target takes the short refinement evaluate the secular functions with the fast
+                       //    arithmetic (swd_fa.h, swd_group_kernel<.., FA>); set to what took effect by the launcher
     int restart;       // 1: in a launch of one model per wavefront a model the guard fires on starts again with the reference's
                        //    sequence in its own wavefront (the build with both sequences) instead of being listed for a re-run launch
     SwdTarget t[8];
@@ -162,8 +165,12 @@ struct SwdLaunchInfo {
     unsigned workgroups; // of the launch (what SwdMultiArgs::started is advanced by)
     long waves;          // wavefronts that do work
     size_t lds;          // bytes per workgroup
+    int fast_arith;      // the launch evaluates with the fast arithmetic (SwdMultiArgs::farith took effect)
     int restarts_in_place; // the launch handles guarded models itself (SwdMultiArgs::restart took effect): no re-run launch needed
 };
+// the launches of the builds with the fast arithmetic (swd_group_fa.hip); called by bh_launch_swd_group
+void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
+                            bool adapt, bool counted, bool cntb);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
                         SwdPairWork *pair = nullptr);
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies

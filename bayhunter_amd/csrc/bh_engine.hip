@@ -27,6 +27,7 @@ int tuning_value(const char *env, const char *txt, int dflt)
 {
     if (!txt) return dflt;
     if (!std::strcmp(env, "BH_SWD_SEARCH")) return (txt[0] == 'f' || txt[0] == '1') ? ((std::strstr(txt, "ray") || txt[0] == '2') ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_FAST) : (txt[0] == '2' ? BH_SEARCH_FAST_RAYLEIGH : BH_SEARCH_REFERENCE);
+    if (!std::strcmp(env, "BH_SWD_ARITH")) return (txt[0] == 'e' || txt[0] == '0') ? BH_ARITH_EXACT : BH_ARITH_FAST;
     if (!std::strcmp(env, "BH_SWD_SCAN")) return (txt[0] == 's' || txt[0] == '0') ? BH_SCAN_STEPS : ((txt[0] == 'c' || txt[0] == '1') ? BH_SCAN_COUNTED : BH_SCAN_AUTO);
     char *end = nullptr;
     const long v = std::strtol(txt, &end, 10);
@@ -142,6 +143,7 @@ struct bh_engine {
     int force_look = 0;  // BH_SWD_LOOKAHEAD env / bh_engine_set_swd_lookahead: 0 = choose automatically
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
+    int swd_arith = BH_ARITH_FAST; // bh_engine_set_swd_arith / BH_SWD_ARITH=exact|fast: fast arithmetic in launches where every target takes the short refinement
     int swd_prescan = 0; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits; off by default: DESIGN.md 3.1c)
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
@@ -545,6 +547,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             a.nev_high = (double *)e->nevhi.p + nev_off[nth];
             a.fast = (J.igr == 0 && J.mode <= 1 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && J.iwave == BH_WAVE_RAYLEIGH))) ? 1 : 0;
             a.counted = e->swd_scan;
+            a.farith = (a.fast && e->swd_arith == BH_ARITH_FAST) ? 1 : 0;
             if (a.fast) {
                 a.gcount = gcounts + nth;
                 a.glist = glists + (size_t)nth * (size_t)(B + 4);
@@ -597,6 +600,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     };
     a.counted = e->swd_scan;
     a.prescan = e->swd_prescan;
+    a.farith = e->swd_arith == BH_ARITH_FAST ? 1 : 0;
     for (int t = 0; t < a.ntargets; ++t) {
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
         if (e->look_l > 0 && a.t[t].iwave == BH_WAVE_LOVE) a.t[t].look = e->look_l;
@@ -815,6 +819,7 @@ int bh_engine_create(int device, bh_engine **out)
     e->force_look = tun.swd_lookahead;
     if (tun.swd_search >= 0) e->swd_search = tun.swd_search;
     if (tun.swd_prescan >= 0) e->swd_prescan = tun.swd_prescan != 0 ? 1 : 0;
+    if (tun.swd_arith >= 0) e->swd_arith = tun.swd_arith != 0 ? BH_ARITH_FAST : BH_ARITH_EXACT;
     if (tun.swd_scan >= 0) e->swd_scan = tun.swd_scan;
     e->love_inlook = tun.swd_love_inlook;
     e->look_r = tun.swd_look_r;
@@ -873,6 +878,14 @@ int bh_engine_get_tuning(bh_engine *e, const char *name, int *value)
     return BH_OK;
 }
 
+int bh_engine_set_swd_arith(bh_engine *e, int arith)
+{
+    if (!e) return BH_EINVAL;
+    if (arith != BH_ARITH_EXACT && arith != BH_ARITH_FAST) return fail(e, BH_EINVAL, "arith must be BH_ARITH_EXACT (0) or BH_ARITH_FAST (1)");
+    e->swd_arith = arith;
+    return BH_OK;
+}
+int bh_engine_get_swd_arith(const bh_engine *e) { return e ? e->swd_arith : 0; }
 int bh_engine_set_swd_prescan(bh_engine *e, int on)
 {
     if (!e) return BH_EINVAL;

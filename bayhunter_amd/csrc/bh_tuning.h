@@ -6,8 +6,8 @@
 // inside a process use bh_engine_set_tuning(name, value) (the name is the field's name below).  A build with
 // -DBH_NO_EXPERIMENTS ignores the environment and refuses bh_engine_set_tuning: every switch has its default.
 //
-// The ENGINE SETTINGS with an API of their own (bh_engine_set_swd_search / _scan / _prescan / _group / _lookahead) take their
-// initial value from the first five entries; an API call afterwards wins.
+// The ENGINE SETTINGS with an API of their own (bh_engine_set_swd_search / _scan / _prescan / _arith / _group / _lookahead) take their
+// initial value from the first six entries; an API call afterwards wins.
 #pragma once
 
 //        field              environment variable        default  meaning (value: flag = set to anything / integer)
@@ -15,6 +15,7 @@
     X(swd_search,        "BH_SWD_SEARCH",        -1, "initial root refinement: r(eference) / f(ast) / fast_rayleigh; -1 = the library's default")    \
     X(swd_scan,          "BH_SWD_SCAN",          -1, "initial scan mode: s(teps) / c(ounted) / a(uto); -1 = auto")                                  \
     X(swd_prescan,       "BH_SWD_PRESCAN",       -1, "initial certified-sign scan: 0 / 1; -1 = off")                                                \
+    X(swd_arith,         "BH_SWD_ARITH",         -1, "initial arithmetic of short-refinement launches: e(xact) / f(ast); -1 = the library's default") \
     X(swd_group,         "BH_SWD_GROUP",          0, "lanes per model of the dispersion kernel (0 = planned per launch)")                           \
     X(swd_lookahead,     "BH_SWD_LOOKAHEAD",      0, "trial velocities per round (0 = planned per launch)")                                         \
     X(swd_look_r,        "BH_SWD_LOOK_R",         0, "trials per round of Rayleigh wavefronts only (0 = planned)")                                  \

@@ -339,6 +339,8 @@ __device__ __forceinline__ void rayleigh_ca19(Ca19 &o, double wvno2, double gam,
     o.c[18] = t * ca13;
 }
 
+#include "swd_fa.h"
+
 // normc (surfdisp96.f:995-1020): divide the 5-vector by its max-norm (floor 1e-40); the log()
 // the Fortran takes of the norm is never used.  max is order-independent, so a tree is used.
 // EXACT = false: the five divisions share one refined reciprocal and report their range.
@@ -584,7 +586,8 @@ struct SearchT {
     enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u,
                       F_SEED3 = 64u,   // Rayleigh, short refinement: the scan's last replaced point seeds the first estimate
                       F_SEEDED = 128u, // this bracket's refinement started with a third point
-                      F_PRE_ON = 256u  // the certified-sign scan is wanted (PRE builds)
+                      F_PRE_ON = 256u, // the certified-sign scan is wanted (PRE builds)
+                      F_FA = 512u      // the values come from the fast arithmetic (swd_fa.h): signs below fa::SIGN_FLOOR fire the guard
     };
     // the certified-sign scan: grid points one look covers at most (the kernel: looks x the lanes of a model)
     static constexpr int pre_max_points = 128;
@@ -679,7 +682,7 @@ struct SearchT {
     __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
                          double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
                          double *cper_ = nullptr, double *cbper_ = nullptr, int ifunc = 2, bool counted = false, bool refseq = false,
-                         bool prescan = false)
+                         bool prescan = false, bool farith = false)
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
@@ -742,6 +745,7 @@ struct SearchT {
         evals = 0;
         put(F_CNT_ON, counted && ifunc == 1);
         put(F_PRE_ON, PRE && prescan && !(counted && ifunc == 1));
+        put(F_FA, FAST && farith);
         flg &= ~(F_CNT_OK | F_JUMP_READY);
         iprev = iprevb = 0;
         vlim = fmin(md.Bv(mmax - 1), betmxd);
@@ -998,6 +1002,9 @@ struct SearchT {
         // 3 refinement finished with c3, 4 nevill top-of-loop, 5 nevill post-bracket section,
         // 6 root found, 7 next estimate of the short refinement, 10 the counted scan's index search
         int todo = 0;
+        // fast arithmetic: a scan or guard value whose sign the rounding error could decide (or a poisoned one) is not trusted --
+        // the guard fires (inside the refinement small values are what is expected: they move the root by < 1e-9 relative)
+        if (FAST && has(F_FA) && !(fabs(del) >= fa::SIGN_FLOOR) && !(st >= ST_FX && st <= ST_FP2 && del == del)) flg |= F_GUARD;
         if (PRE && st >= ST_PRE) { // landing of the certified-sign scan (ST_PRE itself never has an evaluation pending)
             if (st == ST_PJ1) {
                 cp = ceval;

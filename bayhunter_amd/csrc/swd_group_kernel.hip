@@ -74,7 +74,7 @@ constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used
 //   !PAR5  every lane runs the full 5x5 product (used for G < 5 and for the exact re-run).
 //   RAGGED the wavefront holds models with different layer counts (or a water layer): layers a
 //          model does not have are masked with selects; the uniform case has no masking at all.
-template <bool PAR5, bool RAGGED, bool EXACT>
+template <bool PAR5, bool RAGGED, bool EXACT, bool FA = false>
 __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *cam, int col,
                                                      int gbase, int mtop, int mmax, int llw,
                                                      DivRange &dr)
@@ -91,11 +91,15 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
             const double *cn = cam + (size_t)(m > 0 ? m - 1 : 0) * CA_STRIDE + 5 * col;
             double n0 = cn[0], n1 = cn[1], n2 = cn[2], n3 = cn[3], n4 = cn[4];
             double ee = 0.0;
-            ee = ee + e[0] * c0;
-            ee = ee + e[1] * c1;
-            ee = ee + e[2] * c2;
-            ee = ee + e[3] * c3;
-            ee = ee + e[4] * c4;
+            if (FA) { // (fast arithmetic: two short chains of fused multiply-adds)
+                ee = __builtin_fma(e[4], c4, __builtin_fma(e[2], c2, e[0] * c0)) + __builtin_fma(e[3], c3, e[1] * c1);
+            } else {
+                ee = ee + e[0] * c0;
+                ee = ee + e[1] * c1;
+                ee = ee + e[2] * c2;
+                ee = ee + e[3] * c3;
+                ee = ee + e[4] * c4;
+            }
             const double v0 = __shfl(ee, gbase + 0), v1 = __shfl(ee, gbase + 1), v2 = __shfl(ee, gbase + 2),
                          v3 = __shfl(ee, gbase + 3), v4 = __shfl(ee, gbase + 4);
             // keep the fetch of layer m-1 in THIS iteration (the compiler otherwise sinks it to the top of the next
@@ -103,9 +107,13 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
             // time the exchange above has arrived these have as well
             asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4));
             double en[5];
-            DivRange d2 = dr;
-            normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);
-            if (on) dr = d2;
+            if (FA) {
+                fa::normalize5(v0, v1, v2, v3, v4, en);
+            } else {
+                DivRange d2 = dr;
+                normalize5<EXACT>(v0, v1, v2, v3, v4, en, d2);
+                if (on) dr = d2;
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
             c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
@@ -118,13 +126,22 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 double acc = 0.0;
+                if (FA) {
+                    acc = __builtin_fma(e[4], cc[5 * i + 4], __builtin_fma(e[2], cc[5 * i + 2], e[0] * cc[5 * i])) +
+                          __builtin_fma(e[3], cc[5 * i + 3], e[1] * cc[5 * i + 1]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc = acc + e[j] * cc[5 * i + j];
+                    for (int j = 0; j < 5; ++j) acc = acc + e[j] * cc[5 * i + j];
+                }
                 ee[i] = acc;
             }
-            DivRange d2 = dr;
-            normalize5<EXACT>(ee[0], ee[1], ee[2], ee[3], ee[4], en, d2);
-            if (on) dr = d2;
+            if (FA) {
+                fa::normalize5(ee[0], ee[1], ee[2], ee[3], ee[4], en);
+            } else {
+                DivRange d2 = dr;
+                normalize5<EXACT>(ee[0], ee[1], ee[2], ee[3], ee[4], en, d2);
+                if (on) dr = d2;
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) e[i] = on ? en[i] : e[i];
         }
@@ -132,7 +149,7 @@ __device__ __forceinline__ void rayleigh_chain_group(double e[5], const double *
 }
 
 // Phase B of the group kernel, Love: parked per layer (cosq, y, z, xmu, rcp(xmu)).
-template <bool RAGGED, bool EXACT, bool COUNT>
+template <bool RAGGED, bool EXACT, bool COUNT, bool FA = false>
 __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const double *cam, int mtop,
                                                  int mmax, int llw, DivRange &dr, LoveCount &lc)
 {
@@ -147,7 +164,8 @@ __device__ __forceinline__ void love_chain_group(double &e1, double &e2, const d
         const double2 q0 = nx[0], q1 = nx[1], q2 = nx[2];
         double n1 = e1, n2 = e2;
         DivRange d2 = dr;
-        love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
+        if (FA) fa::love_step(n1, n2, p0.x, p0.y, p1.x);
+        else love_step<EXACT>(n1, n2, p0.x, p0.y, p1.x, p1.y, p2.x, d2);
         if (on) {
             if (COUNT) lc.layer(p2.y, e2, n2); // (p2.y: floor(q / pi) of the layer, parked by phase A)
             e1 = n1;
@@ -211,8 +229,14 @@ constexpr int ADAPT_MAX_TRIALS = 8;
 // PREK: the build with the certified-sign scan (SearchT<.., PRE>, the look-ahead at the top of the round loop).  Its out-of-line
 // evaluation takes the kernel to 256 registers, so it is a build of its own, launched only when the scan is asked for
 // (bh_engine_set_swd_prescan; the general builds of launches with several models per wavefront).
-template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB, bool PREK = false>
-__global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
+// FA: the build with the fast arithmetic (swd_fa.h; bh_engine_set_swd_arith): launches in which every target takes the short
+// refinement (FASTM = 2) -- tolerance-level parity, a guard for signs the rounding error could decide.
+// (the FA builds are compiled in a translation unit of their own, swd_group_fa.hip, which includes this file: own flags)
+#ifndef BH_GROUP_WAVES
+#define BH_GROUP_WAVES 2
+#endif
+template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB, bool PREK = false, bool FA = false>
+__global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(BH_GROUP_WAVES, BH_GROUP_WAVES))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
     if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(2
     unsigned evals_before = 0u; // (evaluations of the abandoned first search: they count, as the re-run launch's would)
 restart_with_the_reference_sequence:
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, PREK && A.prescan != 0);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, PREK && A.prescan != 0, FA);
     S.evals += evals_before;
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
@@ -363,6 +387,7 @@ restart_with_the_reference_sequence:
     // (the build with both sequences AND the counted scan has no registers to keep them in: formed anew every round there)
     constexpr bool CACHE = !(CNTB && FASTM == 1);
     double c_omega = -1.0, c_xka = 0.0, c_xkb = 0.0, c_gammk = 0.0, h_xka = 0.0, h_xkb = 0.0, h_gammk = 0.0;
+    double c_inv = 0.0; // fast arithmetic: 1 / rho (Rayleigh) resp. 1 / xmu (Love) of this lane's first layer
     const bool prof = PROF && (A.neval != nullptr);
     // (the phase clocks are a development aid; the one-model-per-wavefront build with both sequences and the counted scan has
     //  no registers for them)
@@ -514,6 +539,7 @@ restart_with_the_reference_sequence:
                     c_xkb = omega / bm;
                     const double t = bm / omega;
                     c_gammk = 2.0 * t * t;
+                    if (FA) c_inv = fa::rcp(md.R(li));
                 }
                 const double ah = md.A(mmax - 1), bh = md.Bv(mmax - 1);
                 h_xka = omega / ah;
@@ -537,24 +563,31 @@ restart_with_the_reference_sequence:
                         gammk = 2.0 * t * t;
                     }
                     const double gam = gammk * wvno2;
-                    double wvnop = wvno + xka;
-                    double wvnom = fabs(wvno - xka);
-                    const double ra = sqrt(wvnop * wvnom);
-                    wvnop = wvno + xkb;
-                    wvnom = fabs(wvno - xkb);
-                    const double rb = sqrt(wvnop * wvnom);
                     const double dpth = md.D(m);
                     const double rho1 = md.R(m);
                     LayerTerms v;
-                    layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v, LT);
                     Ca19 c;
-                    rayleigh_ca19(c, wvno2, gam, gammk, rho1, v);
+                    if (FA) {
+                        fa::layer_products(wvno, xka, xkb, dpth, v);
+                        fa::ca19(c, wvno2, gam, gammk, rho1, (m == li) ? c_inv : fa::rcp(rho1), v);
+                    } else {
+                        double wvnop = wvno + xka;
+                        double wvnom = fabs(wvno - xka);
+                        const double ra = sqrt(wvnop * wvnom);
+                        wvnop = wvno + xkb;
+                        wvnom = fabs(wvno - xkb);
+                        const double rb = sqrt(wvnop * wvnom);
+                        layer_products(ra * dpth, rb * dpth, ra, rb, wvno, xka, xkb, dpth, v, LT);
+                        rayleigh_ca19(c, wvno2, gam, gammk, rho1, v);
+                    }
                     park_ca25(cam + (size_t)m * CA_STRIDE, c);
                 }
             }
             // half-space E vector (surfdisp96.f:800-808), redundantly in every lane
             double e[5];
-            {
+            if (FA) {
+                fa::rayleigh_halfspace(e, wvno, wvno2, h_xka, h_xkb, h_gammk, md.R(mmax - 1));
+            } else {
                 const double xka = h_xka, xkb = h_xkb, gammk = h_gammk;
                 double wvnop = wvno + xka;
                 double wvnom = fabs(wvno - xka);
@@ -579,13 +612,13 @@ restart_with_the_reference_sequence:
                 DivRange dr;
                 dr.reset();
                 if (par5) {
-                    if (ragged) rayleigh_chain_group<true, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
-                    else rayleigh_chain_group<true, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    if (ragged) rayleigh_chain_group<true, true, false, FA>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<true, false, false, FA>(e, cam, col, gbase, mtop, mmax, llw, dr);
                 } else {
-                    if (ragged) rayleigh_chain_group<false, true, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
-                    else rayleigh_chain_group<false, false, false>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    if (ragged) rayleigh_chain_group<false, true, false, FA>(e, cam, col, gbase, mtop, mmax, llw, dr);
+                    else rayleigh_chain_group<false, false, false, FA>(e, cam, col, gbase, mtop, mmax, llw, dr);
                 }
-                if (!dr.ok() && S.active) { // out-of-range operand somewhere: verbatim re-run (whole groups agree)
+                if (!FA && !dr.ok() && S.active) { // out-of-range operand somewhere: verbatim re-run (whole groups agree)
                     e[0] = e0[0]; e[1] = e0[1]; e[2] = e0[2]; e[3] = e0[3]; e[4] = e0[4];
                     rayleigh_chain_group<false, true, true>(e, cam, col, gbase, mtop, mmax, llw, dr);
                 }
@@ -600,7 +633,8 @@ restart_with_the_reference_sequence:
                 const double rho1 = md.R(0);
                 const double znul = 1.0e-5;
                 LayerTerms v;
-                layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
+                if (FA) fa::layer_products(wvno, xka, wvno + 1.0, dpth, v); // (only w and cosp of the P wave are used)
+                else layer_products(ra * dpth, znul, ra, znul, wvno, xka, znul, dpth, v, LT);
                 const double w0 = -rho1 * v.w;
                 del = v.cosp * e[0] + w0 * e[1];
             }
@@ -609,7 +643,10 @@ restart_with_the_reference_sequence:
             const double omega = omg;
             if (!CACHE || omega != c_omega) {
                 c_omega = omega;
-                if (li <= mmax - 2) c_xkb = omega / md.Bv(li);
+                if (li <= mmax - 2) {
+                    c_xkb = omega / md.Bv(li);
+                    if (FA) c_inv = fa::rcp(md.R(li) * md.Bv(li) * md.Bv(li));
+                }
                 const double beta1 = md.Bv(mmax - 1);
                 h_xkb = omega / beta1;
                 h_gammk = 1.0 / (beta1 * beta1); // e2 of the half-space (surfdisp96.f:731)
@@ -624,11 +661,21 @@ restart_with_the_reference_sequence:
                         const double dm = md.D(m);
                         const double xmu = rho1 * beta1 * beta1;
                         const double xkb = (m == li) ? c_xkb : omega / beta1;
+                        double cosq, y, z, fl = 0.0;
+                        if (FA) {
+                            double q;
+                            fa::love_terms(wv, xkb, dm, cosq, y, z, q);
+                            if (CNTB) fl = (wv < xkb) ? love_zero_floor(q) : 0.0;
+                            double2 *dst = reinterpret_cast<double2 *>(cam + (size_t)m * CA_STRIDE + LOVE_TERMS * jj);
+                            dst[0] = make_double2(cosq, y * ((m == li) ? c_inv : fa::rcp(xmu))); // (the products of the recursion's
+                            dst[1] = make_double2(z * xmu, 0.0);                                  //  step are formed here, in parallel)
+                            dst[2] = make_double2(0.0, fl);
+                            continue;
+                        }
                         const double wvnop = wv + xkb;
                         const double wvnom = fabs(wv - xkb);
                         const double rb = sqrt(wvnop * wvnom);
                         const double q = dm * rb;
-                        double cosq, y, z, fl = 0.0;
                         if (wv < xkb) {
                             double sinq;
                             bh_sincos(q, &sinq, &cosq, LT);
@@ -661,7 +708,15 @@ restart_with_the_reference_sequence:
                 const double xkb = h_xkb;
                 const double wvnop = wvno + xkb;
                 const double wvnom = fabs(wvno - xkb);
-                const double rb = sqrt(wvnop * wvnom);
+                double rb;
+                if (FA) {
+                    double t_;
+                    const double r2 = wvnop * wvnom;
+                    fa::sqrt_rsqrt(r2 > 1.0e-290 ? r2 : 1.0, rb, t_);
+                    rb = r2 > 1.0e-290 ? rb : 0.0;
+                } else {
+                    rb = sqrt(wvnop * wvnom);
+                }
                 e1 = rho1 * rb;
                 e2 = h_gammk;
                 lc.reset(wvno > xkb);
@@ -674,9 +729,9 @@ restart_with_the_reference_sequence:
                 DivRange dr;
                 dr.reset();
                 const double *camt = cam + LOVE_TERMS * (li % JL); // this lane's trial
-                if (ragged) love_chain_group<true, false, CNTB>(e1, e2, camt, mtop, mmax, llw, dr, lc);
-                else love_chain_group<false, false, CNTB>(e1, e2, camt, mtop, mmax, llw, dr, lc);
-                if (!dr.ok() && S.active) {
+                if (ragged) love_chain_group<true, false, CNTB, FA>(e1, e2, camt, mtop, mmax, llw, dr, lc);
+                else love_chain_group<false, false, CNTB, FA>(e1, e2, camt, mtop, mmax, llw, dr, lc);
+                if (!FA && !dr.ok() && S.active) {
                     e1 = s1;
                     e2 = s2;
                     lc = lc0;
@@ -712,7 +767,7 @@ restart_with_the_reference_sequence:
                 if (jn > 0) live = live && S.ceval == cj && S.omega == omg;
                 const double nxt = (S.idir > 0) ? cev + S.dc : cev - S.dc;
                 // (a step that reaches a half-space velocity goes through advance(): the guard's probes)
-                const bool plain = S.active && S.st == ST_STEP && !signs_differ(S.del1, del) &&
+                const bool plain = S.active && S.st == ST_STEP && !signs_differ(S.del1, del) && (!FA || fabs(del) >= fa::SIGN_FLOOR) &&
                                    !(cev < S.cm || cev >= S.betmxd + S.dc) && nxt > S.clow && fmax(cev, S.c1) < S.vsafe;
                 const unsigned long long pm = __ballot(plain);
                 bool run = false;
@@ -789,7 +844,7 @@ restart_with_the_reference_sequence:
                     // velocity is inside the scan's bounds and the next request is the next grid point -- what advance()
                     // does then, without its way through the continuation tags
                     const double nx = (S.idir > 0) ? S.c2 + S.dc : S.c2 - S.dc;
-                    const bool plain = live && S.st == ST_STEP && !signs_differ(S.del1, dj) &&
+                    const bool plain = live && S.st == ST_STEP && !signs_differ(S.del1, dj) && (!FA || fabs(dj) >= fa::SIGN_FLOOR) &&
                                        !(S.c2 < S.cm || S.c2 >= S.betmxd + S.dc) && nx > S.clow && fmax(S.c1, S.c2) < S.vsafe;
                     if (plain) {
                         S.cp = S.c1;      // (the point the scan leaves behind, see SearchT::step_done)
@@ -872,6 +927,7 @@ restart_with_the_reference_sequence:
     }
 }
 
+#ifndef BH_GROUP_FA_TU
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / (G * J);
@@ -880,8 +936,28 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
            (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15) +
            (maxmode > 1 ? (size_t)2 * Kmax * MPW * sizeof(double) : 0);
 }
+#endif
 
 } // namespace
+
+#ifdef BH_GROUP_FA_TU
+// The launches of the builds with the fast arithmetic (this translation unit: swd_group_fa.hip).
+void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
+                            bool adapt, bool counted, bool cntb)
+{
+#define BH_FA_(PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, true, PR, AD, CN, false, true>), grid, block, lds, stream, a, redundant, wave_lds)
+#define BH_FA(PR, AD) do { if (cntb) BH_FA_(PR, AD, true); else BH_FA_(PR, AD, false); } while (0)
+    if (adapt) {
+        if (counted) BH_FA(true, true);
+        else BH_FA(false, true);
+    } else {
+        if (counted) BH_FA(true, false);
+        else BH_FA(false, false);
+    }
+#undef BH_FA
+#undef BH_FA_
+}
+#else
 
 // LDS of one workgroup = shared libm tables + GROUP_WPB wavefront regions
 size_t bh_swd_group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
@@ -1135,7 +1211,8 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     }
     // (one model per wavefront and SwdMultiArgs::restart: the build with both sequences, guarded models restart in place)
     const bool no_restart = tun.swd_no_restart != 0;
-    const bool restart = adapt && a.restart != 0 && a.fast && any_phase && !no_restart;
+    // (not with the fast arithmetic: the reference's sequence runs in the reference's arithmetic -- the re-run launch)
+    const bool restart = adapt && a.restart != 0 && a.fast && any_phase && !no_restart && !(a.farith != 0 && !any_group && !any_refseq && !any_modes);
     a.restart = restart ? 1 : 0;
     if (info != nullptr) info->restarts_in_place = restart ? 1 : 0;
     const int build = (a.fast && any_phase) ? ((any_group || any_refseq || restart) ? 1 : 2) : 0;
@@ -1169,7 +1246,13 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
     const bool prek = a.prescan != 0 && !adapt && !cntb && wpb == GROUP_WPB;
     a.prescan = prek ? 1 : 0;
-    if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel)
+    // the fast arithmetic (FA, see the kernel): every target of the launch takes the short refinement, the usual targets
+    const bool farith = a.farith != 0 && build == 2 && simple && !prek && wpb == GROUP_WPB;
+    a.farith = farith ? 1 : 0;
+    if (info != nullptr) info->fast_arith = a.farith;
+    if (farith) {
+        bh_launch_swd_group_fa(a, grid, block, lds, stream, redundant, (int)wave_lds, adapt, counted, cntb);
+    } else if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel)
         if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
         else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
         else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
@@ -1210,4 +1293,4 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
 #undef BH_GROUP_LAUNCH_
     return 0;
 }
-
+#endif // BH_GROUP_FA_TU

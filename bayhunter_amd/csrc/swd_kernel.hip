@@ -75,7 +75,8 @@ __host__ __device__ inline size_t lane_wave_bytes(int Lmax, int K, int mode)
 // from 100 000 models on, 2.5 % slower below (the launcher picks).
 // FAST: 0 the reference sequence, 2 the short refinement (a launch is one target); SIMPLE: a fundamental-mode phase-velocity
 // launch (SearchT, swd_common.h: no second root, no mode loop)
-template <int IFUNC, bool LOOK, int LANE_WPB, int FAST, bool SIMPLE>
+// FA: the fast arithmetic (swd_fa.h; launches of the short refinement only)
+template <int IFUNC, bool LOOK, int LANE_WPB, int FAST, bool SIMPLE, bool FA = false>
 __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem_all[];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
 
     SearchT<BH_WAVE, NEV_LO, FAST, SIMPLE> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
-           cpl + lane, cpl + (size_t)K * BH_WAVE + lane, IFUNC, A.counted != 0);
+           cpl + lane, cpl + (size_t)K * BH_WAVE + lane, IFUNC, A.counted != 0, false, false, FA);
     {
         const size_t nl = (size_t)gridDim.x * LANE_WPB * BH_WAVE; // lanes of the launch
         double *hx = A.nev_high + (size_t)wid * BH_WAVE + lane;
@@ -163,11 +164,14 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
         int nv = -1; // Love: the packed mode count of this evaluation (LoveCount)
         DivRange dr;
         dr.reset();
-        if (IFUNC == 1)
+        if (FA) {
+            if (IFUNC == 1) del = fa::love_secular(wvno, omg, md, mmax, llw, mtop, &nv);
+            else del = fa::rayleigh_secular(wvno, omg, md, mmax, llw, mtop);
+        } else if (IFUNC == 1)
             del = love_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT, &nv);
         else
             del = rayleigh_secular<false>(wvno, omg, md, mmax, llw, mtop, dr, LT);
-        if (!dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
+        if (!FA && !dr.ok()) { // operands left the range the fast divisions are exact in: redo verbatim
             if (IFUNC == 1)
                 del = love_secular<true>(wvno, omg, md, mmax, llw, mtop, dr, LT, &nv);
             else
@@ -515,7 +519,8 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 #define BH_LANE_PICK_FS(IF, LK, WP)                                                  \
     do {                                                                             \
         if (a.fast && a.igr == 0) {                                                  \
-            if (simple) BH_LANE_LAUNCH(IF, LK, WP, 2, true);                         \
+            if (simple && a.farith) hipLaunchKernelGGL((swd_kernel<IF, LK, WP, 2, true, true>), grid, block, lds, stream, b); \
+            else if (simple) BH_LANE_LAUNCH(IF, LK, WP, 2, true);                    \
             else BH_LANE_LAUNCH(IF, LK, WP, 2, false);                               \
         } else if (simple) BH_LANE_LAUNCH(IF, LK, WP, 0, true);                      \
         else BH_LANE_LAUNCH(IF, LK, WP, 0, false);                                   \

@@ -27,6 +27,7 @@ RF_P, RF_SV = 0, 1
 LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
 TARGET_SWD, TARGET_RF, TARGET_USER = 0, 1, 2
 SEARCH_REFERENCE, SEARCH_FAST, SEARCH_FAST_RAYLEIGH = 0, 1, 2  # bh_engine_set_swd_search
+ARITH_EXACT, ARITH_FAST = 0, 1  # bh_engine_set_swd_arith
 SCAN_STEPS, SCAN_COUNTED, SCAN_AUTO = 0, 1, 2  # bh_engine_set_swd_scan
 MAX_PERIODS, MAX_LAYERS, MAX_TARGETS = 60, 100, 8
 
@@ -109,6 +110,8 @@ def load_library():
     L.bh_engine_set_swd_lookahead.argtypes = [vp, C.c_int]
     L.bh_engine_set_swd_search.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_search.argtypes = [vp]
+    L.bh_engine_set_swd_arith.argtypes = [vp, C.c_int]
+    L.bh_engine_get_swd_arith.argtypes = [vp]
     L.bh_engine_set_swd_scan.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_scan.argtypes = [vp]
     L.bh_engine_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
@@ -139,19 +142,19 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 8:
+    if L.bh_abi_version() != 9:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -263,6 +266,29 @@ class Engine(object):
             yield self
         finally:
             self.set_swd_search(prev)
+
+    def set_swd_arith(self, arith):
+        """Arithmetic of the launches in which every target takes the short refinement (include/bh_engine.h:
+        bh_engine_set_swd_arith): "fast" (default) = fused multiply-adds, Newton-refined hardware reciprocals, polynomial
+        sin / cos / exp -- same guarantees as the "fast" search; "exact" = the reference's operations and rounding points."""
+        codes = {"exact": ARITH_EXACT, "fast": ARITH_FAST, ARITH_EXACT: ARITH_EXACT, ARITH_FAST: ARITH_FAST}
+        code = codes.get(arith)
+        if code is None:
+            raise ValueError("arith must be 'exact' or 'fast'")
+        self._check(self._L.bh_engine_set_swd_arith(self._h, code))
+
+    def swd_arith(self):
+        return "fast" if self._L.bh_engine_get_swd_arith(self._h) == ARITH_FAST else "exact"
+
+    @contextlib.contextmanager
+    def computing(self, arith):
+        """The calls inside run with this arithmetic; the engine's setting is restored afterwards."""
+        prev = self.swd_arith()
+        self.set_swd_arith(arith)
+        try:
+            yield self
+        finally:
+            self.set_swd_arith(prev)
 
     def set_swd_scan(self, scan):
         """Love bracket scans: "counted" = skip the steps a mode count proves to be without a sign change (same brackets, same

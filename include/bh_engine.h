@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 8
+#define BH_ABI_VERSION 9
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -102,6 +102,22 @@ int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
 #define BH_SEARCH_FAST_RAYLEIGH 2
 int bh_engine_set_swd_search(bh_engine *e, int search);
 int bh_engine_get_swd_search(const bh_engine *e);
+/* Arithmetic of the secular functions in launches where EVERY target takes the short refinement (BH_SEARCH_FAST with
+ * fundamental-mode phase-velocity targets only; anything else -- BH_SEARCH_REFERENCE, group velocities, higher modes, the
+ * re-run of guarded models -- always computes with BH_ARITH_EXACT).
+ *   BH_ARITH_EXACT  the reference's operations with the reference's rounding points (no fused multiply-add, correctly rounded
+ *                   division and square root, glibc's sincos / exp bit for bit): what the short refinement evaluates is the
+ *                   reference's function to the last bit.
+ *   BH_ARITH_FAST   (the default) the same formulas with fused multiply-adds, Newton-refined hardware reciprocals / square
+ *                   roots and short polynomial sin / cos / exp: values within a few units in the last place of the exact
+ *                   ones -- a root moves by ~1e-13 relative.  The GUARANTEES of BH_SEARCH_FAST hold unchanged (velocities
+ *                   within 1e-5 of the reference's, achieved 1.2e-6; failure flags and zero rows the reference's): a scan
+ *                   value small enough (|f| < 1e-9 of the vector's max-norm) for the rounding to decide its sign sends the
+ *                   model back to the reference's sequence and arithmetic, like any guarded model. */
+#define BH_ARITH_EXACT 0
+#define BH_ARITH_FAST 1
+int bh_engine_set_swd_arith(bh_engine *e, int arith);
+int bh_engine_get_swd_arith(const bh_engine *e);
 /* The bracket scan of Love targets (any root refinement).  Results never depend on this setting.
  * getsol's scan (surfdisp96.f:437-460) evaluates every step of its grid until the secular function changes sign.  For Love
  * waves the number of sign changes below a trial velocity is read off the recursion that evaluates the function (a Sturm

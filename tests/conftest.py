@@ -41,16 +41,19 @@ def engine():
 def _reference_search(request):
     """The GPU parity tests compare bits with the reference: every gpu-marked test starts with the process-wide engine on the
     REFERENCE's root refinement (the engine's own default is the short one, bh_engine.h; the tests of that mode select it
-    themselves and `test_gpu_swd_fast.py::test_default_search_is_the_short_refinement` looks at a fresh engine)."""
+    themselves and `test_gpu_swd_fast.py::test_default_search_is_the_short_refinement` looks at a fresh engine) and on the
+    reference's arithmetic (bh_engine_set_swd_arith; the default, the fast one, is selected by the tests of that mode)."""
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
     from bayhunter_amd import engine as E
     eng = E.default_engine(0)
-    before = eng.swd_search()
+    before, arith = eng.swd_search(), eng.swd_arith()
     eng.set_swd_search("reference")
+    eng.set_swd_arith("exact")       # (the bit-level tests of the short refinement: its restatement computes as the reference does)
     yield
     eng.set_swd_search(before)       # (what a test selected does not leak into the next one)
+    eng.set_swd_arith(arith)
 
 
 def rows(a, nlay):

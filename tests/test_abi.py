@@ -24,7 +24,7 @@ def test_library_built_and_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), "missing export %s" % name
     assert sorted(E.EXPORTED_SYMBOLS) == decl
-    assert lib.bh_abi_version() == 8
+    assert lib.bh_abi_version() == 9
 
 
 def test_python_constants_mirror_the_header():
@@ -32,7 +32,7 @@ def test_python_constants_mirror_the_header():
     from bayhunter_amd import engine as E
     txt = open(os.path.join(REPO, "include", "bh_engine.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"^#define\s+(BH_[A-Z0-9_]+)\s+(-?\d+)\b", txt, flags=re.M)}
-    assert defs["BH_ABI_VERSION"] == 8
+    assert defs["BH_ABI_VERSION"] == 9
     assert (defs["BH_SEARCH_REFERENCE"], defs["BH_SEARCH_FAST"], defs["BH_SEARCH_FAST_RAYLEIGH"]) == (E.SEARCH_REFERENCE, E.SEARCH_FAST, E.SEARCH_FAST_RAYLEIGH) == (0, 1, 2)
     assert (defs["BH_SCAN_STEPS"], defs["BH_SCAN_COUNTED"], defs["BH_SCAN_AUTO"]) == (E.SCAN_STEPS, E.SCAN_COUNTED, E.SCAN_AUTO) == (0, 1, 2)
     assert defs["BH_CHAIN_MAXDEPTH"] == E.BH_CHAIN_MAXDEPTH
