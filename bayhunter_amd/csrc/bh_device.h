@@ -173,6 +173,11 @@ void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t
                             bool adapt, bool counted, bool cntb);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
                         SwdPairWork *pair = nullptr);
+// swd_lean.hip: fundamental-mode phase velocities with the fast arithmetic, one lane per trial velocity (the kernel of the
+// engine's default settings for batches up to a few ten thousand models); a.t[t].look = trials per model and round
+int bh_swd_lean_trials(int B, int ntargets, int ncu);
+size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax);
+int bh_launch_swd_lean(const SwdMultiArgs &a, hipStream_t stream, SwdLaunchInfo *info);
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies
 // (binary32-valued) of thickness, vp, vs and the Love / Rayleigh density mappings
 void bh_launch_sphere(int B, int Lmax, const int32_t *nlay, const double *h, const double *vp,

@@ -457,6 +457,18 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
+    // The trial-per-lane kernel (swd_lean.hip): every target of the call takes the short refinement with the fast arithmetic
+    // and the batch leaves it at least four trials per model and round within two wavefronts per SIMD.
+    int lean_trials = 0;
+    {
+        bool all = e->swd_arith == BH_ARITH_FAST && e->swd_search == BH_SEARCH_FAST && e->force_group == 0 && e->force_look == 0 &&
+                   e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS;
+        for (int j = 0; j < njobs; ++j) all = all && (jobs[j].K == 0 || jobs[j].igr == 0);
+        if (all) lean_trials = bh_swd_lean_trials(B, nlive, e->pairwork.ncu);
+        if (lean_trials >= 4 && bh_swd_lean_lds_bytes(lean_trials, Lmax, kmax) > lds_cap) lean_trials = 0;
+    }
+    const bool lean = lean_trials >= 4;
+    if (lean && G <= 1) G = bh_swd_pick_group(B, nlive, Lmax); // (the launch is set up where the group kernel's is)
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
     // processing order: deepest models first, wavefronts of (nearly) one depth
@@ -481,7 +493,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             wmax = w > wmax ? w : wmax;
         }
     const int pair_min = bh_tuning().swd_pair_minwaves;
-    const bool use_pair = B > 1 && !e->no_order && !e->as_given && !e->no_pair && G > 1 && nlive == 2 && bh_pair_order_fits(B) &&
+    const bool use_pair = !lean && B > 1 && !e->no_order && !e->as_given && !e->no_pair && G > 1 && nlive == 2 && bh_pair_order_fits(B) &&
                           plan_waves >= (pair_min >= 0 ? pair_min : 7 * (long)e->pairwork.ncu) && (pair_min >= 0 || 2 * wmax >= 3 * wmin) &&
                           !(typ_layers > 0 && typ_layers + 2 < Lmax);
     if (B > 1 && !e->no_order && !e->as_given && !use_pair) {
@@ -656,7 +668,22 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         }
         hipStream_t sp = (p == 1 && side_by_side) ? e->aux2 : st;
         const bool pair_ok = use_pair && nparts == 1;
-        const int lrc = bh_launch_swd_group(ap, G, sp, &e->last_swd, e->swd_wpb_now, pair_ok ? &e->pairwork : nullptr);
+        int lrc;
+        if (lean) {
+            // Rayleigh evaluations cost three times Love ones: Love targets take half the trials where that brings the launch
+            // under three wavefronts per two SIMDs
+            const BhTuning &tun = bh_tuning();
+            for (int t = 0; t < ap.ntargets; ++t) {
+                int Jt = lean_trials;
+                if (ap.t[t].iwave == BH_WAVE_LOVE && Jt >= 8 && ap.ntargets > 1) Jt /= 2;
+                if (ap.t[t].iwave == BH_WAVE_RAYLEIGH && tun.swd_lean_r >= 4) Jt = tun.swd_lean_r;
+                if (ap.t[t].iwave == BH_WAVE_LOVE && tun.swd_lean_l >= 4) Jt = tun.swd_lean_l;
+                ap.t[t].look = Jt;
+            }
+            lrc = bh_launch_swd_lean(ap, sp, &e->last_swd);
+        } else {
+            lrc = bh_launch_swd_group(ap, G, sp, &e->last_swd, e->swd_wpb_now, pair_ok ? &e->pairwork : nullptr);
+        }
         e->last_swd_wpb = e->swd_wpb_now;
         if (lrc != 0) {
             ev_end(e, 0, st);

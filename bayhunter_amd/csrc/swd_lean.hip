@@ -1,0 +1,541 @@
+// bayhunter_amd/csrc/swd_lean.hip -- fundamental-mode phase velocities with the FAST ARITHMETIC, one lane = one TRIAL.
+//
+// The kernel of the engine's default settings (BH_SEARCH_FAST + BH_ARITH_FAST) for batches of up to a few ten thousand
+// models: replaces surfdisp96's driver, getsol and nevill (surfdisp96.f:172-357, :390-482, :557-686) for targets that are
+// fundamental-mode phase velocities.  Everything else (reference sequence, group velocities, higher modes, the re-run of
+// guarded models) stays with swd_group_kernel / swd_kernel.
+//
+//   * J = 4 ... 64 neighbouring lanes are one model; a lane evaluates the secular function (swd_fa.h) at ONE trial velocity,
+//     all layers serial in the lane -- no layer-parallel phases, no exchange inside an evaluation, every lane busy.  One
+//     such evaluation costs a wavefront 14 k cycles (Rayleigh, 10 layers; tools/ubench/faeval.hip), whatever the number of
+//     trials it carries, so a round of 16 trials costs what one costs.
+//   * THE SCAN IS THE REFERENCE'S (getsol, :437-460): the same start value c(k-1) - 1.5 dc, the same grid (repeated additions of
+//     dc), the same direction rule, floor (clow), bounds (cm, betmx + dc) and first sign change -- but a round evaluates the
+//     next J grid points at once and the first event among them (sign change, bound, floor) is found with one ballot.
+//   * Inside the bracket the root is located by J-section (one round: the step of 0.005 km/s shrinks to dc / (J + 1)), then
+//     by a round of trials clustered geometrically (1e-7 |x| * 4^i) around the inverse-quadratic estimate; the root returned
+//     is the secant point of the final bracket (<= 1.3e-6 |c| wide, typically 2e-7).  The reference (nevill) stops at a
+//     bracket of 1e-6 c1 and returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
+//   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
+//     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
+//     contains betmx -- plus the rule of the fast arithmetic: a scan or probe value below fa::SIGN_FLOOR is not trusted.  A
+//     guarded model is listed and run again by the engine with the reference's sequence in the reference's arithmetic
+//     (launch_swd_rerun), so failure flags and zero rows are the reference's.
+//   * A model with a water layer (unreachable from BayHunter) is guarded at once.
+#include "../../include/bh_engine.h"
+#include "bh_device.h"
+#include "bh_tuning.h"
+#include <algorithm>
+#define BH_HD __device__ __forceinline__
+#define BH_TAB static __device__ const
+#include "bh_libm.h"
+
+namespace {
+#include "swd_common.h"
+
+// The model in LDS as binary64 (binary32-valued, like the f2py boundary) with the per-layer reciprocals: [7][rows][S]
+struct LeanModel {
+    const double *p; // column pre-offset
+    int S, LS;       // models per wavefront, rows * S
+    __device__ __forceinline__ double D(int m) const { return p[m * S]; }
+    __device__ __forceinline__ double A(int m) const { return p[LS + m * S]; }
+    __device__ __forceinline__ double Bv(int m) const { return p[2 * LS + m * S]; }
+    __device__ __forceinline__ double R(int m) const { return p[3 * LS + m * S]; }
+    __device__ __forceinline__ double IA(int m) const { return p[4 * LS + m * S]; }
+    __device__ __forceinline__ double IB(int m) const { return p[5 * LS + m * S]; }
+    __device__ __forceinline__ double IR(int m) const { return p[6 * LS + m * S]; }
+};
+
+// dltar4 (surfdisp96.f:773-871) with the fast arithmetic, no water layer; iom = 1 / omega
+__device__ __forceinline__ double lean_rayleigh(double wvno, double omega, double iom, const LeanModel &md, int mmax, int mtop)
+{
+    const double wvno2 = wvno * wvno;
+    double e[5];
+    {
+        const double t = md.Bv(mmax - 1) * iom;
+        fa::rayleigh_halfspace(e, wvno, wvno2, omega * md.IA(mmax - 1), omega * md.IB(mmax - 1), 2.0 * t * t, md.R(mmax - 1));
+    }
+    for (int m = mtop - 2; m >= 0; --m) {
+        if (m <= mmax - 2) {
+            const double t = md.Bv(m) * iom;
+            const double gammk = 2.0 * t * t;
+            LayerTerms v;
+            fa::layer_products(wvno, omega * md.IA(m), omega * md.IB(m), md.D(m), v);
+            Ca19 c;
+            fa::ca19(c, wvno2, gammk * wvno2, gammk, md.R(m), md.IR(m), v);
+            double ee[5];
+            fa::apply5(e, c.c, ee);
+            fa::normalize5(ee[0], ee[1], ee[2], ee[3], ee[4], e);
+        }
+    }
+    return e[0];
+}
+// dltar1 (surfdisp96.f:710-769)
+__device__ __forceinline__ double lean_love(double wvno, double omega, const LeanModel &md, int mmax, int mtop)
+{
+    double e1, e2;
+    {
+        const double ib = md.IB(mmax - 1);
+        const double xkb = omega * ib;
+        const double r2 = (wvno + xkb) * fabs(wvno - xkb);
+        double rb, t_;
+        fa::sqrt_rsqrt(r2 > 1.0e-290 ? r2 : 1.0, rb, t_);
+        rb = r2 > 1.0e-290 ? rb : 0.0;
+        e1 = md.R(mmax - 1) * rb;
+        e2 = ib * ib;
+    }
+    for (int m = mtop - 2; m >= 0; --m) {
+        if (m <= mmax - 2) {
+            const double ib = md.IB(m), bm = md.Bv(m), rho1 = md.R(m);
+            double cosq, y, z, q;
+            fa::love_terms(wvno, omega * ib, md.D(m), cosq, y, z, q);
+            fa::love_step(e1, e2, cosq, y * (ib * ib * md.IR(m)), z * (rho1 * bm * bm));
+        }
+    }
+    return e1;
+}
+
+enum : int {
+    PH_START = 0,      // a period's first round: the start value (trial 0) and the first J - 1 upward steps
+    PH_SCAN = 1,       // J further steps of the scan
+    PH_REF1 = 2,       // J-section of the bracket
+    PH_REFC = 3,       // trials clustered around the estimate
+    PH_PROBE_STEP = 4, // the guard's probes of a scan step over a half-space velocity (ST_GS1 / ST_GS2 of SearchT)
+    PH_PROBE_ACC = 5   // the guard's probes outside an accepted bracket (ST_GH / ST_GL)
+};
+
+__device__ __forceinline__ bool sign_neg(double x) { return __double_as_longlong(x) < 0; }
+
+__global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
+{
+    // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
+    if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
+    const SwdTarget T = A.t[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int J = T.look;          // trials per model and round: a power of two, 4 ... 64
+    const int MPW = BH_WAVE / J;   // models per wavefront
+    if ((int)blockIdx.x * MPW >= A.B) return;
+    const int g = lane / J, r = lane - g * J, lbase = g * J;
+    const int sidx = (int)blockIdx.x * MPW + g;
+    const bool valid = sidx < A.B;
+    const int32_t *perm = T.perm != nullptr ? T.perm : A.perm;
+    const int ib = valid ? (perm ? perm[sidx] : sidx) : 0;
+    const int Lmax = A.Lmax, K = T.K, ifunc = T.iwave;
+    extern __shared__ __align__(16) double smem_lean[];
+    double *per = smem_lean;              // [K]
+    double *mdl = per + ((K + 1) & ~1);   // [7][Lmax][MPW]
+    const int LS = Lmax * MPW;
+    for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
+    for (int idx = lane; idx < LS; idx += BH_WAVE) {
+        const int l = idx / MPW, mg = idx - l * MPW;
+        const int sb = (int)blockIdx.x * MPW + mg;
+        const int b = sb < A.B ? (perm ? perm[sb] : sb) : 0;
+        float fd = 0.f, fa_ = 1.f, fb = 1.f, fr = 1.f;
+        if (sb < A.B && l < A.nlay[b]) {
+            const ptrdiff_t o = (ptrdiff_t)b * T.sb + (ptrdiff_t)l * T.sl;
+            fd = (float)T.h[o];
+            fa_ = (float)T.vp[o];
+            fb = (float)T.vs[o];
+            fr = (float)T.rho[o];
+        }
+        mdl[idx] = (double)fd;
+        mdl[LS + idx] = (double)fa_;
+        mdl[2 * LS + idx] = (double)fb;
+        mdl[3 * LS + idx] = (double)fr;
+        mdl[4 * LS + idx] = fa::rcp((double)fa_);
+        mdl[5 * LS + idx] = fa::rcp((double)fb);
+        mdl[6 * LS + idx] = fa::rcp((double)fr);
+    }
+    int mmax = valid ? A.nlay[ib] : 2;
+    mmax = mmax < 1 ? 1 : (mmax > Lmax ? Lmax : mmax);
+    int mtop = mmax;
+    for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
+    mtop = __builtin_amdgcn_readfirstlane(mtop);
+    __syncthreads();
+    LeanModel md;
+    md.p = mdl + g;
+    md.S = MPW;
+    md.LS = LS;
+
+    // ---- driver set-up (surfdisp96.f:124-217; SearchT::init): extremal velocities, start value, input sanity
+    constexpr double dc = (double)0.005f, onea = (double)1.5f, twopi = 2.0 * 3.141592653589793, guard_rel = 3.0e-6;
+    float betmx = -1.e20f, betmn = 1.e20f;
+    int jmn = 0, jsol = 1;
+    bool sane = true;
+    for (int i = 0; i < mmax; ++i) {
+        const float bi = (float)md.Bv(i), ai = (float)md.A(i), di = (float)md.D(i), ri = (float)md.R(i);
+        sane = sane && (ai > 0.0f) && (ai <= 100.0f) && (bi >= 0.0f) && (bi <= 100.0f) && (ri > 0.0f) && (ri < 1.0e6f) &&
+               (i == mmax - 1 || (di >= 0.0f && di < 1.0e7f));
+        if (bi > 0.01f && bi < betmn) {
+            betmn = bi;
+            jmn = i;
+            jsol = 1;
+        } else if (bi <= 0.01f && ai < betmn) {
+            betmn = ai;
+            jmn = i;
+            jsol = 0;
+        }
+        if (bi > betmx) betmx = bi;
+    }
+    float cc1 = (jsol == 0) ? betmn : gtsolh_f32((float)md.A(jmn), (float)md.Bv(jmn));
+    cc1 = 0.95f * cc1;
+    cc1 = 0.90f * cc1;
+    const double cm = (double)cc1, betmxd = (double)betmx;
+    const double vh0 = md.Bv(mmax - 1), vh1 = (ifunc == 2) ? md.A(mmax - 1) : betmxd, vsafe = fmin(vh0, vh1);
+    double *vel = T.vel + (size_t)ib * T.ldv;
+    const bool writer = valid && r == 0;
+    bool active = valid && K > 0 && sane, guard = false;
+    int errflag = 0;
+    if (valid && !sane) {
+        errflag = 1;
+        if (writer)
+            for (int i = 0; i < K; ++i) vel[i] = 0.0;
+    }
+    if (active && md.Bv(0) <= 0.0) { // water layer on top: the reference's sequence
+        guard = true;
+        active = false;
+    }
+    // ---- search state, the same in every lane of the model
+    int k = 0, ph = PH_START, idir = +1, ifirst = 1, nref = 0;
+    double c1 = cm, clow = cm, del1 = 0.0, ck = 0.0, omega = 1.0, iom = 1.0;
+    bool s1stneg = false;
+    double lo = 0.0, hi = 0.0, flo = 0.0, fhi = 0.0, p3 = 0.0, fp3 = 0.0, c3 = 0.0;
+    bool have3 = false;
+    double cell_lo = 0.0, cell_hi = 0.0, pb = 0.0, delb = 0.0;
+    bool flo_neg = false;
+    unsigned evals = 0;
+    if (active) {
+        omega = twopi / per[0];
+        iom = fa::rcp(omega);
+    }
+    const unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
+    unsigned nrounds = 0;
+    long long t_eval = 0;
+    const long long t_start = (A.neval != nullptr) ? clock64() : 0;
+    while (__ballot(active) != 0ull) {
+        ++nrounds;
+        // ---- this lane's trial velocity
+        double cev = c1, cprev = c1; // cprev: the grid point before a scan trial
+        bool pt = false;             // this lane's value takes part in the round's decision
+        if (ph == PH_START || ph == PH_SCAN) {
+            if (ph == PH_SCAN) { // (label 1000 of getsol: the floor in a reversed search)
+                if (idir > 0) {
+                    if (c1 + dc <= clow) c1 = clow;
+                } else if (c1 - dc <= clow) {
+                    idir = +1;
+                    c1 = clow;
+                }
+            }
+            const bool start = ph == PH_START;
+            double q = (start && c1 + dc <= clow) ? clow : c1;
+            const int n = start ? r : r + 1; // steps from there
+            const double step = (idir > 0 || start) ? dc : -dc;
+            cprev = q;
+            for (int i = 0; i < n; ++i) {
+                cprev = q;
+                q = q + step;
+            }
+            cev = (start && r == 0) ? c1 : q;
+            pt = true;
+        } else if (ph == PH_REF1) {
+            cev = lo + (hi - lo) * ((double)(r + 1) / (double)(J + 1));
+            pt = cev > lo && cev < hi;
+        } else if (ph == PH_REFC) {
+            double x = 0.0;
+            bool ok = false;
+            if (have3) {
+                const double d12 = flo - fhi, d1p = flo - fp3, d2p = fhi - fp3;
+                if (d12 != 0.0 && d1p != 0.0 && d2p != 0.0) {
+                    x = lo * fhi * fp3 / (d12 * d1p) - hi * flo * fp3 / (d12 * d2p) + p3 * flo * fhi / (d1p * d2p);
+                    ok = x > lo && x < hi;
+                }
+            }
+            if (!ok) {
+                x = lo - flo * (hi - lo) / (fhi - flo);
+                if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
+            }
+            const int h = J / 2;
+            const double w = 1.0e-7 * fabs(x);
+            cev = (r < h) ? x - __builtin_ldexp(w, 2 * (h - 1 - r)) : x + __builtin_ldexp(w, 2 * (r - h));
+            pt = cev > lo && cev < hi;
+        } else if (ph == PH_PROBE_STEP) {
+            const double l_ = fmin(c1, pb), h_ = fmax(c1, pb);
+            cev = (r == 0) ? l_ + guard_rel * h_ : h_ - guard_rel * h_;
+        } else {
+            cev = (r == 0) ? cell_hi + guard_rel * fabs(c3) : cell_lo - guard_rel * fabs(c3);
+        }
+        if (!active || !(cev > 0.0)) cev = 1.0; // (finished or broken models compute on a harmless value)
+        const long long te0 = (A.neval != nullptr) ? clock64() : 0;
+        const double wvno = omega * fa::rcp(cev);
+        const double del = (ifunc == 2) ? lean_rayleigh(wvno, omega, iom, md, mmax, mtop) : lean_love(wvno, omega, md, mmax, mtop);
+        if (A.neval != nullptr) t_eval += clock64() - te0;
+
+        // ---- the round's decision: one event code per lane, ballots, the values at the event
+        const bool dneg = sign_neg(del);
+        const bool small = !(fabs(del) >= fa::SIGN_FLOOR);
+        const double d_0 = __shfl(del, lbase), d_1 = __shfl(del, lbase + 1); // (every exchange outside the per-model branches)
+        int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
+        if (ph == PH_START || ph == PH_SCAN) {
+            const bool start = ph == PH_START;
+            if (!(start && r == 0)) {
+                // (a start round's steps are upward ones; they are only consumed if the start value says so)
+                const bool down = !start && idir < 0;
+                const double a_ = fmin(cprev, cev), b_ = fmax(cprev, cev);
+                const bool refneg = start ? sign_neg(d_0) : sign_neg(del1);
+                if (down && cev <= clow) ev = 1;
+                else if (dneg != refneg) ev = 2;
+                else if (b_ >= vsafe && ((a_ <= vh0 && vh0 <= b_) || (a_ <= vh1 && vh1 <= b_))) ev = 3;
+                else if (cev < cm || cev >= betmxd + dc) ev = 4;
+            }
+        } else if (ph == PH_REF1 || ph == PH_REFC) {
+            ev = (pt && dneg != sign_neg(flo)) ? 2 : 0;
+        }
+        const unsigned long long m_ev = (__ballot(ev != 0) >> lbase) & maskJ;
+        const unsigned long long m_small = (__ballot(small) >> lbase) & maskJ;
+        const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
+        const int e = m_ev ? (int)__builtin_ctzll(m_ev) : J; // first event among the model's trials
+        const int ie = lbase + (e < J ? e : J - 1);
+        const int ev_e = __shfl(ev, ie);
+        const double c_e = __shfl(cev, ie), d_e = __shfl(del, ie);
+        const double c_em = __shfl(cev, lbase + (e > 0 ? e - 1 : 0)), d_em = __shfl(del, lbase + (e > 0 ? e - 1 : 0));
+        const double c_last = __shfl(cev, lbase + J - 1), d_last = __shfl(del, lbase + J - 1);
+        // refinement rounds: the trials that take part form one run of lanes [r0, r1]
+        const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1;
+        const int i3 = (e < J) ? ((e + 1 <= r1) ? e + 1 : e - 2) : r1 - 1; // a third point next to the new bracket
+        const double c_3 = __shfl(cev, lbase + (i3 >= 0 && i3 < J ? i3 : 0)), d_3 = __shfl(del, lbase + (i3 >= 0 && i3 < J ? i3 : 0));
+        const double c_r1 = __shfl(cev, lbase + (r1 >= 0 ? r1 : 0)), d_r1 = __shfl(del, lbase + (r1 >= 0 ? r1 : 0));
+        if (!active) continue;
+
+        int todo = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed; 3 root c3 accepted; 4 period done with c3
+        if (ph == PH_START || ph == PH_SCAN) {
+            const bool start = ph == PH_START;
+            int off = 0;
+            bool consume = true;
+            if (start) {
+                ++evals;
+                if (m_small & 1ull) guard = true;
+                del1 = d_0;
+                if (ifirst == 1) s1stneg = sign_neg(d_0);
+                idir = (ifirst != 1 && s1stneg != sign_neg(d_0)) ? -1 : +1;
+                off = 1;
+                if (idir > 0) {
+                    if (c1 + dc <= clow) c1 = clow;
+                } else {
+                    consume = false; // reversed search: the upward steps are not the scan's
+                }
+                ph = PH_SCAN;
+            }
+            if (consume) {
+                // trials off .. e are consumed (a floor event: off .. e - 1)
+                const int last = (e < J) ? ((ev_e == 1) ? e - 1 : e) : J - 1;
+                if (last >= off) {
+                    evals += (unsigned)(last - off + 1);
+                    const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
+                    if (m_small & used) guard = true;
+                }
+                // (c1, del1) after the steps before the event
+                if (e < J) {
+                    if (e > off) {
+                        c1 = c_em;
+                        del1 = d_em;
+                    }
+                    if (ev_e == 1) {
+                        idir = +1;
+                        c1 = clow;
+                    } else if (ev_e == 2) {
+                        pb = c_e;
+                        delb = d_e;
+                        todo = 1;
+                    } else if (ev_e == 3) {
+                        pb = c_e;
+                        delb = d_e;
+                        ph = PH_PROBE_STEP;
+                    } else {
+                        todo = 2;
+                    }
+                } else if (J - 1 >= off) {
+                    c1 = c_last;
+                    del1 = d_last;
+                }
+            }
+        } else if (ph == PH_PROBE_STEP) {
+            evals += 2;
+            if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
+                guard = true;
+            } else { // the step is an ordinary one
+                c1 = pb;
+                del1 = delb;
+                ph = PH_SCAN;
+                if (c1 < cm || c1 >= betmxd + dc) todo = 2;
+            }
+        } else if (ph == PH_REF1 || ph == PH_REFC) {
+            evals += (unsigned)__builtin_popcountll(m_pt);
+            ++nref;
+            const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
+            if (m_pt != 0ull) {
+                if (e < J) { // first trial beyond the sign change
+                    hi = c_e;
+                    fhi = d_e;
+                    if (e - 1 >= r0) {
+                        lo = c_em;
+                        flo = d_em;
+                    }
+                } else { // all trials on the lower end's side
+                    lo = c_r1;
+                    flo = d_r1;
+                }
+                if (i3 >= r0 && i3 <= r1) {
+                    p3 = c_3;
+                    fp3 = d_3;
+                    have3 = true;
+                } else if (hi != ohi) {
+                    p3 = ohi;
+                    fp3 = ofhi;
+                    have3 = true;
+                } else if (lo != olo) {
+                    p3 = olo;
+                    fp3 = oflo;
+                    have3 = true;
+                }
+            }
+            ph = PH_REFC;
+            if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 12 || m_pt == 0ull) {
+                c3 = lo - flo * (hi - lo) / (fhi - flo);
+                if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
+                todo = 3;
+            }
+        } else { // PH_PROBE_ACC
+            evals += 2;
+            if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true;
+            todo = 4;
+        }
+        if (todo == 1) { // a bracket: set up its refinement (SearchT::bracketed)
+            cell_lo = fmin(c1, pb);
+            cell_hi = fmax(c1, pb);
+            flo = (c1 < pb) ? del1 : delb;
+            fhi = (c1 < pb) ? delb : del1;
+            flo_neg = sign_neg(flo);
+            if (cell_hi > betmxd && cell_lo < betmxd) guard = true; // (up to three sign changes in there: the reference's sequence)
+            lo = cell_lo;
+            hi = cell_hi;
+            have3 = false;
+            nref = 0;
+            ph = PH_REF1;
+        }
+        if (todo == 3) { // the guard at an accepted bracket
+            const double m2 = 2.0 * dc;
+            todo = 4;
+            if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
+                const double eps = guard_rel * fabs(c3);
+                if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
+                    guard = true;
+                } else {
+                    ph = PH_PROBE_ACC;
+                    todo = 0;
+                }
+            }
+        }
+        if (guard) { // this run's results are not used (the engine runs the model again)
+            active = false;
+            continue;
+        }
+        if (todo == 4) { // getsol after the refinement (:468-471), then the driver's next period (:253-272)
+            if (c3 > betmxd) {
+                todo = 2;
+            } else {
+                ck = c3;
+                if (writer) vel[k] = (double)(float)ck;
+                k = k + 1;
+                if (k >= K) {
+                    active = false;
+                } else {
+                    omega = twopi / per[k];
+                    iom = fa::rcp(omega);
+                    ifirst = 0;
+                    c1 = ck - onea * dc;
+                    clow = cm;
+                    ph = PH_START;
+                }
+            }
+        }
+        if (todo == 2) { // no root at period k: err, zeros from there on (:313-354)
+            errflag = 1;
+            if (writer)
+                for (int i = k; i < K; ++i) vel[i] = 0.0;
+            active = false;
+        }
+    }
+    if (writer) {
+        T.err[ib] = errflag;
+        if (guard && T.gcount != nullptr) { // to be run again with the reference's sequence
+            T.glist[atomicAdd(T.gcount, 1)] = ib;
+            atomicAdd(T.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
+        }
+    }
+    if (A.neval != nullptr) {
+        unsigned long long tot = writer ? evals : 0u, lps = tot * (unsigned long long)(valid ? mmax - 1 : 0);
+        for (int off = 32; off > 0; off >>= 1) {
+            tot += __shfl_xor(tot, off);
+            lps += __shfl_xor(lps, off);
+        }
+        if (lane == 0) {
+            atomicAdd(A.neval, tot);
+            atomicAdd(A.neval + (ifunc == 2 ? 8 : 9), tot);
+            atomicAdd(A.neval + (ifunc == 2 ? 10 : 11), lps);
+            // development aid: rounds and cycles of the wavefronts, [1..3] Rayleigh (sum of rounds, sum of cycles, most rounds), [4..6] Love
+            const int o = (ifunc == 2) ? 1 : 4;
+            atomicAdd(A.neval + o, (unsigned long long)nrounds);
+            atomicAdd(A.neval + o + 1, (unsigned long long)(clock64() - t_start));
+            atomicMax(A.neval + o + 2, (unsigned long long)nrounds);
+            atomicAdd(A.neval + 7, 1ull);
+            atomicAdd(A.neval + (ifunc == 2 ? 12 : 13), (unsigned long long)t_eval); // cycles inside the secular evaluations
+        }
+    }
+}
+} // namespace
+
+size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax)
+{
+    return ((size_t)((Kmax + 1) & ~1) + (size_t)7 * Lmax * (BH_WAVE / J)) * sizeof(double);
+}
+
+// Trials per model and round for a launch of `nt` targets over B models: as many as keep the launch within two wavefronts
+// per SIMD (power of two, 16 at most; 0: the batch is too large for this kernel -- fewer than 4 trials).
+int bh_swd_lean_trials(int B, int nt, int ncu)
+{
+    const long slots = 2L * 4L * (ncu > 0 ? ncu : 256);
+    for (int J = 16; J >= 4; J /= 2) {
+        const long waves = (long)nt * (((long)B * J + BH_WAVE - 1) / BH_WAVE);
+        if (waves <= slots) return J;
+    }
+    return 0;
+}
+
+// All targets of `a` (fundamental-mode phase velocities, a.t[t].look = trials per round, gcount / glist set) in one launch.
+int bh_launch_swd_lean(const SwdMultiArgs &a, hipStream_t stream, SwdLaunchInfo *info)
+{
+    int kmax = 0, jmin = BH_WAVE;
+    long wmax = 1, wsum = 0;
+    for (int t = 0; t < a.ntargets; ++t) {
+        const int J = a.t[t].look;
+        if (J < 4 || J > BH_WAVE || (J & (J - 1)) != 0 || a.t[t].igr != 0 || a.t[t].mode > 1) return -1;
+        kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
+        jmin = J < jmin ? J : jmin;
+        const int mpw = BH_WAVE / J;
+        const long w = (a.B + mpw - 1) / mpw;
+        wmax = w > wmax ? w : wmax;
+        wsum += w;
+    }
+    const size_t lds = bh_swd_lean_lds_bytes(jmin, a.Lmax, kmax);
+    if (lds > 64 * 1024) return -1;
+    const dim3 grid((unsigned)wmax, (unsigned)a.ntargets), block(BH_WAVE);
+    if (info != nullptr) {
+        info->workgroups = grid.x * grid.y;
+        info->waves = wsum;
+        info->lds = lds;
+        info->fast_arith = 1;
+        info->restarts_in_place = 0;
+    }
+    hipLaunchKernelGGL(swd_lean_kernel, grid, block, lds, stream, a);
+    return 0;
+}
