@@ -175,7 +175,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLau
                         SwdPairWork *pair = nullptr);
 // swd_lean.hip: fundamental-mode phase velocities with the fast arithmetic, one lane per trial velocity (the kernel of the
 // engine's default settings for batches up to a few ten thousand models); a.t[t].look = trials per model and round
-int bh_swd_lean_trials(int B, int ntargets, int ncu);
+int bh_swd_lean_trials(int B, int ntargets);
 size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax);
 int bh_launch_swd_lean(const SwdMultiArgs &a, hipStream_t stream, SwdLaunchInfo *info);
 // earth-flattening of a batch (surfdisp96.f:486-553): writes layer-major [Lmax][B] float64 copies

@@ -117,6 +117,7 @@ struct bh_engine {
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
     SwdPairWork pairwork{};                // SIMD-pairing order of the group kernel (bh_device.h)
     bool no_pair = false;                  // BH_SWD_NO_PAIR env: order by depth only (A/B testing)
+    int last_swd_kernel = -1;              // bh_engine_last_swd_kernel
     SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
     int last_swd_wpb = 2;                  // its wavefronts per workgroup
     int err_t_nt = -1, err_t_B = -1;       // layout for which err_t's untouched rows are known to be zero
@@ -462,10 +463,10 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     int lean_trials = 0;
     {
         bool all = e->swd_arith == BH_ARITH_FAST && e->swd_search == BH_SEARCH_FAST && e->force_group == 0 && e->force_look == 0 &&
-                   e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS;
+                   e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS && Lmax <= 32;
         for (int j = 0; j < njobs; ++j) all = all && (jobs[j].K == 0 || jobs[j].igr == 0);
-        if (all) lean_trials = bh_swd_lean_trials(B, nlive, e->pairwork.ncu);
-        if (lean_trials >= 4 && bh_swd_lean_lds_bytes(lean_trials, Lmax, kmax) > lds_cap) lean_trials = 0;
+        if (all) lean_trials = bh_swd_lean_trials(B, nlive);
+        if (lean_trials >= 4 && bh_swd_lean_lds_bytes(lean_trials, Lmax, kmax) > lds_cap) lean_trials = 0; // (a workgroup's LDS)
     }
     const bool lean = lean_trials >= 4;
     if (lean && G <= 1) G = bh_swd_pick_group(B, nlive, Lmax); // (the launch is set up where the group kernel's is)
@@ -535,6 +536,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             }
             ra.board = (unsigned *)e->board.p;
         }
+        e->last_swd_kernel = BH_KERNEL_LANE;
         ev_begin(e, 0, st);
         if (fork2) {
             HIPCHK(e, hipEventRecord(e->ev_fork2, st));
@@ -670,18 +672,17 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         const bool pair_ok = use_pair && nparts == 1;
         int lrc;
         if (lean) {
-            // Rayleigh evaluations cost three times Love ones: Love targets take half the trials where that brings the launch
-            // under three wavefronts per two SIMDs
             const BhTuning &tun = bh_tuning();
             for (int t = 0; t < ap.ntargets; ++t) {
                 int Jt = lean_trials;
-                if (ap.t[t].iwave == BH_WAVE_LOVE && Jt >= 8 && ap.ntargets > 1) Jt /= 2;
                 if (ap.t[t].iwave == BH_WAVE_RAYLEIGH && tun.swd_lean_r >= 4) Jt = tun.swd_lean_r;
                 if (ap.t[t].iwave == BH_WAVE_LOVE && tun.swd_lean_l >= 4) Jt = tun.swd_lean_l;
                 ap.t[t].look = Jt;
             }
             lrc = bh_launch_swd_lean(ap, sp, &e->last_swd);
+            e->last_swd_kernel = BH_KERNEL_LEAN;
         } else {
+            e->last_swd_kernel = BH_KERNEL_GROUP;
             lrc = bh_launch_swd_group(ap, G, sp, &e->last_swd, e->swd_wpb_now, pair_ok ? &e->pairwork : nullptr);
         }
         e->last_swd_wpb = e->swd_wpb_now;
@@ -913,6 +914,7 @@ int bh_engine_set_swd_arith(bh_engine *e, int arith)
     return BH_OK;
 }
 int bh_engine_get_swd_arith(const bh_engine *e) { return e ? e->swd_arith : 0; }
+int bh_engine_last_swd_kernel(const bh_engine *e) { return e ? e->last_swd_kernel : -1; }
 int bh_engine_set_swd_prescan(bh_engine *e, int on)
 {
     if (!e) return BH_EINVAL;

@@ -14,7 +14,7 @@
 //     next J grid points at once and the first event among them (sign change, bound, floor) is found with one ballot.
 //   * Inside the bracket the root is located by J-section (one round: the step of 0.005 km/s shrinks to dc / (J + 1)), then
 //     by a round of trials clustered geometrically (1e-7 |x| * 4^i) around the inverse-quadratic estimate; the root returned
-//     is the secant point of the final bracket (<= 1.3e-6 |c| wide, typically 2e-7).  The reference (nevill) stops at a
+//     is the inverse-quadratic point of the final bracket (<= 1.3e-6 |c| wide, typically 2e-7) and its nearest neighbour.  The reference (nevill) stops at a
 //     bracket of 1e-6 c1 and returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
 //   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
 //     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
@@ -65,7 +65,14 @@ __device__ __forceinline__ double lean_rayleigh(double wvno, double omega, doubl
             fa::ca19(c, wvno2, gammk * wvno2, gammk, md.R(m), md.IR(m), v);
             double ee[5];
             fa::apply5(e, c.c, ee);
-            fa::normalize5(ee[0], ee[1], ee[2], ee[3], ee[4], e);
+            // normc (:995-1020) after every second layer and after the last: a positive scale factor of the vector cancels in
+            // the final max-norm scaling, and two layers cannot leave the binary64 range (inputs are bounded: SearchT::init)
+            if ((m & 1) == 0) {
+                fa::normalize5(ee[0], ee[1], ee[2], ee[3], ee[4], e);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) e[i] = ee[i];
+            }
         }
     }
     return e[0];
@@ -105,30 +112,51 @@ enum : int {
 };
 
 __device__ __forceinline__ bool sign_neg(double x) { return __double_as_longlong(x) < 0; }
+// LDS ordering inside ONE wavefront: its LDS instructions execute in order; only the compiler must not reorder
+__device__ __forceinline__ void lean_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-__global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
+constexpr int LEAN_WPB = 4; // wavefronts per workgroup: independent (no barrier), one per SIMD of the CU the workgroup lands on
+
+__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
     if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
-    const SwdTarget T = A.t[blockIdx.y];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (BH_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / BH_WAVE));
+    // Wavefront -> (target, index).  Two targets are interleaved wavefront by wavefront in proportion to their wavefront
+    // counts (wg_n0 / wg_n1), so that every CU -- a workgroup's four wavefronts sit on its four SIMDs -- gets its share of both.
+    int wid = (int)blockIdx.x * LEAN_WPB + wave, ty = (int)blockIdx.y;
+    if (A.wg_n1 > 0) {
+        const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
+        if (wid >= (int)N) return;
+        const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
+        ty = (l1 > l0) ? 1 : 0;
+        wid = (l1 > l0) ? l0 : wid - l0;
+    }
+    const SwdTarget T = A.t[ty];
     const int J = T.look;          // trials per model and round: a power of two, 4 ... 64
     const int MPW = BH_WAVE / J;   // models per wavefront
-    if ((int)blockIdx.x * MPW >= A.B) return;
+    if (wid * MPW >= A.B) return;
     const int g = lane / J, r = lane - g * J, lbase = g * J;
-    const int sidx = (int)blockIdx.x * MPW + g;
+    const int sidx = wid * MPW + g;
     const bool valid = sidx < A.B;
     const int32_t *perm = T.perm != nullptr ? T.perm : A.perm;
     const int ib = valid ? (perm ? perm[sidx] : sidx) : 0;
     const int Lmax = A.Lmax, K = T.K, ifunc = T.iwave;
-    extern __shared__ __align__(16) double smem_lean[];
-    double *per = smem_lean;              // [K]
-    double *mdl = per + ((K + 1) & ~1);   // [7][Lmax][MPW]
+    extern __shared__ __align__(16) unsigned char smem_lean[];
+    double *omg = reinterpret_cast<double *>(smem_lean + (size_t)wave * wave_lds); // [K]: 2 pi / period
+    double *mdl = omg + ((K + 1) & ~1);                                            // [7][Lmax][MPW]
     const int LS = Lmax * MPW;
-    for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
+    constexpr double dc = (double)0.005f, onea = (double)1.5f, twopi = 2.0 * 3.141592653589793, guard_rel = 3.0e-6;
+    for (int k = lane; k < K; k += BH_WAVE) omg[k] = twopi / T.periods[k];
     for (int idx = lane; idx < LS; idx += BH_WAVE) {
         const int l = idx / MPW, mg = idx - l * MPW;
-        const int sb = (int)blockIdx.x * MPW + mg;
+        const int sb = wid * MPW + mg;
         const int b = sb < A.B ? (perm ? perm[sb] : sb) : 0;
         float fd = 0.f, fa_ = 1.f, fb = 1.f, fr = 1.f;
         if (sb < A.B && l < A.nlay[b]) {
@@ -151,14 +179,13 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
     int mtop = mmax;
     for (int off = 32; off > 0; off >>= 1) mtop = max(mtop, __shfl_xor(mtop, off));
     mtop = __builtin_amdgcn_readfirstlane(mtop);
-    __syncthreads();
+    lean_wave_sync();
     LeanModel md;
     md.p = mdl + g;
     md.S = MPW;
     md.LS = LS;
 
     // ---- driver set-up (surfdisp96.f:124-217; SearchT::init): extremal velocities, start value, input sanity
-    constexpr double dc = (double)0.005f, onea = (double)1.5f, twopi = 2.0 * 3.141592653589793, guard_rel = 3.0e-6;
     float betmx = -1.e20f, betmn = 1.e20f;
     int jmn = 0, jsol = 1;
     bool sane = true;
@@ -199,13 +226,15 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
     int k = 0, ph = PH_START, idir = +1, ifirst = 1, nref = 0;
     double c1 = cm, clow = cm, del1 = 0.0, ck = 0.0, omega = 1.0, iom = 1.0;
     bool s1stneg = false;
-    double lo = 0.0, hi = 0.0, flo = 0.0, fhi = 0.0, p3 = 0.0, fp3 = 0.0, c3 = 0.0;
+    double cp = 0.0, delp = 0.0; // the grid point before c1 and its value (third point of the first estimate)
+    bool havep = false;
+    double lo = 0.0, hi = 0.0, flo = 0.0, fhi = 0.0, p3 = 0.0, fp3 = 0.0, c3 = 0.0, wprev = 0.0;
     bool have3 = false;
     double cell_lo = 0.0, cell_hi = 0.0, pb = 0.0, delb = 0.0;
     bool flo_neg = false;
     unsigned evals = 0;
     if (active) {
-        omega = twopi / per[0];
+        omega = omg[0];
         iom = fa::rcp(omega);
     }
     const unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
@@ -217,41 +246,43 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
         // ---- this lane's trial velocity
         double cev = c1, cprev = c1; // cprev: the grid point before a scan trial
         bool pt = false;             // this lane's value takes part in the round's decision
-        if (ph == PH_START || ph == PH_SCAN) {
-            if (ph == PH_SCAN) { // (label 1000 of getsol: the floor in a reversed search)
+        if (ph <= PH_SCAN) {
+            // The grid of getsol's scan (:437-446).  The reference forms it by repeated additions of dc; here point n is
+            // base + n dc in one fused operation -- the two differ in the last bits, i.e. by less than any value of the
+            // secular function that the kernels trust the sign of (fa::SIGN_FLOOR).
+            const bool start = ph == PH_START;
+            if (!start) { // (label 1000 of getsol: the floor in a reversed search)
                 if (idir > 0) {
                     if (c1 + dc <= clow) c1 = clow;
                 } else if (c1 - dc <= clow) {
                     idir = +1;
                     c1 = clow;
+                    havep = false;
                 }
             }
-            const bool start = ph == PH_START;
-            double q = (start && c1 + dc <= clow) ? clow : c1;
+            const double base = (start && c1 + dc <= clow) ? clow : c1;
             const int n = start ? r : r + 1; // steps from there
             const double step = (idir > 0 || start) ? dc : -dc;
-            cprev = q;
-            for (int i = 0; i < n; ++i) {
-                cprev = q;
-                q = q + step;
-            }
-            cev = (start && r == 0) ? c1 : q;
+            cprev = __builtin_fma((double)(n - 1), step, base);
+            cev = (n == 0) ? c1 : __builtin_fma((double)n, step, base);
             pt = true;
         } else if (ph == PH_REF1) {
-            cev = lo + (hi - lo) * ((double)(r + 1) / (double)(J + 1));
+            cev = __builtin_fma(hi - lo, (double)(r + 1) * fa::rcp((double)(J + 1)), lo);
             pt = cev > lo && cev < hi;
         } else if (ph == PH_REFC) {
             double x = 0.0;
             bool ok = false;
-            if (have3) {
+            if (have3) { // inverse quadratic interpolation through the three points
                 const double d12 = flo - fhi, d1p = flo - fp3, d2p = fhi - fp3;
-                if (d12 != 0.0 && d1p != 0.0 && d2p != 0.0) {
-                    x = lo * fhi * fp3 / (d12 * d1p) - hi * flo * fp3 / (d12 * d2p) + p3 * flo * fhi / (d1p * d2p);
+                const double den = d12 * d1p * d2p;
+                if (den != 0.0) {
+                    const double id = fa::rcp(den);
+                    x = (lo * fhi * fp3 * d2p - hi * flo * fp3 * d1p + p3 * flo * fhi * d12) * id;
                     ok = x > lo && x < hi;
                 }
             }
             if (!ok) {
-                x = lo - flo * (hi - lo) / (fhi - flo);
+                x = lo - flo * (hi - lo) * fa::rcp(fhi - flo);
                 if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
             }
             const int h = J / 2;
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
         const bool small = !(fabs(del) >= fa::SIGN_FLOOR);
         const double d_0 = __shfl(del, lbase), d_1 = __shfl(del, lbase + 1); // (every exchange outside the per-model branches)
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
-        if (ph == PH_START || ph == PH_SCAN) {
+        if (ph <= PH_SCAN) {
             const bool start = ph == PH_START;
             if (!(start && r == 0)) {
                 // (a start round's steps are upward ones; they are only consumed if the start value says so)
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                 else if (b_ >= vsafe && ((a_ <= vh0 && vh0 <= b_) || (a_ <= vh1 && vh1 <= b_))) ev = 3;
                 else if (cev < cm || cev >= betmxd + dc) ev = 4;
             }
-        } else if (ph == PH_REF1 || ph == PH_REFC) {
+        } else if (ph <= PH_REFC) {
             ev = (pt && dneg != sign_neg(flo)) ? 2 : 0;
         }
         const unsigned long long m_ev = (__ballot(ev != 0) >> lbase) & maskJ;
@@ -297,8 +328,9 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
         const int ie = lbase + (e < J ? e : J - 1);
         const int ev_e = __shfl(ev, ie);
         const double c_e = __shfl(cev, ie), d_e = __shfl(del, ie);
-        const double c_em = __shfl(cev, lbase + (e > 0 ? e - 1 : 0)), d_em = __shfl(del, lbase + (e > 0 ? e - 1 : 0));
-        const double c_last = __shfl(cev, lbase + J - 1), d_last = __shfl(del, lbase + J - 1);
+        const int iem = lbase + (e > 0 ? (e <= J ? e - 1 : J - 1) : 0), iem2 = lbase + (e > 1 ? (e <= J ? e - 2 : J - 2) : 0);
+        const double c_em = __shfl(cev, iem), d_em = __shfl(del, iem);     // e - 1 (e = J: the last trial)
+        const double c_em2 = __shfl(cev, iem2), d_em2 = __shfl(del, iem2); // e - 2 (e = J: the one before the last)
         // refinement rounds: the trials that take part form one run of lanes [r0, r1]
         const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1;
         const int i3 = (e < J) ? ((e + 1 <= r1) ? e + 1 : e - 2) : r1 - 1; // a third point next to the new bracket
@@ -307,7 +339,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
         if (!active) continue;
 
         int todo = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed; 3 root c3 accepted; 4 period done with c3
-        if (ph == PH_START || ph == PH_SCAN) {
+        if (ph <= PH_SCAN) {
             const bool start = ph == PH_START;
             int off = 0;
             bool consume = true;
@@ -315,11 +347,15 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                 ++evals;
                 if (m_small & 1ull) guard = true;
                 del1 = d_0;
+                havep = false;
                 if (ifirst == 1) s1stneg = sign_neg(d_0);
                 idir = (ifirst != 1 && s1stneg != sign_neg(d_0)) ? -1 : +1;
                 off = 1;
                 if (idir > 0) {
-                    if (c1 + dc <= clow) c1 = clow;
+                    if (c1 + dc <= clow) {
+                        c1 = clow;
+                        havep = false;
+                    }
                 } else {
                     consume = false; // reversed search: the upward steps are not the scan's
                 }
@@ -333,15 +369,26 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                     const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
                     if (m_small & used) guard = true;
                 }
-                // (c1, del1) after the steps before the event
+                // (c1, del1) and the point before it after the steps that precede the event (e = J: after all of them)
+                const int ns = e - off; // steps taken before the event
+                if (ns >= 2) {
+                    cp = c_em2;
+                    delp = d_em2;
+                    havep = true;
+                } else if (ns == 1) {
+                    cp = c1;
+                    delp = del1;
+                    havep = true;
+                }
+                if (ns >= 1) {
+                    c1 = c_em;
+                    del1 = d_em;
+                }
                 if (e < J) {
-                    if (e > off) {
-                        c1 = c_em;
-                        del1 = d_em;
-                    }
                     if (ev_e == 1) {
                         idir = +1;
                         c1 = clow;
+                        havep = false;
                     } else if (ev_e == 2) {
                         pb = c_e;
                         delb = d_e;
@@ -353,9 +400,6 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                     } else {
                         todo = 2;
                     }
-                } else if (J - 1 >= off) {
-                    c1 = c_last;
-                    del1 = d_last;
                 }
             }
         } else if (ph == PH_PROBE_STEP) {
@@ -363,12 +407,15 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
             if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
                 guard = true;
             } else { // the step is an ordinary one
+                cp = c1;
+                delp = del1;
+                havep = true;
                 c1 = pb;
                 del1 = delb;
                 ph = PH_SCAN;
                 if (c1 < cm || c1 >= betmxd + dc) todo = 2;
             }
-        } else if (ph == PH_REF1 || ph == PH_REFC) {
+        } else if (ph <= PH_REFC) {
             evals += (unsigned)__builtin_popcountll(m_pt);
             ++nref;
             const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
@@ -398,9 +445,19 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                     have3 = true;
                 }
             }
-            ph = PH_REFC;
-            if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 12 || m_pt == 0ull) {
-                c3 = lo - flo * (hi - lo) / (fhi - flo);
+            // the estimate's round did not close in (a poor estimate: an end value that is not the function's, a kink): J-section next
+            ph = (ph == PH_REFC && hi - lo > 0.25 * wprev) ? PH_REF1 : PH_REFC;
+            wprev = hi - lo;
+            if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 16 || m_pt == 0ull) {
+                // the root: inverse quadratic interpolation through the bracket's ends and the nearest third point (the secant
+                // point alone is off by a good part of the bracket where the function bends), else the secant point
+                c3 = lo - flo * (hi - lo) * fa::rcp(fhi - flo);
+                if (have3) {
+                    const double d12 = flo - fhi, d1p = flo - fp3, d2p = fhi - fp3;
+                    const double den = d12 * d1p * d2p;
+                    const double xq = (lo * fhi * fp3 * d2p - hi * flo * fp3 * d1p + p3 * flo * fhi * d12) * fa::rcp(den);
+                    if (den != 0.0 && xq >= lo && xq <= hi) c3 = xq;
+                }
                 if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
                 todo = 3;
             }
@@ -418,9 +475,12 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
             if (cell_hi > betmxd && cell_lo < betmxd) guard = true; // (up to three sign changes in there: the reference's sequence)
             lo = cell_lo;
             hi = cell_hi;
-            have3 = false;
+            p3 = cp;
+            fp3 = delp;
+            have3 = havep;
             nref = 0;
-            ph = PH_REF1;
+            wprev = hi - lo;
+            ph = have3 ? PH_REFC : PH_REF1;
         }
         if (todo == 3) { // the guard at an accepted bracket
             const double m2 = 2.0 * dc;
@@ -449,7 +509,7 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
                 if (k >= K) {
                     active = false;
                 } else {
-                    omega = twopi / per[k];
+                    omega = omg[k];
                     iom = fa::rcp(omega);
                     ifirst = 0;
                     c1 = ck - onea * dc;
@@ -494,41 +554,49 @@ __global__ __launch_bounds__(BH_WAVE) void swd_lean_kernel(SwdMultiArgs A)
 }
 } // namespace
 
-size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax)
+// LDS of one workgroup (LEAN_WPB wavefronts, a private region each)
+static size_t lean_wave_lds(int J, int Lmax, int Kmax)
 {
-    return ((size_t)((Kmax + 1) & ~1) + (size_t)7 * Lmax * (BH_WAVE / J)) * sizeof(double);
+    return ((((size_t)((Kmax + 1) & ~1) + (size_t)7 * Lmax * (BH_WAVE / J)) * sizeof(double)) + 15) & ~(size_t)15;
 }
+size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax) { return LEAN_WPB * lean_wave_lds(J, Lmax, Kmax); }
 
-// Trials per model and round for a launch of `nt` targets over B models: as many as keep the launch within two wavefronts
-// per SIMD (power of two, 16 at most; 0: the batch is too large for this kernel -- fewer than 4 trials).
-int bh_swd_lean_trials(int B, int nt, int ncu)
+// Trials per model and round for a call of `nt` targets over B models: 16 while that keeps the launch within two wavefronts
+// per SIMD of an MI355X (8192 (model, target) pairs: the latency regime -- fewer rounds), 8 beyond (the throughput regime --
+// fewer evaluations that the scan does not consume).  A function of the call's shape alone, NOT of the device: a model's
+// result depends on it in the last bits (the refinement's trial points do), and a sampler's windows must not.
+int bh_swd_lean_trials(int B, int nt)
 {
-    const long slots = 2L * 4L * (ncu > 0 ? ncu : 256);
-    for (int J = 16; J >= 4; J /= 2) {
-        const long waves = (long)nt * (((long)B * J + BH_WAVE - 1) / BH_WAVE);
-        if (waves <= slots) return J;
-    }
-    return 0;
+    return ((long)B * nt <= 8192) ? 16 : 8;
 }
 
 // All targets of `a` (fundamental-mode phase velocities, a.t[t].look = trials per round, gcount / glist set) in one launch.
-int bh_launch_swd_lean(const SwdMultiArgs &a, hipStream_t stream, SwdLaunchInfo *info)
+int bh_launch_swd_lean(const SwdMultiArgs &a0, hipStream_t stream, SwdLaunchInfo *info)
 {
+    SwdMultiArgs a = a0;
     int kmax = 0, jmin = BH_WAVE;
-    long wmax = 1, wsum = 0;
+    long wmax = 1, wsum = 0, nw[BH_MAX_TARGETS] = {0};
     for (int t = 0; t < a.ntargets; ++t) {
         const int J = a.t[t].look;
         if (J < 4 || J > BH_WAVE || (J & (J - 1)) != 0 || a.t[t].igr != 0 || a.t[t].mode > 1) return -1;
         kmax = a.t[t].K > kmax ? a.t[t].K : kmax;
         jmin = J < jmin ? J : jmin;
         const int mpw = BH_WAVE / J;
-        const long w = (a.B + mpw - 1) / mpw;
-        wmax = w > wmax ? w : wmax;
-        wsum += w;
+        nw[t] = (a.B + mpw - 1) / mpw;
+        wmax = nw[t] > wmax ? nw[t] : wmax;
+        wsum += nw[t];
     }
-    const size_t lds = bh_swd_lean_lds_bytes(jmin, a.Lmax, kmax);
+    const size_t wave_lds = lean_wave_lds(jmin, a.Lmax, kmax);
+    const size_t lds = LEAN_WPB * wave_lds;
     if (lds > 64 * 1024) return -1;
-    const dim3 grid((unsigned)wmax, (unsigned)a.ntargets), block(BH_WAVE);
+    dim3 grid((unsigned)((wmax + LEAN_WPB - 1) / LEAN_WPB), (unsigned)a.ntargets);
+    a.wg_n0 = a.wg_n1 = 0;
+    if (a.ntargets == 2) { // interleaved (see the kernel)
+        a.wg_n0 = (int)nw[0];
+        a.wg_n1 = (int)nw[1];
+        grid = dim3((unsigned)((wsum + LEAN_WPB - 1) / LEAN_WPB), 1);
+    }
+    const dim3 block(BH_WAVE * LEAN_WPB);
     if (info != nullptr) {
         info->workgroups = grid.x * grid.y;
         info->waves = wsum;
@@ -536,6 +604,6 @@ int bh_launch_swd_lean(const SwdMultiArgs &a, hipStream_t stream, SwdLaunchInfo 
         info->fast_arith = 1;
         info->restarts_in_place = 0;
     }
-    hipLaunchKernelGGL(swd_lean_kernel, grid, block, lds, stream, a);
+    hipLaunchKernelGGL(swd_lean_kernel, grid, block, lds, stream, a, (int)wave_lds);
     return 0;
 }

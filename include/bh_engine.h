@@ -118,6 +118,18 @@ int bh_engine_get_swd_search(const bh_engine *e);
 #define BH_ARITH_FAST 1
 int bh_engine_set_swd_arith(bh_engine *e, int arith);
 int bh_engine_get_swd_arith(const bh_engine *e);
+/* Which dispersion kernel the most recent call with dispersion targets launched (diagnostic; -1: none yet):
+ *   BH_KERNEL_GROUP  several lanes per model, layer-parallel (swd_group_kernel),
+ *   BH_KERNEL_LANE   one lane per evaluation, reference-exact or FA builds (swd_kernel),
+ *   BH_KERNEL_LEAN   one lane per trial velocity with the fast arithmetic (swd_lean_kernel): BH_SEARCH_FAST + BH_ARITH_FAST
+ *                    calls whose targets are all fundamental-mode phase velocities and whose models fit its LDS budget
+ *                    (up to 32 layers).  It evaluates 16 trial velocities per model and round in calls of up to 8192
+ *                    (model, target) pairs and 8 beyond; a model's velocities depend on that number in their last bits
+ *                    (~1e-9 relative) and on nothing else about the call. */
+#define BH_KERNEL_GROUP 0
+#define BH_KERNEL_LANE 1
+#define BH_KERNEL_LEAN 2
+int bh_engine_last_swd_kernel(const bh_engine *e);
 /* The bracket scan of Love targets (any root refinement).  Results never depend on this setting.
  * getsol's scan (surfdisp96.f:437-460) evaluates every step of its grid until the secular function changes sign.  For Love
  * waves the number of sign changes below a trial velocity is read off the recursion that evaluates the function (a Sturm
