@@ -117,6 +117,7 @@ struct bh_engine {
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
     SwdPairWork pairwork{};                // SIMD-pairing order of the group kernel (bh_device.h)
     bool no_pair = false;                  // BH_SWD_NO_PAIR env: order by depth only (A/B testing)
+    int swd_trials = 0;                    // bh_engine_set_swd_trials: trials per round of the trial-per-lane kernel (0 = by the call's shape)
     int last_swd_kernel = -1;              // bh_engine_last_swd_kernel
     SwdLaunchInfo last_swd{};              // of the most recent group-kernel launch (workgroups == 0: none)
     int last_swd_wpb = 2;                  // its wavefronts per workgroup
@@ -465,7 +466,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         bool all = e->swd_arith == BH_ARITH_FAST && e->swd_search == BH_SEARCH_FAST && e->force_group == 0 && e->force_look == 0 &&
                    e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS && Lmax <= 32;
         for (int j = 0; j < njobs; ++j) all = all && (jobs[j].K == 0 || jobs[j].igr == 0);
-        if (all) lean_trials = bh_swd_lean_trials(B, nlive);
+        if (all) lean_trials = e->swd_trials > 0 ? e->swd_trials : bh_swd_lean_trials(B, nlive);
         if (lean_trials >= 4 && bh_swd_lean_lds_bytes(lean_trials, Lmax, kmax) > lds_cap) lean_trials = 0; // (a workgroup's LDS)
     }
     const bool lean = lean_trials >= 4;
@@ -915,6 +916,15 @@ int bh_engine_set_swd_arith(bh_engine *e, int arith)
 }
 int bh_engine_get_swd_arith(const bh_engine *e) { return e ? e->swd_arith : 0; }
 int bh_engine_last_swd_kernel(const bh_engine *e) { return e ? e->last_swd_kernel : -1; }
+int bh_engine_set_swd_trials(bh_engine *e, int trials)
+{
+    if (!e) return BH_EINVAL;
+    if (trials != 0 && trials != 4 && trials != 8 && trials != 16 && trials != 32 && trials != 64)
+        return fail(e, BH_EINVAL, "trials must be 0 (by the call's shape), 4, 8, 16, 32 or 64");
+    e->swd_trials = trials;
+    return BH_OK;
+}
+int bh_engine_get_swd_trials(const bh_engine *e) { return e ? e->swd_trials : 0; }
 int bh_engine_set_swd_prescan(bh_engine *e, int on)
 {
     if (!e) return BH_EINVAL;

@@ -60,7 +60,7 @@ def auto_spec_depth(nchains, budget=None):
 
 class DeviceChains(object):
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast"):
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast", arith="exact"):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
         torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
         (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
@@ -85,7 +85,14 @@ class DeviceChains(object):
         chains sample does not change (tests/test_gpu_device_chains.py::test_search_modes_sample_the_same_posterior),
         a window takes 22-27 % less.  "fast_rayleigh": the short refinement for the Rayleigh targets only.
         "reference": the reference's bits throughout (what `ChainBatch`, the replay of recorded reference runs, uses);
-        None: whatever the engine is set to."""
+        None: whatever the engine is set to.
+        arith: arithmetic of those launches where every dispersion target takes the short refinement (Engine.set_swd_arith,
+        applied like `search`).  Default "exact": the windows keep the layer-parallel kernel, whose rounds cost the same
+        whatever a model's depth and which restarts a guarded model in place -- measured on MI355X (chain-iterations/s,
+        "exact" / "fast"): 8 chains 5.3e4 / 6.0e4, a 64-chain tempered rung (hot chains: deep models) 1.84e5 / 1.64e5, 512
+        chains 4.0e5 / 3.6e5.  "fast": the trial-per-lane kernel with 16 trials per round whatever the window's size
+        (Engine.set_swd_trials), so that windows of any depth and shards of any size walk the same trajectory.  None:
+        whatever the engine is set to."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
@@ -96,6 +103,9 @@ class DeviceChains(object):
         if search not in (None, "reference", "fast", "fast_rayleigh"):
             raise ValueError("search must be None, 'reference', 'fast' or 'fast_rayleigh'")
         self.search = search
+        if arith not in (None, "exact", "fast"):
+            raise ValueError("arith must be None, 'exact' or 'fast'")
+        self.arith = arith
         if device is None:
             device = self.engine.device
         if int(device) != int(self.engine.device):
@@ -254,6 +264,10 @@ class DeviceChains(object):
         prev = e.swd_search() if self.search is not None else None
         if prev is not None and prev != self.search:
             e.set_swd_search(self.search)
+        prev_arith, prev_trials = (e.swd_arith() if self.arith is not None else None), e.swd_trials()
+        if prev_arith is not None and prev_arith != self.arith:
+            e.set_swd_arith(self.arith)
+        e.set_swd_trials(16)
         try:
             e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
                                  t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),
@@ -262,6 +276,9 @@ class DeviceChains(object):
             e.set_typical_layers(0)
             if prev is not None and prev != self.search:
                 e.set_swd_search(prev)
+            if prev_arith is not None and prev_arith != self.arith:
+                e.set_swd_arith(prev_arith)
+            e.set_swd_trials(prev_trials)
         e.chain_accept_window(self.cfg, self.state, Cn, self.iiter, w, self.ld, self.logL.data_ptr(), self.mis.data_ptr())
         self.iiter += w
         self.launches += 1

@@ -112,6 +112,8 @@ def load_library():
     L.bh_engine_get_swd_search.argtypes = [vp]
     L.bh_engine_set_swd_arith.argtypes = [vp, C.c_int]
     L.bh_engine_last_swd_kernel.argtypes = [vp]
+    L.bh_engine_set_swd_trials.argtypes = [vp, C.c_int]
+    L.bh_engine_get_swd_trials.argtypes = [vp]
     L.bh_engine_get_swd_arith.argtypes = [vp]
     L.bh_engine_set_swd_scan.argtypes = [vp, C.c_int]
     L.bh_engine_get_swd_scan.argtypes = [vp]
@@ -143,7 +145,7 @@ def load_library():
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
@@ -155,7 +157,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                     "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
                     "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                     "bh_chain_propose_window", "bh_chain_accept_window")
@@ -277,6 +279,14 @@ class Engine(object):
         if code is None:
             raise ValueError("arith must be 'exact' or 'fast'")
         self._check(self._L.bh_engine_set_swd_arith(self._h, code))
+
+    def set_swd_trials(self, trials):
+        """Trials per model and round of the trial-per-lane kernel: 0 = by the call's shape (16 up to 8192 (model, target)
+        pairs, 8 beyond), or 4 / 8 / 16 / 32 / 64 in every call (bh_engine_set_swd_trials)."""
+        self._check(self._L.bh_engine_set_swd_trials(self._h, int(trials)))
+
+    def swd_trials(self):
+        return int(self._L.bh_engine_get_swd_trials(self._h))
 
     def last_swd_kernel(self):
         """Which dispersion kernel the most recent call launched: "group", "lane", "lean" (bh_engine_last_swd_kernel) or None."""

@@ -126,6 +126,11 @@ int bh_engine_get_swd_arith(const bh_engine *e);
  *                    (up to 32 layers).  It evaluates 16 trial velocities per model and round in calls of up to 8192
  *                    (model, target) pairs and 8 beyond; a model's velocities depend on that number in their last bits
  *                    (~1e-9 relative) and on nothing else about the call. */
+/* Trials per model and round of BH_KERNEL_LEAN: 0 (default) = by the call's shape as described above; 4, 8, 16, 32 or 64 =
+ * that many in every call -- what a sampler sets whose windows and shards must give the same bits whatever their size
+ * (DeviceChains: 16). */
+int bh_engine_set_swd_trials(bh_engine *e, int trials);
+int bh_engine_get_swd_trials(const bh_engine *e);
 #define BH_KERNEL_GROUP 0
 #define BH_KERNEL_LANE 1
 #define BH_KERNEL_LEAN 2
