@@ -61,11 +61,13 @@ class _Chain(object):
 class ChainBatch(object):
     """`nchains` independent rj-McMC chains sharing one set of targets and one engine."""
 
-    def __init__(self, targets, seeds, initparams=None, modelpriors=None, search="reference"):
+    def __init__(self, targets, seeds, initparams=None, modelpriors=None, search="reference", arith="exact"):
         """search: root refinement of the dispersion search in the chains' evaluation calls (Engine.set_swd_search).  The
         default is the REFERENCE's sequence, whatever the engine's own setting: these chains walk in the reference's order
-        from the reference's seeds, and a recorded run of `SingleChain` replays exactly only with the reference's bits."""
+        from the reference's seeds, and a recorded run of `SingleChain` replays exactly only with the reference's bits.
+        arith: the arithmetic where every dispersion target of a call takes the short refinement (Engine.set_swd_arith)."""
         self.search = search
+        self.arith = arith
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
         self.priors = dict(DEFAULT_PRIORS)
         self.priors.update(modelpriors or {})
@@ -229,7 +231,7 @@ class ChainBatch(object):
             nlay[b] = n
             h[:n, b], vp[:n, b], vs[:n, b] = ph, pvp, pvs
             noise[b] = nz
-        with self.targets.engine.searching(self.search):
+        with self.targets.engine.searching(self.search), self.targets.engine.computing(self.arith):
             logL, misfits, err = self.targets.evaluate_batch(nlay, h, vp, vs, noise)
         return list(logL), [m for m in misfits]
 

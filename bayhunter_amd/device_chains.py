@@ -143,7 +143,8 @@ class DeviceChains(object):
 
         # ---- initial state through the reference-order host code --------------------------------
         host = ChainBatch(self.targets, chain_seeds(seed, off, self.C), ip, pr,
-                          search=self.search if self.search is not None else self.targets.engine.swd_search())
+                          search=self.search if self.search is not None else self.targets.engine.swd_search(),
+                          arith=self.arith if self.arith is not None else self.targets.engine.swd_arith())
         self.noisepriors = host.noisepriors
         self.targets._register()  # constant target data + laws live on the device from here on
 

@@ -40,8 +40,8 @@ Workloads (BASELINE.json configs):
 N > 1: one process per GPU (torchrun), independent batches per rank, no data-path collective
 (the path shards by model) -> "scaling": "weak"; barrier + max-over-ranks timing.
 
-`roofline` is for the dominant kernel (the dispersion kernel `swd_group_kernel`, Rayleigh + Love wavefronts in one
-launch): achieved = algorithmic bytes per launch / its average launch duration measured with HIP events on the launch
+`roofline` is for the dominant kernel (the dispersion kernel -- with the engine's defaults `swd_lean_kernel`, Rayleigh + Love
+wavefronts in one launch): achieved = algorithmic bytes per launch / its average launch duration measured with HIP events on the launch
 stream during the timed region.  `cpu_baseline` is the reference's own Fortran / C++ (oracle/_ref, built from
 /root/reference where it exists; kind "reference") driven by a process pool on this box's host cores on a bounded sample
 of the same workload; without oracle/_ref the oracle (the bit-exact CPU restatement, OpenMP) is the baseline (kind "port").
@@ -300,7 +300,7 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
         kw = dict(betas=np.tile(ladder, C // 8), ladder=np.repeat(np.arange(C // 8), 8) + (C // 8) * rank, swap_every=100)
     # ONE job seed on every rank: the chains' streams follow their global index, the exchange decisions the job seed
     dc = DeviceChains(jt, C, init, priors, seed=20260927, device=dev.index, dist=dist if world > 1 else None,
-                      spec_depth=args.spec_depth or None, search=None, **kw)   # (search: the engine's setting = --search)
+                      spec_depth=args.spec_depth or None, search=None, **({"arith": args.arith} if args.arith else {}), **kw)   # (search: the engine's setting = --search; arith: DeviceChains' own default unless --arith)
 
     def fence():
         eng.synchronize(); torch.cuda.synchronize()
@@ -606,16 +606,23 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     bytes_per_launch = nswd * B * (4 * L * 8 + K * 8 + 4)
     swd_ms_per_launch = fam_ms["swd"] / max(1, ncalls)
     achieved = bytes_per_launch / (swd_ms_per_launch * 1e-3) / 1e9
-    pmc = pmc_summary(workload + ("fast" if eng.swd_search() != "reference" else ""), B)
+    lean = eng.last_swd_kernel() == "lean"
+    # (committed counter passes: "<workload>" = the reference's sequence, "<workload>fast" = the engine's defaults -- short refinement
+    #  + fast arithmetic = the trial-per-lane kernel --, "<workload>fastexact" = short refinement with the reference's arithmetic)
+    pmc = pmc_summary(workload + ("" if eng.swd_search() == "reference" else ("fast" if lean else "fastexact")), B)
     # measured HBM bytes per launch (PMC pass of tools/profile_round.sh, committed summary); null without one
     traffic = pmc.get("hbm_bytes_per_launch")
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
             **pmc_stamp(pmc, swd_ms_per_launch),
             "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
-            "traffic_note": "what exceeds the algorithmic bytes is not model data: the wavefronts' progress board (a word per hardware "
-                            "wavefront slot, polled every 8 rounds) -- ~10 GB/s, a thousandth of the HBM peak",
-            "kernel": "swd_group_kernel (all dispersion targets of a step in one launch)",
+            "traffic_note": ("the models are read once per lane group; what exceeds the algorithmic bytes is the re-run launch's look at the (empty) guard "
+                             "lists and the kernels' code" if lean else
+                             "what exceeds the algorithmic bytes is not model data: the wavefronts' progress board (a word per hardware "
+                             "wavefront slot, polled every 8 rounds) -- ~10 GB/s, a thousandth of the HBM peak"),
+            "kernel": {"lean": "swd_lean_kernel (one lane per trial velocity; all dispersion targets of a step in one launch)",
+                       "lane": "swd_kernel (one lane per evaluation; one launch per dispersion target)"}.get(
+                           eng.last_swd_kernel(), "swd_group_kernel (all dispersion targets of a step in one launch)"),
             "kernel_ms_per_launch": swd_ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "required HBM line; the kernel is a scalar FP64 recurrence and is bound by FP64 vector issue, not by HBM "
                     "(SURVEY.md 8(d)): see binding"}
@@ -821,6 +828,10 @@ def main():
     ap.add_argument("--search", default=None, choices=["reference", "fast", "fast_rayleigh"],
                     help="root refinement of the dispersion search (bh_engine_set_swd_search): fast = the engine's default, what "
                          "`value` is measured with; reference = the reference's own sequence, bit-identical velocities")
+    ap.add_argument("--arith", default=None, choices=["fast", "exact"],
+                    help="arithmetic of the launches in which every target takes the short refinement (bh_engine_set_swd_arith): "
+                         "fast = the engine's default, what `value` is measured with (the trial-per-lane kernel); exact = the "
+                         "reference's rounding points.  The chain workloads take DeviceChains' own default (exact) unless given")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="also: the other search, the RF kernels alone, the port baseline, the CPU pool sweep")
@@ -888,6 +899,8 @@ def main():
     from bayhunter_amd import engine as E
     eng = E.Engine(local_rank)
     eng.set_swd_search(args.search)
+    if args.arith:
+        eng.set_swd_arith(args.arith)
     t_start = time.perf_counter()
     out = None
     if args.workload in ("c4", "c5", "c5_full"):

@@ -384,13 +384,16 @@ def test_guarded_models_restart_inside_their_own_wavefront_in_one_model_per_wave
 
 
 def test_default_search_is_the_short_refinement(engine, oracle):
-    """A fresh engine takes the guarded short refinement for fundamental-mode phase velocities (the bits of its CPU
-    restatement) and the reference's sequence for everything else (group velocities, higher modes: the reference's bits);
-    the setting is per engine."""
+    """A fresh engine takes the guarded short refinement for fundamental-mode phase velocities (with the reference's
+    arithmetic selected: the bits of its CPU restatement; its own default, the fast arithmetic: tests/test_gpu_swd_lean.py) and
+    the reference's sequence for everything else (group velocities, higher modes: the reference's bits); the settings are per
+    engine."""
     from bayhunter_amd import engine as E
     eng = E.Engine(0)
     try:
         assert eng.swd_search() == "fast" and engine.swd_search() == "reference"
+        assert eng.swd_arith() == "fast" and engine.swd_arith() == "exact"
+        eng.set_swd_arith("exact")
         rs = np.random.RandomState(77)
         nlay, h, vp, vs, rho = synth_models(rs, 700, 10, lvz_frac=0.25, ragged=True)
         a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]

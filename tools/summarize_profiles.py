@@ -101,7 +101,8 @@ def steady(v):
 
 summary = {}
 DOM = {"c2": ("swd_group_kernel", 4096), "c3": ("swd_group_kernel", 4096), "c2noboard": ("swd_group_kernel", 4096),
-       "c2fast": ("swd_group_kernel", 4096), "c3fast": ("swd_group_kernel", 4096),
+       "c2fast": ("swd_lean_kernel", 4096), "c3fast": ("swd_lean_kernel", 4096),   # the engine's defaults: the trial-per-lane kernel
+       "c2fastexact": ("swd_group_kernel", 4096),                                   # short refinement, the reference's arithmetic
        "rf_c3": ("rf_synth_kernel", 4096)}
 
 
