@@ -238,14 +238,26 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         iom = fa::rcp(omega);
     }
     const unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
+    // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG (J >= 16).  The estimate x that a round of clustered trials is centred on is, 99 times
+    // in 100, within 2e-7 |x| of the root it then finds.  So only the lower half of the model's lanes carry the cluster; the upper
+    // half evaluates -- at the NEXT period's frequency -- the first round of the next period's scan on the grid anchored at
+    // x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x, those values ARE the next period's first
+    // round (its grid is anchored 2.5e-7 relative off the root: the reference's own root is known to 1e-6, and the guard covers
+    // grids that differ by 3e-6); otherwise they are dropped.  Two rounds per period instead of three.
+    const int H = J / 2;
+    const bool can_spec = J >= 16;
+    const unsigned long long maskH = (1ull << H) - 1ull;
     unsigned nrounds = 0;
     long long t_eval = 0;
     const long long t_start = (A.neval != nullptr) ? clock64() : 0;
     while (__ballot(active) != 0ull) {
         ++nrounds;
-        // ---- this lane's trial velocity
+        // ---- this lane's trial velocity (and frequency)
         double cev = c1, cprev = c1; // cprev: the grid point before a scan trial
-        bool pt = false;             // this lane's value takes part in the round's decision
+        double om_l = omega, iom_l = iom;
+        bool pt = false;             // this lane's value takes part in the refinement's decision
+        bool spec = false;           // the upper half of this model's lanes carries the next period's first round
+        double xspec = 0.0;
         if (ph <= PH_SCAN) {
             // The grid of getsol's scan (:437-446).  The reference forms it by repeated additions of dc; here point n is
             // base + n dc in one fused operation -- the two differ in the last bits, i.e. by less than any value of the
@@ -265,7 +277,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             const double step = (idir > 0 || start) ? dc : -dc;
             cprev = __builtin_fma((double)(n - 1), step, base);
             cev = (n == 0) ? c1 : __builtin_fma((double)n, step, base);
-            pt = true;
         } else if (ph == PH_REF1) {
             cev = __builtin_fma(hi - lo, (double)(r + 1) * fa::rcp((double)(J + 1)), lo);
             pt = cev > lo && cev < hi;
@@ -285,10 +296,23 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 x = lo - flo * (hi - lo) * fa::rcp(fhi - flo);
                 if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
             }
-            const int h = J / 2;
-            const double w = 1.0e-7 * fabs(x);
-            cev = (r < h) ? x - __builtin_ldexp(w, 2 * (h - 1 - r)) : x + __builtin_ldexp(w, 2 * (r - h));
-            pt = cev > lo && cev < hi;
+            spec = can_spec && k + 1 < K;
+            xspec = x;
+            const int nc = spec ? H : J; // lanes of the cluster
+            if (r < nc) {
+                const int h = nc / 2;
+                const double w = 1.0e-7 * fabs(x);
+                cev = (r < h) ? x - __builtin_ldexp(w, 2 * (h - 1 - r)) : x + __builtin_ldexp(w, 2 * (r - h));
+                pt = cev > lo && cev < hi;
+            } else { // the next period's first round on the grid anchored at the estimate (k + 1 >= 1: clow = cm)
+                const int s_ = r - H;
+                const double c1n = x - onea * dc;
+                const double basen = (c1n + dc <= cm) ? cm : c1n;
+                cprev = __builtin_fma((double)(s_ - 1), dc, basen);
+                cev = (s_ == 0) ? c1n : __builtin_fma((double)s_, dc, basen);
+                om_l = omg[k + 1];
+                iom_l = fa::rcp(om_l);
+            }
         } else if (ph == PH_PROBE_STEP) {
             const double l_ = fmin(c1, pb), h_ = fmax(c1, pb);
             cev = (r == 0) ? l_ + guard_rel * h_ : h_ - guard_rel * h_;
@@ -297,23 +321,27 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         }
         if (!active || !(cev > 0.0)) cev = 1.0; // (finished or broken models compute on a harmless value)
         const long long te0 = (A.neval != nullptr) ? clock64() : 0;
-        const double wvno = omega * fa::rcp(cev);
-        const double del = (ifunc == 2) ? lean_rayleigh(wvno, omega, iom, md, mmax, mtop) : lean_love(wvno, omega, md, mmax, mtop);
+        const double wvno = om_l * fa::rcp(cev);
+        const double del = (ifunc == 2) ? lean_rayleigh(wvno, om_l, iom_l, md, mmax, mtop) : lean_love(wvno, om_l, md, mmax, mtop);
         if (A.neval != nullptr) t_eval += clock64() - te0;
 
-        // ---- the round's decision: one event code per lane, ballots, the values at the event
+        // ---- the round's decision: one event code per lane, ballots, the values at the events (every exchange outside the
+        // per-model branches).  Window A = the lanes of this round's own business (all J, or the cluster's H); window B = the
+        // upper H lanes where they carry the next period's first round.
         const bool dneg = sign_neg(del);
         const bool small = !(fabs(del) >= fa::SIGN_FLOOR);
-        const double d_0 = __shfl(del, lbase), d_1 = __shfl(del, lbase + 1); // (every exchange outside the per-model branches)
+        const double d_0 = __shfl(del, lbase), d_1 = __shfl(del, lbase + 1), d_H = __shfl(del, lbase + H);
+        const bool inB = ph == PH_REFC && spec && r >= H;
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
-        if (ph <= PH_SCAN) {
-            const bool start = ph == PH_START;
-            if (!(start && r == 0)) {
-                // (a start round's steps are upward ones; they are only consumed if the start value says so)
-                const bool down = !start && idir < 0;
+        if (ph <= PH_SCAN || inB) {
+            const bool first = ph == PH_START || inB;        // the window is a period's first round: trial 0 = the start value,
+            const int rr = inB ? r - H : r;                  // the steps upward (consumed only if the start value says so)
+            if (!(first && rr == 0)) {
+                const bool down = !first && idir < 0;
                 const double a_ = fmin(cprev, cev), b_ = fmax(cprev, cev);
-                const bool refneg = start ? sign_neg(d_0) : sign_neg(del1);
-                if (down && cev <= clow) ev = 1;
+                const bool refneg = inB ? sign_neg(d_H) : (first ? sign_neg(d_0) : sign_neg(del1));
+                const double floor_ = inB ? cm : clow;
+                if (down && cev <= floor_) ev = 1;
                 else if (dneg != refneg) ev = 2;
                 else if (b_ >= vsafe && ((a_ <= vh0 && vh0 <= b_) || (a_ <= vh1 && vh1 <= b_))) ev = 3;
                 else if (cev < cm || cev >= betmxd + dc) ev = 4;
@@ -324,206 +352,230 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const unsigned long long m_ev = (__ballot(ev != 0) >> lbase) & maskJ;
         const unsigned long long m_small = (__ballot(small) >> lbase) & maskJ;
         const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
-        const int e = m_ev ? (int)__builtin_ctzll(m_ev) : J; // first event among the model's trials
-        const int ie = lbase + (e < J ? e : J - 1);
-        const int ev_e = __shfl(ev, ie);
-        const double c_e = __shfl(cev, ie), d_e = __shfl(del, ie);
-        const int iem = lbase + (e > 0 ? (e <= J ? e - 1 : J - 1) : 0), iem2 = lbase + (e > 1 ? (e <= J ? e - 2 : J - 2) : 0);
-        const double c_em = __shfl(cev, iem), d_em = __shfl(del, iem);     // e - 1 (e = J: the last trial)
-        const double c_em2 = __shfl(cev, iem2), d_em2 = __shfl(del, iem2); // e - 2 (e = J: the one before the last)
+        const int nA = (ph == PH_REFC && spec) ? H : J;
+        const unsigned long long m_evA = m_ev & ((ph == PH_REFC && spec) ? maskH : maskJ), m_evB = (m_ev >> H) & maskH;
+        const int eA = m_evA ? (int)__builtin_ctzll(m_evA) : nA; // first event among window A's trials (nA: none)
+        const int eB = m_evB ? (int)__builtin_ctzll(m_evB) : H;
+        const int iA = lbase + (eA < nA ? eA : nA - 1), iA1 = lbase + (eA > 0 ? eA - 1 : 0), iA2 = lbase + (eA > 1 ? eA - 2 : 0);
+        const int iB = lbase + H + (eB < H ? eB : H - 1), iB1 = lbase + H + (eB > 0 ? eB - 1 : 0), iB2 = lbase + H + (eB > 1 ? eB - 2 : 0);
+        const int evA_e = __shfl(ev, iA), evB_e = __shfl(ev, iB);
+        const double cA_e = __shfl(cev, iA), dA_e = __shfl(del, iA), cA_1 = __shfl(cev, iA1), dA_1 = __shfl(del, iA1),
+                     cA_2 = __shfl(cev, iA2), dA_2 = __shfl(del, iA2);
+        const double cB_e = __shfl(cev, iB), dB_e = __shfl(del, iB), cB_1 = __shfl(cev, iB1), dB_1 = __shfl(del, iB1),
+                     cB_2 = __shfl(cev, iB2), dB_2 = __shfl(del, iB2);
         // refinement rounds: the trials that take part form one run of lanes [r0, r1]
         const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1;
-        const int i3 = (e < J) ? ((e + 1 <= r1) ? e + 1 : e - 2) : r1 - 1; // a third point next to the new bracket
+        const int i3 = (eA < nA) ? ((eA + 1 <= r1) ? eA + 1 : eA - 2) : r1 - 1; // a third point next to the new bracket
         const double c_3 = __shfl(cev, lbase + (i3 >= 0 && i3 < J ? i3 : 0)), d_3 = __shfl(del, lbase + (i3 >= 0 && i3 < J ? i3 : 0));
         const double c_r1 = __shfl(cev, lbase + (r1 >= 0 ? r1 : 0)), d_r1 = __shfl(del, lbase + (r1 >= 0 ? r1 : 0));
         if (!active) continue;
 
-        int todo = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed; 3 root c3 accepted; 4 period done with c3
-        if (ph <= PH_SCAN) {
-            const bool start = ph == PH_START;
-            int off = 0;
-            bool consume = true;
-            if (start) {
-                ++evals;
-                if (m_small & 1ull) guard = true;
-                del1 = d_0;
-                havep = false;
-                if (ifirst == 1) s1stneg = sign_neg(d_0);
-                idir = (ifirst != 1 && s1stneg != sign_neg(d_0)) ? -1 : +1;
-                off = 1;
-                if (idir > 0) {
-                    if (c1 + dc <= clow) {
-                        c1 = clow;
-                        havep = false;
+        // Pass 0: this round's own business.  Pass 1 (only after pass 0 has finished a period whose cluster round carried the next
+        // period's first round, and the root came out where the estimate was): that first round.
+        bool again = false;
+        int pass = 0;
+        do {
+            const bool useB = pass == 1;
+            again = false;
+            int todo = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed; 3 root c3 accepted; 4 period done with c3
+            if (useB || ph <= PH_SCAN) {
+                const bool start = useB || ph == PH_START;
+                const int wn = useB ? H : J, e = useB ? eB : eA, ev_e = useB ? evB_e : evA_e;
+                const unsigned long long msm = useB ? (m_small >> H) & maskH : m_small;
+                const double c_e = useB ? cB_e : cA_e, d_e = useB ? dB_e : dA_e, c_em = useB ? cB_1 : cA_1, d_em = useB ? dB_1 : dA_1,
+                             c_em2 = useB ? cB_2 : cA_2, d_em2 = useB ? dB_2 : dA_2, d_first = useB ? d_H : d_0;
+                int off = 0;
+                bool consume = true;
+                if (start) {
+                    ++evals;
+                    if (msm & 1ull) guard = true;
+                    del1 = d_first;
+                    havep = false;
+                    if (ifirst == 1) s1stneg = sign_neg(d_first);
+                    idir = (ifirst != 1 && s1stneg != sign_neg(d_first)) ? -1 : +1;
+                    off = 1;
+                    if (idir > 0) {
+                        if (c1 + dc <= clow) {
+                            c1 = clow;
+                            havep = false;
+                        }
+                    } else {
+                        consume = false; // reversed search: the upward steps are not the scan's
                     }
-                } else {
-                    consume = false; // reversed search: the upward steps are not the scan's
+                    ph = PH_SCAN;
                 }
-                ph = PH_SCAN;
-            }
-            if (consume) {
-                // trials off .. e are consumed (a floor event: off .. e - 1)
-                const int last = (e < J) ? ((ev_e == 1) ? e - 1 : e) : J - 1;
-                if (last >= off) {
-                    evals += (unsigned)(last - off + 1);
-                    const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
-                    if (m_small & used) guard = true;
+                if (consume) {
+                    // trials off .. e are consumed (a floor event: off .. e - 1)
+                    const int last = (e < wn) ? ((ev_e == 1) ? e - 1 : e) : wn - 1;
+                    if (last >= off) {
+                        evals += (unsigned)(last - off + 1);
+                        const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
+                        if (msm & used) guard = true;
+                    }
+                    // (c1, del1) and the point before it after the steps that precede the event (e = wn: after all of them)
+                    const int ns = e - off; // steps taken before the event
+                    if (ns >= 2) {
+                        cp = c_em2;
+                        delp = d_em2;
+                        havep = true;
+                    } else if (ns == 1) {
+                        cp = c1;
+                        delp = del1;
+                        havep = true;
+                    }
+                    if (ns >= 1) {
+                        c1 = c_em;
+                        del1 = d_em;
+                    }
+                    if (e < wn) {
+                        if (ev_e == 1) {
+                            idir = +1;
+                            c1 = clow;
+                            havep = false;
+                        } else if (ev_e == 2) {
+                            pb = c_e;
+                            delb = d_e;
+                            todo = 1;
+                        } else if (ev_e == 3) {
+                            pb = c_e;
+                            delb = d_e;
+                            ph = PH_PROBE_STEP;
+                        } else {
+                            todo = 2;
+                        }
+                    }
                 }
-                // (c1, del1) and the point before it after the steps that precede the event (e = J: after all of them)
-                const int ns = e - off; // steps taken before the event
-                if (ns >= 2) {
-                    cp = c_em2;
-                    delp = d_em2;
-                    havep = true;
-                } else if (ns == 1) {
+            } else if (ph == PH_PROBE_STEP) {
+                evals += 2;
+                if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
+                    guard = true;
+                } else { // the step is an ordinary one
                     cp = c1;
                     delp = del1;
                     havep = true;
+                    c1 = pb;
+                    del1 = delb;
+                    ph = PH_SCAN;
+                    if (c1 < cm || c1 >= betmxd + dc) todo = 2;
                 }
-                if (ns >= 1) {
-                    c1 = c_em;
-                    del1 = d_em;
+            } else if (ph <= PH_REFC) {
+                evals += (unsigned)__builtin_popcountll(m_pt);
+                ++nref;
+                const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
+                if (m_pt != 0ull) {
+                    if (eA < nA) { // first trial beyond the sign change
+                        hi = cA_e;
+                        fhi = dA_e;
+                        if (eA - 1 >= r0) {
+                            lo = cA_1;
+                            flo = dA_1;
+                        }
+                    } else { // all trials on the lower end's side
+                        lo = c_r1;
+                        flo = d_r1;
+                    }
+                    if (i3 >= r0 && i3 <= r1) {
+                        p3 = c_3;
+                        fp3 = d_3;
+                        have3 = true;
+                    } else if (hi != ohi) {
+                        p3 = ohi;
+                        fp3 = ofhi;
+                        have3 = true;
+                    } else if (lo != olo) {
+                        p3 = olo;
+                        fp3 = oflo;
+                        have3 = true;
+                    }
                 }
-                if (e < J) {
-                    if (ev_e == 1) {
-                        idir = +1;
-                        c1 = clow;
-                        havep = false;
-                    } else if (ev_e == 2) {
-                        pb = c_e;
-                        delb = d_e;
-                        todo = 1;
-                    } else if (ev_e == 3) {
-                        pb = c_e;
-                        delb = d_e;
-                        ph = PH_PROBE_STEP;
+                // the estimate's round did not close in (a poor estimate: an end value that is not the function's, a kink): J-section next
+                ph = (ph == PH_REFC && hi - lo > 0.25 * wprev) ? PH_REF1 : PH_REFC;
+                wprev = hi - lo;
+                if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 16 || m_pt == 0ull) {
+                    // the root: inverse quadratic interpolation through the bracket's ends and the nearest third point (the secant
+                    // point alone is off by a good part of the bracket where the function bends), else the secant point
+                    c3 = lo - flo * (hi - lo) * fa::rcp(fhi - flo);
+                    if (have3) {
+                        const double d12 = flo - fhi, d1p = flo - fp3, d2p = fhi - fp3;
+                        const double den = d12 * d1p * d2p;
+                        const double xq = (lo * fhi * fp3 * d2p - hi * flo * fp3 * d1p + p3 * flo * fhi * d12) * fa::rcp(den);
+                        if (den != 0.0 && xq >= lo && xq <= hi) c3 = xq;
+                    }
+                    if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
+                    todo = 3;
+                }
+            } else { // PH_PROBE_ACC
+                evals += 2;
+                if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true;
+                todo = 4;
+            }
+            if (todo == 1) { // a bracket: set up its refinement (SearchT::bracketed)
+                cell_lo = fmin(c1, pb);
+                cell_hi = fmax(c1, pb);
+                flo = (c1 < pb) ? del1 : delb;
+                fhi = (c1 < pb) ? delb : del1;
+                flo_neg = sign_neg(flo);
+                if (cell_hi > betmxd && cell_lo < betmxd) guard = true; // (up to three sign changes in there: the reference's sequence)
+                lo = cell_lo;
+                hi = cell_hi;
+                p3 = cp;
+                fp3 = delp;
+                have3 = havep;
+                nref = 0;
+                wprev = hi - lo;
+                ph = have3 ? PH_REFC : PH_REF1;
+            }
+            bool probed = false;
+            if (todo == 3) { // the guard at an accepted bracket
+                const double m2 = 2.0 * dc;
+                todo = 4;
+                if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
+                    const double eps = guard_rel * fabs(c3);
+                    if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
+                        guard = true;
                     } else {
-                        todo = 2;
+                        ph = PH_PROBE_ACC;
+                        todo = 0;
+                    }
+                }
+            } else if (todo == 4) {
+                probed = true; // (the period ends a round after its cluster: nothing rode along)
+            }
+            if (guard) { // this run's results are not used (the engine runs the model again)
+                active = false;
+                todo = 0;
+            }
+            if (todo == 4) { // getsol after the refinement (:468-471), then the driver's next period (:253-272)
+                if (c3 > betmxd) {
+                    todo = 2;
+                } else {
+                    ck = c3;
+                    if (writer) vel[k] = (double)(float)ck;
+                    k = k + 1;
+                    if (k >= K) {
+                        active = false;
+                    } else {
+                        omega = omg[k];
+                        iom = fa::rcp(omega);
+                        ifirst = 0;
+                        c1 = ck - onea * dc;
+                        clow = cm;
+                        ph = PH_START;
+                        if (!useB && !probed && spec && fabs(c3 - xspec) <= 2.5e-7 * fabs(c3)) {
+                            c1 = xspec - onea * dc; // (the grid the upper lanes evaluated)
+                            again = true;
+                        }
                     }
                 }
             }
-        } else if (ph == PH_PROBE_STEP) {
-            evals += 2;
-            if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
-                guard = true;
-            } else { // the step is an ordinary one
-                cp = c1;
-                delp = del1;
-                havep = true;
-                c1 = pb;
-                del1 = delb;
-                ph = PH_SCAN;
-                if (c1 < cm || c1 >= betmxd + dc) todo = 2;
+            if (todo == 2) { // no root at period k: err, zeros from there on (:313-354)
+                errflag = 1;
+                if (writer)
+                    for (int i = k; i < K; ++i) vel[i] = 0.0;
+                active = false;
             }
-        } else if (ph <= PH_REFC) {
-            evals += (unsigned)__builtin_popcountll(m_pt);
-            ++nref;
-            const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
-            if (m_pt != 0ull) {
-                if (e < J) { // first trial beyond the sign change
-                    hi = c_e;
-                    fhi = d_e;
-                    if (e - 1 >= r0) {
-                        lo = c_em;
-                        flo = d_em;
-                    }
-                } else { // all trials on the lower end's side
-                    lo = c_r1;
-                    flo = d_r1;
-                }
-                if (i3 >= r0 && i3 <= r1) {
-                    p3 = c_3;
-                    fp3 = d_3;
-                    have3 = true;
-                } else if (hi != ohi) {
-                    p3 = ohi;
-                    fp3 = ofhi;
-                    have3 = true;
-                } else if (lo != olo) {
-                    p3 = olo;
-                    fp3 = oflo;
-                    have3 = true;
-                }
-            }
-            // the estimate's round did not close in (a poor estimate: an end value that is not the function's, a kink): J-section next
-            ph = (ph == PH_REFC && hi - lo > 0.25 * wprev) ? PH_REF1 : PH_REFC;
-            wprev = hi - lo;
-            if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 16 || m_pt == 0ull) {
-                // the root: inverse quadratic interpolation through the bracket's ends and the nearest third point (the secant
-                // point alone is off by a good part of the bracket where the function bends), else the secant point
-                c3 = lo - flo * (hi - lo) * fa::rcp(fhi - flo);
-                if (have3) {
-                    const double d12 = flo - fhi, d1p = flo - fp3, d2p = fhi - fp3;
-                    const double den = d12 * d1p * d2p;
-                    const double xq = (lo * fhi * fp3 * d2p - hi * flo * fp3 * d1p + p3 * flo * fhi * d12) * fa::rcp(den);
-                    if (den != 0.0 && xq >= lo && xq <= hi) c3 = xq;
-                }
-                if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
-                todo = 3;
-            }
-        } else { // PH_PROBE_ACC
-            evals += 2;
-            if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true;
-            todo = 4;
-        }
-        if (todo == 1) { // a bracket: set up its refinement (SearchT::bracketed)
-            cell_lo = fmin(c1, pb);
-            cell_hi = fmax(c1, pb);
-            flo = (c1 < pb) ? del1 : delb;
-            fhi = (c1 < pb) ? delb : del1;
-            flo_neg = sign_neg(flo);
-            if (cell_hi > betmxd && cell_lo < betmxd) guard = true; // (up to three sign changes in there: the reference's sequence)
-            lo = cell_lo;
-            hi = cell_hi;
-            p3 = cp;
-            fp3 = delp;
-            have3 = havep;
-            nref = 0;
-            wprev = hi - lo;
-            ph = have3 ? PH_REFC : PH_REF1;
-        }
-        if (todo == 3) { // the guard at an accepted bracket
-            const double m2 = 2.0 * dc;
-            todo = 4;
-            if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
-                const double eps = guard_rel * fabs(c3);
-                if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
-                    guard = true;
-                } else {
-                    ph = PH_PROBE_ACC;
-                    todo = 0;
-                }
-            }
-        }
-        if (guard) { // this run's results are not used (the engine runs the model again)
-            active = false;
-            continue;
-        }
-        if (todo == 4) { // getsol after the refinement (:468-471), then the driver's next period (:253-272)
-            if (c3 > betmxd) {
-                todo = 2;
-            } else {
-                ck = c3;
-                if (writer) vel[k] = (double)(float)ck;
-                k = k + 1;
-                if (k >= K) {
-                    active = false;
-                } else {
-                    omega = omg[k];
-                    iom = fa::rcp(omega);
-                    ifirst = 0;
-                    c1 = ck - onea * dc;
-                    clow = cm;
-                    ph = PH_START;
-                }
-            }
-        }
-        if (todo == 2) { // no root at period k: err, zeros from there on (:313-354)
-            errflag = 1;
-            if (writer)
-                for (int i = k; i < K; ++i) vel[i] = 0.0;
-            active = false;
-        }
+            ++pass;
+        } while (again);
     }
     if (writer) {
         T.err[ib] = errflag;
