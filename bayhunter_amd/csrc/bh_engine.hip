@@ -359,7 +359,7 @@ int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t *
             int32_t cum[BH_MAX_TARGETS];
             HIPCHK(e, hipStreamSynchronize(st));
             HIPCHK(e, hipMemcpy(cum, (int32_t *)e->guard.p + 2 * BH_MAX_TARGETS, sizeof(cum), hipMemcpyDeviceToHost));
-            for (int t = 0; t < BH_MAX_TARGETS; ++t) e->guard_total[t] += (uint64_t)cum[t];
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) e->guard_total[t] += (uint64_t)(uint32_t)cum[t]; // (the device word wraps as unsigned)
         }
         e->guard_fresh = true;
     }
@@ -636,79 +636,55 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     // sequence (BH_SEARCH_FAST_RAYLEIGH with Love targets in the call) the launch takes the build with both sequences and the
     // targets say which is theirs (two launches side by side were measured: the Rayleigh / Love pairs on the SIMDs are lost,
     // c4 1.37 -> 1.58 ms per window).
-    SwdMultiArgs part[2];
-    int nparts = 0;
     {
         int nfast = 0;
         for (int t = 0; t < a.ntargets; ++t) nfast += takes_fast(a.t[t]) ? 1 : 0;
         for (int t = 0; t < a.ntargets; ++t) a.t[t].refseq = (nfast > 0 && a.t[t].igr == 0 && !takes_fast(a.t[t])) ? 1 : 0;
         a.fast = nfast > 0 ? 1 : 0;
         a.restart = 1; // (takes effect in launches of one model per wavefront: see bh_launch_swd_group)
-        part[nparts++] = a;
     }
-    const bool side_by_side = nparts == 2 && e->aux2 != nullptr;
     int32_t *gcounts = nullptr, *glists = nullptr;
-    e->guard_last = part[0].fast != 0;
-    if (part[0].fast) {
+    e->guard_last = a.fast != 0;
+    if (a.fast) {
         if ((rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
-        for (int t = 0; t < part[0].ntargets; ++t)
-            if (part[0].t[t].igr == 0) {
-                part[0].t[t].gcount = gcounts + t;
-                part[0].t[t].glist = glists + (size_t)t * (size_t)(B + 4);
+        for (int t = 0; t < a.ntargets; ++t)
+            if (a.t[t].igr == 0) {
+                a.t[t].gcount = gcounts + t;
+                a.t[t].glist = glists + (size_t)t * (size_t)(B + 4);
             }
     }
     ev_begin(e, 0, st);
-    if (side_by_side) {
-        HIPCHK(e, hipEventRecord(e->ev_fork2, st));
-        HIPCHK(e, hipStreamWaitEvent(e->aux2, e->ev_fork2, 0));
+    int lrc;
+    if (lean) {
+        const BhTuning &tun = bh_tuning();
+        for (int t = 0; t < a.ntargets; ++t) {
+            int Jt = lean_trials;
+            if (a.t[t].iwave == BH_WAVE_RAYLEIGH && tun.swd_lean_r >= 4) Jt = tun.swd_lean_r;
+            if (a.t[t].iwave == BH_WAVE_LOVE && tun.swd_lean_l >= 4) Jt = tun.swd_lean_l;
+            a.t[t].look = Jt;
+        }
+        lrc = bh_launch_swd_lean(a, st, &e->last_swd);
+        e->last_swd_kernel = BH_KERNEL_LEAN;
+    } else {
+        e->last_swd_kernel = BH_KERNEL_GROUP;
+        lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
     }
-    unsigned started_by = 0;
-    for (int p = 0; p < nparts; ++p) {
-        SwdMultiArgs &ap = part[p];
-        if (p > 0) {
-            ap.stamp = (++e->swd_stamp) & 0xffffu;
-            if (ap.stamp == 0) ap.stamp = (++e->swd_stamp) & 0xffffu;
-        }
-        hipStream_t sp = (p == 1 && side_by_side) ? e->aux2 : st;
-        const bool pair_ok = use_pair && nparts == 1;
-        int lrc;
-        if (lean) {
-            const BhTuning &tun = bh_tuning();
-            for (int t = 0; t < ap.ntargets; ++t) {
-                int Jt = lean_trials;
-                if (ap.t[t].iwave == BH_WAVE_RAYLEIGH && tun.swd_lean_r >= 4) Jt = tun.swd_lean_r;
-                if (ap.t[t].iwave == BH_WAVE_LOVE && tun.swd_lean_l >= 4) Jt = tun.swd_lean_l;
-                ap.t[t].look = Jt;
-            }
-            lrc = bh_launch_swd_lean(ap, sp, &e->last_swd);
-            e->last_swd_kernel = BH_KERNEL_LEAN;
-        } else {
-            e->last_swd_kernel = BH_KERNEL_GROUP;
-            lrc = bh_launch_swd_group(ap, G, sp, &e->last_swd, e->swd_wpb_now, pair_ok ? &e->pairwork : nullptr);
-        }
-        e->last_swd_wpb = e->swd_wpb_now;
-        if (lrc != 0) {
-            ev_end(e, 0, st);
-            return fail(e, BH_EINVAL, "model too deep for LDS");
-        }
-        // (the counter a second stream waits on moves only once the launch is known to have been accepted: a failed launch
-        // never increments the device word, and every later wait for the advanced value would hang -- ADVICE r03)
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-            ev_end(e, 0, st);
-            return fail(e, BH_EHIP, "dispersion kernel launch", le);
-        }
-        started_by += e->last_swd.workgroups;
+    e->last_swd_wpb = e->swd_wpb_now;
+    if (lrc != 0) {
+        ev_end(e, 0, st);
+        return fail(e, BH_EINVAL, "model too deep for LDS");
     }
-    if (e->started) e->started_expected += started_by;
-    e->last_swd.workgroups = started_by;
-    if (part[0].fast && !e->last_swd.restarts_in_place && (rc = launch_swd_rerun(e, st, part[0], gcounts, glists))) {
+    // (the counter a second stream waits on moves only once the launch is known to have been accepted: a failed launch
+    // never increments the device word, and every later wait for the advanced value would hang -- ADVICE r03)
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        ev_end(e, 0, st);
+        return fail(e, BH_EHIP, "dispersion kernel launch", le);
+    }
+    if (e->started) e->started_expected += e->last_swd.workgroups;
+    if (a.fast && !e->last_swd.restarts_in_place && (rc = launch_swd_rerun(e, st, a, gcounts, glists))) {
         ev_end(e, 0, st);
         return rc;
-    }
-    if (side_by_side) {
-        HIPCHK(e, hipEventRecord(e->ev_join2, e->aux2));
-        HIPCHK(e, hipStreamWaitEvent(st, e->ev_join2, 0));
     }
     ev_end(e, 0, st);
     return BH_OK;
@@ -940,13 +916,13 @@ int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launche
     if (counts || total) {
         int32_t w[3 * BH_MAX_TARGETS] = {0};
         if (e->guard.p && !e->guard_fresh) {
-            HIPCHK(e, hipStreamSynchronize(e->stream));
+            HIPCHK(e, hipDeviceSynchronize()); // (the last call may have run on a caller's stream)
             HIPCHK(e, hipMemcpy(w, e->guard.p, sizeof(w), hipMemcpyDeviceToHost));
         }
         if (counts)
             for (int t = 0; t < BH_MAX_TARGETS; ++t) counts[t] = e->guard_last ? w[t] + w[BH_MAX_TARGETS + t] : 0;
         if (total)
-            for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)w[2 * BH_MAX_TARGETS + t];
+            for (int t = 0; t < BH_MAX_TARGETS; ++t) total[t] = e->guard_total[t] + (uint64_t)(uint32_t)w[2 * BH_MAX_TARGETS + t];
     }
     return BH_OK;
 }

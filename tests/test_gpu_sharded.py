@@ -111,3 +111,24 @@ def test_rccl_code_path_world_size_1():
         assert dc.samples("p2", cold_only=True)["models"].shape[1] == C // 2
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_of_a_two_rank_tempered_job_parses():
+    """`bench.py --gpus 2 --workload c5` as the driver launches it (torch.distributed.run, two ranks), in its
+    dry-run form (BH_BENCH_DRYRUN=1: both ranks on GPU 0 over gloo -- the boxes of the build have one GPU): rank 0 prints ONE
+    parseable line under the size limit, the ladder laid across the ranks exchanges temperatures."""
+    import json
+    repo = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BH_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--workload", "c5", "--steps", "300",
+           "--warmup", "100", "--out", os.path.join(repo, "gpurun_out", "bench_full_dryrun.json")]
+    os.makedirs(os.path.join(repo, "gpurun_out"), exist_ok=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8000
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "chain-iterations/s" and "DRY RUN" in d["data"]
+    assert d["config"]["accepted_swaps"] > 0
+    assert d["collective_check"]["world_size"] == 2 and d["collective_check"]["ranks_seen_by_all_reduce"] == 2
