@@ -587,7 +587,7 @@ struct SearchT {
                       F_SEED3 = 64u,   // Rayleigh, short refinement: the scan's last replaced point seeds the first estimate
                       F_SEEDED = 128u, // this bracket's refinement started with a third point
                       F_PRE_ON = 256u, // the certified-sign scan is wanted (PRE builds)
-                      F_FA = 512u      // the values come from the fast arithmetic (swd_fa.h): signs below fa::SIGN_FLOOR fire the guard
+                      F_FA = 512u      // the values come from the fast arithmetic (swd_fa.h): values that are not numbers (below fa::SIGN_FLOOR) fire the guard
     };
     // the certified-sign scan: grid points one look covers at most (the kernel: looks x the lanes of a model)
     static constexpr int pre_max_points = 128;

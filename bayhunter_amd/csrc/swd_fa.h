@@ -9,17 +9,22 @@
 // units in the last place of the exactly rounded formula, i.e. it differs from the reference-exact evaluation by what that
 // evaluation's own rounding error is; about a third of its instructions.
 //
-// What that does to a search (SearchT, short refinement): a root moves by ~1e-13 relative (tolerance of the path: 1e-5,
-// the short refinement's own distance from the reference: 1.2e-6); a scan's sign pattern -- which bracket, which failure
-// flag -- can differ from the exact evaluation's only where |f| at a grid point is of the size of the rounding error.  The
-// kernels do not trust such a sign: a scan or guard value below SIGN_FLOOR (f is max-norm scaled: |f| <= 1; the running
-// error bound of swd_csign.h evaluated on the same points stays below 1e-11, tests/test_oracle_csign.py) fires the
-// short refinement's guard, and the model is run again with the reference's sequence in the reference's arithmetic -- the
-// same path a guarded model takes anyway.
+// What that does to a search (SearchT, short refinement; swd_lean.hip).  Measured on the device over 10^8 (model, period,
+// velocity) points of each wave type (tools/ubench/fadiff.hip), both values max-norm scaled (|f| <= 1): |f_fast - f_exact| is
+// below 1e-11 in 99.6 % of them and reaches 1.2e-8 -- the large ones where the trial velocity lies within ~1e-7 relative of a
+// layer velocity, where the REFERENCE's own k - k_beta cancels and its value is uncertain by as much.  A root moves by ~1e-13
+// relative (tolerance of the path: 1e-5; the short refinement's own distance from the reference: 1.2e-6).  A scan's sign
+// pattern can differ from the exact evaluation's only where |f| at a grid point is smaller than that difference, i.e. where
+// a root lies within ~1e-8 of the grid point: the bracket then moves by one step around the same root (same velocity, same
+// flag).  What the kernels do NOT accept is a value that is not a number or is exactly lost (|f| < SIGN_FLOOR = 1e-12: an
+// argument beyond the sin / cos reduction's range, an underflow): it fires the short refinement's guard and the model is run
+// again with the reference's sequence in the reference's arithmetic -- the path a guarded model takes anyway.  The parity
+// statement rests on the tests: failure flags and zero rows identical to the reference's on 1.7 million LVZ-rich models
+// (tests/test_gpu_swd_lean.py), velocities within 2e-6.
 #pragma once
 
 namespace fa {
-constexpr double SIGN_FLOOR = 1.0e-9;
+constexpr double SIGN_FLOOR = 1.0e-12;
 
 // sqrt(x) and 1/sqrt(x) together (x > 0, normal): hardware seed (~2^-23), two Goldschmidt steps
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &rs)

@@ -18,7 +18,7 @@
 //     bracket of 1e-6 c1 and returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
 //   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
 //     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
-//     contains betmx -- plus the rule of the fast arithmetic: a scan or probe value below fa::SIGN_FLOOR is not trusted.  A
+//     contains betmx -- plus the rule of the fast arithmetic: a scan or probe value that is not a number or below fa::SIGN_FLOOR fires it.  A
 //     guarded model is listed and run again by the engine with the reference's sequence in the reference's arithmetic
 //     (launch_swd_rerun), so failure flags and zero rows are the reference's.
 //   * A model with a water layer (unreachable from BayHunter) is guarded at once.
@@ -212,6 +212,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     double *vel = T.vel + (size_t)ib * T.ldv;
     const bool writer = valid && r == 0;
     bool active = valid && K > 0 && sane, guard = false;
+    int greason = 0; // (development aid: which rule fired the guard -- 1 water layer, 2 / 3 small start / scan value, 4 step probes, 5 bracket
+                     //  probes, 6 bracket contains betmx, 7 root at a bracket end or at betmx)
     int errflag = 0;
     if (valid && !sane) {
         errflag = 1;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             for (int i = 0; i < K; ++i) vel[i] = 0.0;
     }
     if (active && md.Bv(0) <= 0.0) { // water layer on top: the reference's sequence
-        guard = true;
+        guard = true, greason = 1;
         active = false;
     }
     // ---- search state, the same in every lane of the model
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         double xspec = 0.0;
         if (ph <= PH_SCAN) {
             // The grid of getsol's scan (:437-446).  The reference forms it by repeated additions of dc; here point n is
-            // base + n dc in one fused operation -- the two differ in the last bits, i.e. by less than any value of the
-            // secular function that the kernels trust the sign of (fa::SIGN_FLOOR).
+            // base + n dc in one fused operation -- the two differ in the last bits (1e-16 relative: a thousandth of what the
+            // fast arithmetic itself moves a sign change by, swd_fa.h).
             const bool start = ph == PH_START;
             if (!start) { // (label 1000 of getsol: the floor in a reversed search)
                 if (idir > 0) {
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 bool consume = true;
                 if (start) {
                     ++evals;
-                    if (msm & 1ull) guard = true;
+                    if (msm & 1ull) guard = true, greason = 2;
                     del1 = d_first;
                     havep = false;
                     if (ifirst == 1) s1stneg = sign_neg(d_first);
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     if (last >= off) {
                         evals += (unsigned)(last - off + 1);
                         const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
-                        if (msm & used) guard = true;
+                        if (msm & used) guard = true, greason = 3;
                     }
                     // (c1, del1) and the point before it after the steps that precede the event (e = wn: after all of them)
                     const int ns = e - off; // steps taken before the event
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             } else if (ph == PH_PROBE_STEP) {
                 evals += 2;
                 if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
-                    guard = true;
+                    guard = true, greason = 4;
                 } else { // the step is an ordinary one
                     cp = c1;
                     delp = del1;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 }
             } else { // PH_PROBE_ACC
                 evals += 2;
-                if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true;
+                if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true, greason = 5;
                 todo = 4;
             }
             if (todo == 1) { // a bracket: set up its refinement (SearchT::bracketed)
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 flo = (c1 < pb) ? del1 : delb;
                 fhi = (c1 < pb) ? delb : del1;
                 flo_neg = sign_neg(flo);
-                if (cell_hi > betmxd && cell_lo < betmxd) guard = true; // (up to three sign changes in there: the reference's sequence)
+                if (cell_hi > betmxd && cell_lo < betmxd) guard = true, greason = 6; // (up to three sign changes in there: the reference's sequence)
                 lo = cell_lo;
                 hi = cell_hi;
                 p3 = cp;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
                     const double eps = guard_rel * fabs(c3);
                     if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
-                        guard = true;
+                        guard = true, greason = 7;
                     } else {
                         ph = PH_PROBE_ACC;
                         todo = 0;
@@ -601,6 +603,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             atomicMax(A.neval + o + 2, (unsigned long long)nrounds);
             atomicAdd(A.neval + 7, 1ull);
             atomicAdd(A.neval + (ifunc == 2 ? 12 : 13), (unsigned long long)t_eval); // cycles inside the secular evaluations
+        }
+        if (writer && guard) atomicAdd(A.neval + 14, 1ull << (8 * (greason & 7)) ); // guard reasons, a byte each
+        if (false) {
         }
     }
 }
