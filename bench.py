@@ -338,7 +338,8 @@ def run_chains(args, eng, rank, world, dist, dev, workload, steps, warmup):
             "value": world * C * timed_iters / elapsed, "unit": "chain-iterations/s", "n_gpus": world, "steps": steps,
             "timed_iterations_per_chain": int(timed_iters),
             "warmup": warmup, "ms_per_step": elapsed / max(1, timed_iters) * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if os.environ.get("BH_BENCH_DRYRUN", "0") != "1" else "synthetic (DRY RUN: all ranks on one GPU, gloo)",
             "config": {"workload": {"c4": "BASELINE configs[3]: independent chains sharded per GPU, joint Rayleigh+Love+P-RF, up to 20 layers",
                                     "c5": "BASELINE configs[4]: parallel tempering, one temperature of an 8-rung ladder per rank, exchange "
                                           "every 100 iterations, joint Rayleigh+Love+P-RF, up to 20 layers",
