@@ -117,6 +117,20 @@ def test_failure_flags_and_zero_rows_are_the_references_on_millions_of_models(le
         assert nguard > 0      # (the sets do contain the situations the guard is there for)
 
 
+@pytest.mark.parametrize("ref", sorted(REFS))
+def test_calls_beyond_the_kernels_range_take_the_fast_arithmetic_elsewhere(lean, oracle, ref):
+    """More than 65536 (model, target) pairs in a call: one lane per evaluation (swd_kernel's builds with the fast arithmetic) --
+    the same guarantees."""
+    rs = np.random.RandomState(4711)
+    nlay, h, vp, vs, rho = synth_models(rs, 70000, 10, lvz_frac=0.25, ragged=True)
+    per = np.linspace(2, 60, 30)
+    iwave, igr = REFS[ref]
+    v, e = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+    assert lean.last_swd_kernel() == "lane"
+    ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
+    check_against_the_reference(v, e, ov, oe)
+
+
 def test_reference_golden_vectors_within_tolerance(lean):
     g = golden("swd_golden.npz")
     nlay = g["nlay"]
