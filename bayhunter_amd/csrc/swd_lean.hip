@@ -122,7 +122,8 @@ __device__ __forceinline__ void lean_wave_sync()
 
 constexpr int LEAN_WPB = 4; // wavefronts per workgroup: independent (no barrier), one per SIMD of the CU the workgroup lands on
 
-__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
+template <int J> // trials per model and round: 4, 8, 16, 32 or 64 lanes = one model
+__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) __attribute__((amdgpu_num_vgpr(208))) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
     if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
@@ -139,10 +140,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         wid = (l1 > l0) ? l0 : wid - l0;
     }
     const SwdTarget T = A.t[ty];
-    const int J = T.look;          // trials per model and round: a power of two, 4 ... 64
-    const int MPW = BH_WAVE / J;   // models per wavefront
+    constexpr int MPW = BH_WAVE / J; // models per wavefront
     if (wid * MPW >= A.B) return;
-    const int g = lane / J, r = lane - g * J, lbase = g * J;
+    const int g = lane / J, r = lane & (J - 1), lbase = lane & ~(J - 1);
     const int sidx = wid * MPW + g;
     const bool valid = sidx < A.B;
     const int32_t *perm = T.perm != nullptr ? T.perm : A.perm;
@@ -239,16 +239,17 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         omega = omg[0];
         iom = fa::rcp(omega);
     }
-    const unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
+    constexpr unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
     // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG (J >= 16).  The estimate x that a round of clustered trials is centred on is, 99 times
     // in 100, within 2e-7 |x| of the root it then finds.  So only the lower half of the model's lanes carry the cluster; the upper
     // half evaluates -- at the NEXT period's frequency -- the first round of the next period's scan on the grid anchored at
     // x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x, those values ARE the next period's first
     // round (its grid is anchored 2.5e-7 relative off the root: the reference's own root is known to 1e-6, and the guard covers
     // grids that differ by 3e-6); otherwise they are dropped.  Two rounds per period instead of three.
-    const int H = J / 2;
-    const bool can_spec = J >= 16;
-    const unsigned long long maskH = (1ull << H) - 1ull;
+    constexpr int H = J / 2;
+    constexpr bool can_spec = J >= 16;
+    constexpr unsigned long long maskH = (1ull << H) - 1ull;
+    const double invJ1 = 1.0 / (double)(J + 1);
     unsigned nrounds = 0;
     long long t_eval = 0;
     const long long t_start = (A.neval != nullptr) ? clock64() : 0;
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         double om_l = omega, iom_l = iom;
         bool pt = false;             // this lane's value takes part in the refinement's decision
         bool spec = false;           // the upper half of this model's lanes carries the next period's first round
-        double xspec = 0.0;
+        double xc = 0.0;             // centre of the cluster
+        const int ph0 = ph;          // the phase this round's trials were laid out for
         if (ph <= PH_SCAN) {
             // The grid of getsol's scan (:437-446).  The reference forms it by repeated additions of dc; here point n is
             // base + n dc in one fused operation -- the two differ in the last bits (1e-16 relative: a thousandth of what the
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             cprev = __builtin_fma((double)(n - 1), step, base);
             cev = (n == 0) ? c1 : __builtin_fma((double)n, step, base);
         } else if (ph == PH_REF1) {
-            cev = __builtin_fma(hi - lo, (double)(r + 1) * fa::rcp((double)(J + 1)), lo);
+            cev = __builtin_fma(hi - lo, (double)(r + 1) * invJ1, lo);
             pt = cev > lo && cev < hi;
         } else if (ph == PH_REFC) {
             double x = 0.0;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 if (!(x > lo && x < hi)) x = 0.5 * (lo + hi);
             }
             spec = can_spec && k + 1 < K;
-            xspec = x;
+            xc = x;
             const int nc = spec ? H : J; // lanes of the cluster
             if (r < nc) {
                 const int h = nc / 2;
@@ -327,12 +329,13 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const double del = (ifunc == 2) ? lean_rayleigh(wvno, om_l, iom_l, md, mmax, mtop) : lean_love(wvno, om_l, md, mmax, mtop);
         if (A.neval != nullptr) t_eval += clock64() - te0;
 
-        // ---- the round's decision: one event code per lane, ballots, the values at the events (every exchange outside the
-        // per-model branches).  Window A = the lanes of this round's own business (all J, or the cluster's H); window B = the
-        // upper H lanes where they carry the next period's first round.
+        // ---- the round's decision.  Signs and "not a number" travel as ballots; one event code per lane and a ballot give the
+        // first event of a window of lanes; the VALUES at the events are fetched by two small sets of exchanges (all outside the
+        // per-model branches); the velocities there are recomputed from the lane index.
         const bool dneg = sign_neg(del);
-        const bool small = !(fabs(del) >= fa::SIGN_FLOOR);
-        const double d_0 = __shfl(del, lbase), d_1 = __shfl(del, lbase + 1), d_H = __shfl(del, lbase + H);
+        const unsigned long long mneg = (__ballot(dneg) >> lbase) & maskJ;
+        const unsigned long long m_small = (__ballot(!(fabs(del) >= fa::SIGN_FLOOR)) >> lbase) & maskJ;
+        const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
         const bool inB = ph == PH_REFC && spec && r >= H;
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
         if (ph <= PH_SCAN || inB) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             if (!(first && rr == 0)) {
                 const bool down = !first && idir < 0;
                 const double a_ = fmin(cprev, cev), b_ = fmax(cprev, cev);
-                const bool refneg = inB ? sign_neg(d_H) : (first ? sign_neg(d_0) : sign_neg(del1));
+                const bool refneg = inB ? ((mneg >> H) & 1ull) != 0ull : (first ? (mneg & 1ull) != 0ull : sign_neg(del1));
                 const double floor_ = inB ? cm : clow;
                 if (down && cev <= floor_) ev = 1;
                 else if (dneg != refneg) ev = 2;
@@ -352,104 +355,27 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             ev = (pt && dneg != sign_neg(flo)) ? 2 : 0;
         }
         const unsigned long long m_ev = (__ballot(ev != 0) >> lbase) & maskJ;
-        const unsigned long long m_small = (__ballot(small) >> lbase) & maskJ;
-        const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
+        // stage 1: the refinement's window A = all J lanes, or the cluster's H
         const int nA = (ph == PH_REFC && spec) ? H : J;
-        const unsigned long long m_evA = m_ev & ((ph == PH_REFC && spec) ? maskH : maskJ), m_evB = (m_ev >> H) & maskH;
-        const int eA = m_evA ? (int)__builtin_ctzll(m_evA) : nA; // first event among window A's trials (nA: none)
-        const int eB = m_evB ? (int)__builtin_ctzll(m_evB) : H;
-        const int iA = lbase + (eA < nA ? eA : nA - 1), iA1 = lbase + (eA > 0 ? eA - 1 : 0), iA2 = lbase + (eA > 1 ? eA - 2 : 0);
-        const int iB = lbase + H + (eB < H ? eB : H - 1), iB1 = lbase + H + (eB > 0 ? eB - 1 : 0), iB2 = lbase + H + (eB > 1 ? eB - 2 : 0);
-        const int evA_e = __shfl(ev, iA), evB_e = __shfl(ev, iB);
-        const double cA_e = __shfl(cev, iA), dA_e = __shfl(del, iA), cA_1 = __shfl(cev, iA1), dA_1 = __shfl(del, iA1),
-                     cA_2 = __shfl(cev, iA2), dA_2 = __shfl(del, iA2);
-        const double cB_e = __shfl(cev, iB), dB_e = __shfl(del, iB), cB_1 = __shfl(cev, iB1), dB_1 = __shfl(del, iB1),
-                     cB_2 = __shfl(cev, iB2), dB_2 = __shfl(del, iB2);
-        // refinement rounds: the trials that take part form one run of lanes [r0, r1]
-        const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1;
+        const unsigned long long m_evA = (ph == PH_REFC && spec) ? (m_ev & maskH) : m_ev;
+        const int eA = m_evA ? (int)__builtin_ctzll(m_evA) : nA; // first trial beyond the sign change (nA: none)
+        const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1; // the trials that take part: one run of lanes
         const int i3 = (eA < nA) ? ((eA + 1 <= r1) ? eA + 1 : eA - 2) : r1 - 1; // a third point next to the new bracket
-        const double c_3 = __shfl(cev, lbase + (i3 >= 0 && i3 < J ? i3 : 0)), d_3 = __shfl(del, lbase + (i3 >= 0 && i3 < J ? i3 : 0));
-        const double c_r1 = __shfl(cev, lbase + (r1 >= 0 ? r1 : 0)), d_r1 = __shfl(del, lbase + (r1 >= 0 ? r1 : 0));
-        if (!active) continue;
+        const double dA_e = __shfl(del, lbase + (eA < nA ? eA : nA - 1)), dA_1 = __shfl(del, lbase + (eA > 0 ? eA - 1 : 0));
+        const double d_3 = __shfl(del, lbase + (i3 >= 0 && i3 < J ? i3 : 0)), d_r1 = __shfl(del, lbase + (r1 >= 0 ? r1 : 0));
 
-        // Pass 0: this round's own business.  Pass 1 (only after pass 0 has finished a period whose cluster round carried the next
-        // period's first round, and the root came out where the estimate was): that first round.
-        bool again = false;
-        int pass = 0;
-        do {
-            const bool useB = pass == 1;
-            again = false;
-            int todo = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed; 3 root c3 accepted; 4 period done with c3
-            if (useB || ph <= PH_SCAN) {
-                const bool start = useB || ph == PH_START;
-                const int wn = useB ? H : J, e = useB ? eB : eA, ev_e = useB ? evB_e : evA_e;
-                const unsigned long long msm = useB ? (m_small >> H) & maskH : m_small;
-                const double c_e = useB ? cB_e : cA_e, d_e = useB ? dB_e : dA_e, c_em = useB ? cB_1 : cA_1, d_em = useB ? dB_1 : dA_1,
-                             c_em2 = useB ? cB_2 : cA_2, d_em2 = useB ? dB_2 : dA_2, d_first = useB ? d_H : d_0;
-                int off = 0;
-                bool consume = true;
-                if (start) {
-                    ++evals;
-                    if (msm & 1ull) guard = true, greason = 2;
-                    del1 = d_first;
-                    havep = false;
-                    if (ifirst == 1) s1stneg = sign_neg(d_first);
-                    idir = (ifirst != 1 && s1stneg != sign_neg(d_first)) ? -1 : +1;
-                    off = 1;
-                    if (idir > 0) {
-                        if (c1 + dc <= clow) {
-                            c1 = clow;
-                            havep = false;
-                        }
-                    } else {
-                        consume = false; // reversed search: the upward steps are not the scan's
-                    }
-                    ph = PH_SCAN;
-                }
-                if (consume) {
-                    // trials off .. e are consumed (a floor event: off .. e - 1)
-                    const int last = (e < wn) ? ((ev_e == 1) ? e - 1 : e) : wn - 1;
-                    if (last >= off) {
-                        evals += (unsigned)(last - off + 1);
-                        const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
-                        if (msm & used) guard = true, greason = 3;
-                    }
-                    // (c1, del1) and the point before it after the steps that precede the event (e = wn: after all of them)
-                    const int ns = e - off; // steps taken before the event
-                    if (ns >= 2) {
-                        cp = c_em2;
-                        delp = d_em2;
-                        havep = true;
-                    } else if (ns == 1) {
-                        cp = c1;
-                        delp = del1;
-                        havep = true;
-                    }
-                    if (ns >= 1) {
-                        c1 = c_em;
-                        del1 = d_em;
-                    }
-                    if (e < wn) {
-                        if (ev_e == 1) {
-                            idir = +1;
-                            c1 = clow;
-                            havep = false;
-                        } else if (ev_e == 2) {
-                            pb = c_e;
-                            delb = d_e;
-                            todo = 1;
-                        } else if (ev_e == 3) {
-                            pb = c_e;
-                            delb = d_e;
-                            ph = PH_PROBE_STEP;
-                        } else {
-                            todo = 2;
-                        }
-                    }
-                }
-            } else if (ph == PH_PROBE_STEP) {
+        int todo = 0;          // 2 root search failed; 3 root c3 accepted; 4 period done with c3
+        bool scan_now = false; // stage 2 consumes a scan window for this model
+        int w0 = 0;            // its first lane
+        bool sc_first = false; // it is a period's first round
+        if (active) {
+            scan_now = ph <= PH_SCAN;
+            sc_first = ph == PH_START;
+            bool probed = false;
+            if (ph == PH_PROBE_STEP) {
                 evals += 2;
-                if ((m_small & 3ull) || sign_neg(d_0) != sign_neg(del1) || sign_neg(d_1) != sign_neg(del1)) {
+                const bool n1 = sign_neg(del1);
+                if ((m_small & 3ull) || ((mneg & 1ull) != 0ull) != n1 || ((mneg & 2ull) != 0ull) != n1) {
                     guard = true, greason = 4;
                 } else { // the step is an ordinary one
                     cp = c1;
@@ -460,24 +386,32 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     ph = PH_SCAN;
                     if (c1 < cm || c1 >= betmxd + dc) todo = 2;
                 }
-            } else if (ph <= PH_REFC) {
+            } else if (ph == PH_REF1 || ph == PH_REFC) {
+                // the velocity of trial i of this round's window A
+                const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
+                const int nc = nA, h = nc / 2;
+                const double w = 1.0e-7 * fabs(xc);
+                const bool sect = ph == PH_REF1;
+                auto ctrial = [&](int i) -> double {
+                    return sect ? __builtin_fma(ohi - olo, (double)(i + 1) * invJ1, olo)
+                                : ((i < h) ? xc - __builtin_ldexp(w, 2 * (h - 1 - i)) : xc + __builtin_ldexp(w, 2 * (i - h)));
+                };
                 evals += (unsigned)__builtin_popcountll(m_pt);
                 ++nref;
-                const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
                 if (m_pt != 0ull) {
                     if (eA < nA) { // first trial beyond the sign change
-                        hi = cA_e;
+                        hi = ctrial(eA);
                         fhi = dA_e;
                         if (eA - 1 >= r0) {
-                            lo = cA_1;
+                            lo = ctrial(eA - 1);
                             flo = dA_1;
                         }
                     } else { // all trials on the lower end's side
-                        lo = c_r1;
+                        lo = ctrial(r1);
                         flo = d_r1;
                     }
                     if (i3 >= r0 && i3 <= r1) {
-                        p3 = c_3;
+                        p3 = ctrial(i3);
                         fp3 = d_3;
                         have3 = true;
                     } else if (hi != ohi) {
@@ -506,28 +440,12 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
                     todo = 3;
                 }
-            } else { // PH_PROBE_ACC
+            } else if (ph == PH_PROBE_ACC) {
                 evals += 2;
-                if ((m_small & 3ull) || sign_neg(d_0) == flo_neg || sign_neg(d_1) != flo_neg) guard = true, greason = 5;
+                if ((m_small & 3ull) || ((mneg & 1ull) != 0ull) == flo_neg || ((mneg & 2ull) != 0ull) != flo_neg) guard = true, greason = 5;
                 todo = 4;
+                probed = true; // (the period ends a round after its cluster: nothing rode along)
             }
-            if (todo == 1) { // a bracket: set up its refinement (SearchT::bracketed)
-                cell_lo = fmin(c1, pb);
-                cell_hi = fmax(c1, pb);
-                flo = (c1 < pb) ? del1 : delb;
-                fhi = (c1 < pb) ? delb : del1;
-                flo_neg = sign_neg(flo);
-                if (cell_hi > betmxd && cell_lo < betmxd) guard = true, greason = 6; // (up to three sign changes in there: the reference's sequence)
-                lo = cell_lo;
-                hi = cell_hi;
-                p3 = cp;
-                fp3 = delp;
-                have3 = havep;
-                nref = 0;
-                wprev = hi - lo;
-                ph = have3 ? PH_REFC : PH_REF1;
-            }
-            bool probed = false;
             if (todo == 3) { // the guard at an accepted bracket
                 const double m2 = 2.0 * dc;
                 todo = 4;
@@ -540,8 +458,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         todo = 0;
                     }
                 }
-            } else if (todo == 4) {
-                probed = true; // (the period ends a round after its cluster: nothing rode along)
             }
             if (guard) { // this run's results are not used (the engine runs the model again)
                 active = false;
@@ -563,9 +479,11 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         c1 = ck - onea * dc;
                         clow = cm;
                         ph = PH_START;
-                        if (!useB && !probed && spec && fabs(c3 - xspec) <= 2.5e-7 * fabs(c3)) {
-                            c1 = xspec - onea * dc; // (the grid the upper lanes evaluated)
-                            again = true;
+                        if (!probed && spec && fabs(c3 - xc) <= 2.5e-7 * fabs(c3)) { // the upper lanes' values are this period's first round
+                            c1 = xc - onea * dc; // (the grid they evaluated)
+                            scan_now = true;
+                            sc_first = true;
+                            w0 = H;
                         }
                     }
                 }
@@ -576,8 +494,109 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     for (int i = k; i < K; ++i) vel[i] = 0.0;
                 active = false;
             }
-            ++pass;
-        } while (again);
+        }
+        // stage 2: the scan window [w0, w0 + wn) of the models that consume one this round
+        const int wn = (w0 != 0) ? H : J;
+        const unsigned long long m_evS = (w0 != 0) ? ((m_ev >> H) & maskH) : m_ev;
+        const int e = m_evS ? (int)__builtin_ctzll(m_evS) : wn; // first event among the window's trials (wn: none)
+        const int wb = lbase + w0;
+        const int ev_e = __shfl(ev, wb + (e < wn ? e : wn - 1));
+        const double d_e = __shfl(del, wb + (e < wn ? e : wn - 1)), d_em = __shfl(del, wb + (e > 0 ? e - 1 : 0)),
+                     d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb);
+        if (active && scan_now) {
+            const bool start = sc_first;
+            const unsigned long long msm = (w0 != 0) ? ((m_small >> H) & maskH) : m_small;
+            // the velocity of trial t of the window (what its lane evaluated)
+            const double base = (start && c1 + dc <= clow) ? clow : c1;
+            const double step = (start || idir > 0) ? dc : -dc;
+            const double c1s = c1;
+            auto cgrid = [&](int t) -> double { return (start && t == 0) ? c1s : __builtin_fma((double)(start ? t : t + 1), step, base); };
+            int off = 0, todo2 = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed
+            bool consume = true;
+            if (start) {
+                ++evals;
+                if (msm & 1ull) guard = true, greason = 2;
+                del1 = d_first;
+                havep = false;
+                if (ifirst == 1) s1stneg = sign_neg(d_first);
+                idir = (ifirst != 1 && s1stneg != sign_neg(d_first)) ? -1 : +1;
+                off = 1;
+                if (idir > 0) {
+                    if (c1 + dc <= clow) {
+                        c1 = clow;
+                        havep = false;
+                    }
+                } else {
+                    consume = false; // reversed search: the upward steps are not the scan's
+                }
+                ph = PH_SCAN;
+            }
+            if (consume) {
+                // trials off .. e are consumed (a floor event: off .. e - 1)
+                const int last = (e < wn) ? ((ev_e == 1) ? e - 1 : e) : wn - 1;
+                if (last >= off) {
+                    evals += (unsigned)(last - off + 1);
+                    const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
+                    if (msm & used) guard = true, greason = 3;
+                }
+                // (c1, del1) and the point before it after the steps that precede the event (e = wn: after all of them)
+                const int ns = e - off; // steps taken before the event
+                if (ns >= 2) {
+                    cp = cgrid(e - 2);
+                    delp = d_em2;
+                    havep = true;
+                } else if (ns == 1) {
+                    cp = c1;
+                    delp = del1;
+                    havep = true;
+                }
+                if (ns >= 1) {
+                    c1 = cgrid(e - 1);
+                    del1 = d_em;
+                }
+                if (e < wn) {
+                    if (ev_e == 1) {
+                        idir = +1;
+                        c1 = clow;
+                        havep = false;
+                    } else if (ev_e == 2) {
+                        pb = cgrid(e);
+                        delb = d_e;
+                        todo2 = 1;
+                    } else if (ev_e == 3) {
+                        pb = cgrid(e);
+                        delb = d_e;
+                        ph = PH_PROBE_STEP;
+                    } else {
+                        todo2 = 2;
+                    }
+                }
+            }
+            if (todo2 == 1) { // a bracket: set up its refinement (SearchT::bracketed)
+                cell_lo = fmin(c1, pb);
+                cell_hi = fmax(c1, pb);
+                flo = (c1 < pb) ? del1 : delb;
+                fhi = (c1 < pb) ? delb : del1;
+                flo_neg = sign_neg(flo);
+                if (cell_hi > betmxd && cell_lo < betmxd) guard = true, greason = 6; // (up to three sign changes in there: the reference's sequence)
+                lo = cell_lo;
+                hi = cell_hi;
+                p3 = cp;
+                fp3 = delp;
+                have3 = havep;
+                nref = 0;
+                wprev = hi - lo;
+                ph = have3 ? PH_REFC : PH_REF1;
+            }
+            if (guard) active = false;
+            if (todo2 == 2 && active) { // no root at period k: err, zeros from there on (:313-354)
+                errflag = 1;
+                if (writer)
+                    for (int i = k; i < K; ++i) vel[i] = 0.0;
+                active = false;
+            }
+        }
+        (void)ph0;
     }
     if (writer) {
         T.err[ib] = errflag;
@@ -661,6 +680,15 @@ int bh_launch_swd_lean(const SwdMultiArgs &a0, hipStream_t stream, SwdLaunchInfo
         info->fast_arith = 1;
         info->restarts_in_place = 0;
     }
-    hipLaunchKernelGGL(swd_lean_kernel, grid, block, lds, stream, a, (int)wave_lds);
+    const int J = a.t[0].look; // (one trial count per launch: the kernel is compiled per count)
+    for (int t = 1; t < a.ntargets; ++t)
+        if (a.t[t].look != J) return -1;
+    switch (J) {
+    case 4: hipLaunchKernelGGL(swd_lean_kernel<4>, grid, block, lds, stream, a, (int)wave_lds); break;
+    case 8: hipLaunchKernelGGL(swd_lean_kernel<8>, grid, block, lds, stream, a, (int)wave_lds); break;
+    case 16: hipLaunchKernelGGL(swd_lean_kernel<16>, grid, block, lds, stream, a, (int)wave_lds); break;
+    case 32: hipLaunchKernelGGL(swd_lean_kernel<32>, grid, block, lds, stream, a, (int)wave_lds); break;
+    default: hipLaunchKernelGGL(swd_lean_kernel<64>, grid, block, lds, stream, a, (int)wave_lds); break;
+    }
     return 0;
 }
