@@ -3,6 +3,8 @@
 raggedness, periods, wave/velocity types, modes, earth flattening, lane mappings, look-ahead and depth
 hints (dev tool; the fixed cases live in tests/).
     python tools/gpu_fuzz.py SEED NCONFIG          the reference sequence: bit-identical to the oracle
+    LEAN=1 python tools/gpu_fuzz.py SEED NCONFIG   the engine's defaults (short refinement + fast arithmetic: the trial-per-lane kernel
+                                                   where it applies): tolerance and failure flags against the reference sequence
     FAST=1 python tools/gpu_fuzz.py SEED NCONFIG   the short refinement with its guard (bh_engine_set_swd_search): bit-identical
                                                    to ITS CPU restatement (oracle search mode 2), and against the reference
                                                    sequence: failure flags and zero patterns (both must be the reference's),
@@ -22,8 +24,10 @@ rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device("cuda:0")
 bad = 0
-FAST = os.environ.get("FAST", "0") == "1"
+LEAN = os.environ.get("LEAN", "0") == "1"      # the engine's defaults: short refinement + fast arithmetic, the planner's own launch
+FAST = os.environ.get("FAST", "0") == "1" or LEAN
 eng.set_swd_search("fast" if FAST else "reference")
+eng.set_swd_arith("fast" if LEAN else "exact")   # (FAST = 1 alone: the reference's arithmetic, compared bit for bit with its restatement)
 if os.environ.get("SCAN", "auto") in ("steps", "counted"):     # (default: the engine's BH_SCAN_AUTO)
     eng.set_swd_scan(os.environ["SCAN"])
 nguard = 0
@@ -44,6 +48,8 @@ for it in range(ncfg):
     G = int(rs.choice([0, 0, 0, 1, 3, 5, 9, 12, 16, 21]))
     J = int(rs.choice([0, 0, 1, 2, 3, 4, 7]))
     hint = int(rs.choice([0, 0, 3, 6, 12]))
+    if LEAN:
+        G = J = 0
     eng.set_swd_group(G); eng.set_swd_lookahead(J); eng.set_typical_layers(hint)
     with O.swd_search(2 if FAST else 0):
         ov, oe, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
@@ -58,7 +64,7 @@ for it in range(ncfg):
                           mode=mode, flsph=flsph)
         torch.cuda.synchronize()
         v, e = dv.cpu().numpy(), de.cpu().numpy()
-    ok = np.array_equal(e, oe) and np.array_equal(v, ov)
+    ok = LEAN or (np.array_equal(e, oe) and np.array_equal(v, ov))   # (LEAN: no bit-level restatement; tolerance and flags below)
     if not ok:
         bad += 1
         print("MISMATCH", dict(B=B, L=L, ragged=ragged, K=K, iwave=iwave, igr=igr, mode=mode, flsph=flsph, G=G, J=J, hint=hint),

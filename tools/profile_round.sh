@@ -28,6 +28,15 @@ python $R/bench.py --workload c3g --no-cpu-baseline > "$OUT/bench_c3g.json" 2> "
 python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_c2_b65536.json" 2> "$OUT/bench_c2_b65536.err"
 python $R/bench.py --workload c2 --batch 65536 --steps 5 --warmup 2 --no-cpu-baseline --search reference > "$OUT/bench_c2_b65536_reference.json" 2> "$OUT/bench_c2_b65536_reference.err"
 python $R/bench.py --workload c2 --batch 512 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_c2_b512.json" 2> "$OUT/bench_c2_b512.err"
+python $R/bench.py --workload c2 --batch 16384 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_c2_b16384.json" 2> "$OUT/bench_c2_b16384.err"
+# the short refinement with the reference's arithmetic (the layer-parallel kernel); the chains with the fast arithmetic
+python $R/bench.py --workload c2 --arith exact --no-cpu-baseline > "$OUT/bench_c2_fastexact.json" 2> "$OUT/bench_c2_fastexact.err"
+for w in c4 c5 c5_full; do python $R/bench.py --workload $w --steps 600 --warmup 300 --arith fast > "$OUT/bench_${w}_arithfast.json" 2> "$OUT/bench_${w}_arithfast.err"; done
+# the trial-per-lane kernel: rounds and cycles per round; the fast arithmetic's cost and distance from the exact one
+python $R/tools/gpu_lean_rounds.py > "$OUT/lean_rounds.txt" 2>&1
+python $R/tools/gpu_lean_guard.py > "$OUT/lean_guard.txt" 2>&1
+[ -x $R/tools/ubench/faeval ] && $R/tools/ubench/faeval > "$OUT/faeval.txt" 2>&1
+[ -x $R/tools/ubench/fadiff ] && $R/tools/ubench/fadiff > "$OUT/fadiff.txt" 2>&1
 python $R/bench.py --workload c4 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c4_depth1.json" 2> "$OUT/bench_c4_depth1.err"
 python $R/bench.py --workload c5 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c5_depth1.json" 2> "$OUT/bench_c5_depth1.err"
 BH_SWD_SEARCH=reference python $R/tools/gpu_latency.py > "$OUT/latency.txt" 2>&1
@@ -50,10 +59,11 @@ export BH_SWD_SEARCH=reference
 python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3.txt" 2>&1
 python $R/tools/gpu_c3_tail.py > "$OUT/c3_tail.txt" 2>&1
 unset BH_SWD_SEARCH
-python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3_fast.txt" 2>&1
+BH_SWD_ARITH=exact python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3_fastexact.txt" 2>&1
 # randomised parity sweeps (tools/gpu_fuzz.py): reference sequence; short refinement with its guard (BH_FUZZ_REF=0 BH_FUZZ_FAST=0: skip)
 [ "${BH_FUZZ_REF:-3000}" != 0 ] && python $R/tools/gpu_fuzz.py 404 ${BH_FUZZ_REF:-3000} > "$OUT/fuzz_reference.txt" 2>&1
 [ "${BH_FUZZ_FAST:-8000}" != 0 ] && FAST=1 python $R/tools/gpu_fuzz.py 405 ${BH_FUZZ_FAST:-8000} > "$OUT/fuzz_fast.txt" 2>&1
+[ "${BH_FUZZ_LEAN:-8000}" != 0 ] && LEAN=1 python $R/tools/gpu_fuzz.py 406 ${BH_FUZZ_LEAN:-8000} > "$OUT/fuzz_lean.txt" 2>&1
 for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
 for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
 fi
@@ -67,6 +77,7 @@ $TR -d "$OUT/trace_c3fast" -o t -- python $R/bench.py --workload c3 --search fas
 $TR -d "$OUT/trace_c3g" -o t -- python $R/bench.py --workload c3g --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3g.log" 2>&1
 $TR -d "$OUT/trace_c2_b65536" -o t -- python $R/bench.py --workload c2 --search reference --batch 65536 --steps 5 --warmup 2 $NB > "$OUT/trace_c2_b65536.log" 2>&1
 $TR -d "$OUT/trace_c2fast" -o t -- python $R/bench.py --workload c2 --search fast --steps 10 --warmup 2 $NB > "$OUT/trace_c2fast.log" 2>&1
+$TR -d "$OUT/trace_c2fastexact" -o t -- python $R/bench.py --workload c2 --search fast --arith exact --steps 10 --warmup 2 $NB > "$OUT/trace_c2fastexact.log" 2>&1
 $TR -d "$OUT/trace_c4" -o t -- python $R/bench.py --workload c4 --steps 700 --warmup 300 > "$OUT/trace_c4.log" 2>&1
 $TR -d "$OUT/trace_c5" -o t -- python $R/bench.py --workload c5 --steps 600 --warmup 300 > "$OUT/trace_c5.log" 2>&1
 for sh in c3 tut t512u t512r n16384; do
@@ -88,6 +99,10 @@ for WL in c2 c3; do for SM in fast reference; do      # (keys: c2fast / c3fast =
   $PM --pmc $SQ -d "$OUT/pmc_${KEY}_SQ" -o pmc -- $CMD > "$OUT/pmc_${KEY}_SQ.log" 2>&1
   $PM --pmc $SQ2 -d "$OUT/pmc_${KEY}_SQ2" -o pmc -- $CMD > "$OUT/pmc_${KEY}_SQ2.log" 2>&1
 done; done
+CMD="python $R/bench.py --workload c2 --search fast --arith exact --steps 4 --warmup 1 $NB"   # the short refinement in the reference's arithmetic
+for C in FETCH_SIZE WRITE_SIZE; do $PM --pmc $C -d "$OUT/pmc_c2fastexact_$C" -o pmc -- $CMD > "$OUT/pmc_c2fastexact_$C.log" 2>&1; done
+$PM --pmc $SQ -d "$OUT/pmc_c2fastexact_SQ" -o pmc -- $CMD > "$OUT/pmc_c2fastexact_SQ.log" 2>&1
+$PM --pmc $SQ2 -d "$OUT/pmc_c2fastexact_SQ2" -o pmc -- $CMD > "$OUT/pmc_c2fastexact_SQ2.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do   # the progress board's share of the c2 traffic: the same passes with the board off
   BH_SWD_NO_BOARD=1 $PM --pmc $C -d "$OUT/pmc_c2noboard_$C" -o pmc -- python $R/bench.py --workload c2 --search reference --steps 4 --warmup 1 $NB > "$OUT/pmc_c2noboard_$C.log" 2>&1
 done
