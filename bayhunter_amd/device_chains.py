@@ -60,7 +60,7 @@ def auto_spec_depth(nchains, budget=None):
 
 class DeviceChains(object):
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
-                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast", arith="exact"):
+                 betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast", arith="fast"):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
         torch.distributed): `seed` is the JOB's seed, the same on every rank; the chains are numbered globally
         (`chain_offset` = global index of this rank's first chain, default: ranks own consecutive blocks in rank
@@ -87,12 +87,12 @@ class DeviceChains(object):
         "reference": the reference's bits throughout (what `ChainBatch`, the replay of recorded reference runs, uses);
         None: whatever the engine is set to.
         arith: arithmetic of those launches where every dispersion target takes the short refinement (Engine.set_swd_arith,
-        applied like `search`).  Default "exact": the windows keep the layer-parallel kernel, whose rounds cost the same
-        whatever a model's depth and which restarts a guarded model in place -- measured on MI355X (chain-iterations/s,
-        "exact" / "fast"): 8 chains 5.3e4 / 6.0e4, a 64-chain tempered rung (hot chains: deep models) 1.84e5 / 1.64e5, 512
-        chains 4.0e5 / 3.6e5.  "fast": the trial-per-lane kernel with 16 trials per round whatever the window's size
-        (Engine.set_swd_trials), so that windows of any depth and shards of any size walk the same trajectory.  None:
-        whatever the engine is set to."""
+        applied like `search`).  Default "fast" (the engine's own): the windows run the trial-per-lane kernel with 16 trials
+        per round whatever their size (Engine.set_swd_trials), so that windows of any depth and shards of any size walk the
+        same trajectory; its guarded models (2 % of a sampler's Love proposals) are re-run by a second launch.  "exact": the
+        reference's rounding points -- the windows then take the layer-parallel kernel, which restarts a guarded model in
+        place.  Measured on MI355X (chain-iterations/s, "fast" / "exact"): 8 chains 6.8e4 / 5.2e4, a 64-chain tempered rung
+        1.99e5 / 1.83e5, 512 chains 4.1e5 / 3.9e5.  None: whatever the engine is set to."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)

@@ -832,7 +832,7 @@ def main():
     ap.add_argument("--arith", default=None, choices=["fast", "exact"],
                     help="arithmetic of the launches in which every target takes the short refinement (bh_engine_set_swd_arith): "
                          "fast = the engine's default, what `value` is measured with (the trial-per-lane kernel); exact = the "
-                         "reference's rounding points.  The chain workloads take DeviceChains' own default (exact) unless given")
+                         "reference's rounding points.  The chain workloads take DeviceChains' own default (fast as well) unless given")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="also: the other search, the RF kernels alone, the port baseline, the CPU pool sweep")
