@@ -123,7 +123,7 @@ __device__ __forceinline__ void lean_wave_sync()
 constexpr int LEAN_WPB = 4; // wavefronts per workgroup: independent (no barrier), one per SIMD of the CU the workgroup lands on
 
 template <int J> // trials per model and round: 4, 8, 16, 32 or 64 lanes = one model
-__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) __attribute__((amdgpu_num_vgpr(208))) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
+__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
     if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
