@@ -52,6 +52,50 @@ __device__ __forceinline__ double rcp1(double x) // one step (~2^-45): scale fac
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 }
 
+// sin and cos of 0 <= x < 1e5 and exp(-x), 0 <= x <= 700: the reductions and coefficients of swd_csign.h (fdlibm's kernels on
+// [-pi/4, pi/4]; Taylor to r^12 on |r| <= ln 2 / 2), the polynomials summed by Estrin's scheme -- half the depth of the chain of
+// dependent operations, which is what two wavefronts per SIMD cannot hide.
+__device__ __forceinline__ void sincos(double x, double &sn, double &cs)
+{
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r, z2 = z * z, z4 = z2 * z2;
+    const double s01 = __builtin_fma(z, 8.33333333332248946124e-03, -1.66666666666666324348e-01);
+    const double s23 = __builtin_fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
+    const double s45 = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    const double ps = __builtin_fma(z4, s45, __builtin_fma(z2, s23, s01));
+    const double s = __builtin_fma(r * z, ps, r);
+    const double c01 = __builtin_fma(z, -1.38888888888741095749e-03, 4.16666666666666019037e-02);
+    const double c23 = __builtin_fma(z, -2.75573143513906633035e-07, 2.48015872894767294178e-05);
+    const double c45 = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    const double pc = __builtin_fma(z4, c45, __builtin_fma(z2, c23, c01));
+    const double c = __builtin_fma(z2, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ double expneg(double x)
+{
+    const double t = -x;
+    const double n = __builtin_rint(t * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, t);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    // p(r) = 1/2 + r/6 + r^2/24 + ... + r^10/12! (so that e^r = 1 + r + r^2 p)
+    const double p01 = __builtin_fma(r, 1.66666666666666666667e-01, 0.5);
+    const double p23 = __builtin_fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
+    const double p45 = __builtin_fma(r, 1.98412698412698412698e-04, 1.38888888888888888889e-03);
+    const double p67 = __builtin_fma(r, 2.75573192239858906526e-06, 2.48015873015873015873e-05);
+    const double p89 = __builtin_fma(r, 2.50521083854417187751e-08, 2.75573192239858906526e-07);
+    const double p03 = __builtin_fma(r2, p23, p01), p47 = __builtin_fma(r2, p67, p45);
+    const double p8a = __builtin_fma(r2, 2.08767569878680989792e-09, p89);
+    const double p = __builtin_fma(r8, p8a, __builtin_fma(r4, p47, p03));
+    const double e = __builtin_fma(r2, p, r) + 1.0;
+    return e * __longlong_as_double((long long)((unsigned long long)((long long)n + 1023ll) << 52));
+}
+
 // One wave type of one layer (surfdisp96.f:906-935): cos-like, sin-like / r, -+ r sin-like, and e^-p of an evanescent wave
 // (1 for a propagating one).  k == xk takes the reference's limits (cos = 1, w = d, x = 0).  Arguments beyond the
 // reduction's range poison the value (NaN -> the guard).
@@ -66,11 +110,11 @@ __device__ __forceinline__ void wave(double k, double xk, double d, double &cs, 
     const double p = r * d;
     double sn;
     if (dk < 0.0) {
-        csign::sincos_fast(fmin(p, 9.0e4), sn, cs);
+        sincos(fmin(p, 9.0e4), sn, cs);
         x = -(r * sn);
         em = 1.0;
     } else {
-        em = csign::expneg_fast(fmin(p, 700.0));
+        em = expneg(fmin(p, 700.0));
         const double hf = 0.5 * (em * em);
         cs = 0.5 + hf;
         sn = 0.5 - hf;
@@ -191,10 +235,10 @@ __device__ __forceinline__ void love_terms(double wvno, double xkb, double dm, d
     q = dm * rb;
     double sn;
     if (dk < 0.0) {
-        csign::sincos_fast(fmin(q, 9.0e4), sn, cosq);
+        sincos(fmin(q, 9.0e4), sn, cosq);
         z = -(rb * sn);
     } else {
-        em = csign::expneg_fast(fmin(q, 700.0));
+        em = expneg(fmin(q, 700.0));
         const double hf = 0.5 * (em * em);
         cosq = 0.5 + hf;
         sn = 0.5 - hf;
