@@ -146,7 +146,7 @@ struct bh_engine {
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
     int swd_arith = BH_ARITH_FAST; // bh_engine_set_swd_arith / BH_SWD_ARITH=exact|fast: fast arithmetic in launches where every target takes the short refinement
-    int swd_prescan = 0; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits; off by default: DESIGN.md 3.1c)
+    int swd_prescan = 0; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits; off by default: measured not to pay)
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
@@ -348,7 +348,7 @@ int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
     return BH_OK;
 }
 
-// The guard of the short refinement (SearchT, swd_common.h): work space = BH_MAX_TARGETS counts (16 words) followed by one
+// The guard of the short refinement (SearchT, swd_common.h): work space = three blocks of BH_MAX_TARGETS counts (GUARD_HEAD = 24 words, below) followed by one
 // list of B model indices per target.
 constexpr int GUARD_HEAD = 24;
 int guard_space(bh_engine *e, hipStream_t st, int B, int32_t **counts, int32_t **lists)

@@ -501,7 +501,7 @@ enum : int {
     ST_FX = 5,    // single point: regula falsi / bisection
     ST_FP1 = 6,   // x - tau (towards c1) of the acceptance pair around the estimate x
     ST_FP2 = 7,   // x + tau (towards c2)
-    ST_FB = 8,    // (unused since the guard takes brackets that contain betmx)
+    // (8: unused)
     // the counted scan (Love; see SearchT): not the reference's sequence of scan evaluations, but the same bracket
     ST_JUMP = 9,  // the grid point `jn` steps above c1
     ST_BIS = 10,  // a grid point between c1 and c2 (`jn` steps above c1; c2 is `nn` steps above c1 and counts more)
@@ -558,7 +558,7 @@ enum : int {
 // scans see different sign patterns exactly when a sign change lies within |s| of a grid point.  With a lone root that moves
 // the bracket by a step (same root); but the half-space terms contain |k - k_v|, so a root creeping up to a half-space
 // velocity v has a mirror-image sign change just above v, and with that pair it decides whether the reference sees a sign
-// change AT ALL (the only mechanism in 9.4 million random models).  The guard, eps = 3e-6 x velocity:
+// change AT ALL (docs/HISTORY.md 3.1b: the only mechanism in 9.4 million random models).  The guard, eps = 3e-6 x velocity:
 //   - a scan step without a sign change that contains a half-space velocity may hide the pair: probe eps inside both ends;
 //   - an accepted bracket whose root lies within two steps of a half-space velocity / betmx: root within eps of a bracket
 //     end or of betmx, or a sign change within eps OUTSIDE a bracket end (the image right behind it).

@@ -537,7 +537,7 @@ void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream)
 
 // ---- launch plan ------------------------------------------------------------------------------------
 // Which mapping (one lane per model, or G lanes per model) and how many trial velocities per round and
-// target.  Cost model, calibrated on MI355X with 10-layer models and 30 periods (profiles/):
+// target.  Cost model, calibrated on MI355X with 10-layer models and 30 periods (profiles/, docs/HISTORY.md 3.1):
 // at this kernel's register budget 2 wavefronts are resident per SIMD = 2048 on the chip; a launch runs in
 // ceil(wavefronts / 2048) rounds, each as long as its longest wavefront.  Relative wavefront durations:
 //   group kernel, Rayleigh: 1 / .64 / .52 / .45 / .36 for 1 / 2 / 3 / 4 / 7 trials per round,

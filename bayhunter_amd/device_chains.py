@@ -47,7 +47,7 @@ from .Targets import JointTarget
 def auto_spec_depth(nchains, budget=None):
     """Speculation depth for `nchains` chains on one GPU: the deepest tree whose nodes (chains x (2^d - 1)
     evaluations per launch) stay within `budget` evaluations -- below ~1000 models a launch of the dispersion kernel
-    costs about what 8 models cost (1.5 ms at B <= 512, 2.0 ms at 1024, 3.0 ms at 2048), so d
+    costs about what 8 models cost (docs/HISTORY.md 3.1: 1.5 ms at B <= 512, 2.0 ms at 1024, 3.0 ms at 2048), so d
     iterations per launch are nearly free; beyond it the launch time grows faster than the depth.
     BH_SPEC_BUDGET overrides the budget (0 = no speculation)."""
     if budget is None:

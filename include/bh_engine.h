@@ -146,8 +146,8 @@ int bh_engine_last_swd_kernel(const bh_engine *e);
  *   BH_SCAN_STEPS    every step evaluated, as the reference does.
  *   BH_SCAN_COUNTED  the counted scan wherever a launch holds a Love target -- except launches of several models per
  *                    wavefront that mix both root refinements (that kernel build does not carry it).
- *   BH_SCAN_AUTO     (default) the counted scan in the launches where it is measured to pay.
- * Rayleigh targets always step. */
+ *   BH_SCAN_AUTO     (default) the counted scan in the launches where it is measured to pay (docs/HISTORY.md 3.1a).
+ * Rayleigh targets always step; the trial-per-lane kernel (BH_KERNEL_LEAN) steps for both wave types, sixteen steps a round. */
 #define BH_SCAN_STEPS 0
 #define BH_SCAN_COUNTED 1
 #define BH_SCAN_AUTO 2
@@ -160,7 +160,8 @@ int bh_engine_get_swd_scan(const bh_engine *e);
  * point) and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's; the
  * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
  * step-by-step scan.  Applies to both root refinements and all target types in launches of several models per wavefront
- * (a few thousand models per call); ignored elsewhere.  DESIGN.md 3.1c has the measurement that keeps it off. */
+ * (a few thousand models per call); ignored elsewhere.  Measured not to pay (the look-ahead costs what the skipped rounds
+ * cost): off. */
 int bh_engine_set_swd_prescan(bh_engine *e, int on);
 int bh_engine_get_swd_prescan(const bh_engine *e);
 

@@ -642,8 +642,9 @@ static int guard_probe(const medium *md, double omega, double c, double ref)
  * point is formed by the reference's own repeated additions of dc, so the bracket handed to the refinement -- and every
  * bit after it -- is the reference's.  Upward scans below the slowest of (half-space S velocity, betmx) only; anything
  * else (downward scans, a scan that has turned round at clow, an ambiguous count) takes the reference's steps one by one.
- * The stride is a deterministic function of the search state: the first one aims two steps short of where the last
- * period's bracket was found (*iprev), then 4, 8, ... (first period: 16, 32, 64). */
+ * The stride is a deterministic function of the search state: the first one aims one step beyond where the last
+ * period's bracket was found (iprev + 1: g_stride_back = -1, as the device's plan_first_jump), then 4, 8, ... (first
+ * period: 16, 32, 64). */
 typedef struct {
     int on;
     int iprev; /* steps from the start value to the bracket of the previous period (0: none yet) */
