@@ -131,6 +131,28 @@ def test_calls_beyond_the_kernels_range_take_the_fast_arithmetic_elsewhere(lean,
     check_against_the_reference(v, e, ov, oe)
 
 
+@pytest.mark.parametrize("trials", [4, 8, 32, 64])
+def test_every_trial_count_keeps_the_guarantees(lean, oracle, trials):
+    """bh_engine_set_swd_trials: 4 / 8 trials per round (no next-period ride-along below 16), 32 / 64 (one or two models per
+    wavefront) -- the same flags, zero rows and tolerance; the setting is validated and restored."""
+    from bayhunter_amd.engine import EngineError
+    rs = np.random.RandomState(99 + trials)
+    nlay, h, vp, vs, rho = synth_models(rs, 3000, 12, lvz_frac=0.3, ragged=True)
+    per = np.linspace(2, 60, 30)
+    assert lean.swd_trials() == 0
+    with pytest.raises(EngineError):
+        lean.set_swd_trials(12)
+    lean.set_swd_trials(trials)
+    try:
+        for iwave in (2, 1):
+            v, e = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, 0)
+            assert lean.last_swd_kernel() == "lean"
+            ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, 0)
+            check_against_the_reference(v, e, ov, oe)
+    finally:
+        lean.set_swd_trials(0)
+
+
 def test_reference_golden_vectors_within_tolerance(lean):
     g = golden("swd_golden.npz")
     nlay = g["nlay"]
