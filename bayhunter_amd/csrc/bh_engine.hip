@@ -460,13 +460,13 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     const size_t lds_cap = 64 * 1024;
     if (G <= 1 && bh_swd_lds_bytes(Lmax, kmax, maxmode) > lds_cap) G = 2; // deep models / many periods
     // The trial-per-lane kernel (swd_lean.hip): every target of the call takes the short refinement with the fast arithmetic, in
-    // calls of up to 65 536 (model, target) pairs.  Beyond, one lane per EVALUATION (swd_kernel's FA builds: no trial is evaluated
-    // that the search does not consume) is ahead -- measured, c2 shape, lean / lane kernel: B = 16 384 2.9 / 4.5 ms, 32 768
-    // 5.4 / 5.7, 49 152 7.9 / 6.9, 65 536 10.4 / 8.7 ms (7.5e6 evals/s).
+    // calls of up to 2^20 (model, target) pairs (with four trials per round it stays ahead of one lane per evaluation -- swd_kernel's
+    // FA builds -- as far as measured: c2 at B = 65 536 7.99 against 8.44 ms).
     int lean_trials = 0;
     {
         bool all = e->swd_arith == BH_ARITH_FAST && e->swd_search == BH_SEARCH_FAST && e->force_group == 0 && e->force_look == 0 &&
-                   e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS && Lmax <= 32 && (long)B * nlive <= 65536L;
+                   e->look_r == 0 && e->look_l == 0 && bh_tuning().swd_no_lean == 0 && maxmode <= 1 && kmax <= BH_MAX_PERIODS && Lmax <= 32 &&
+                   (long)B * nlive <= (bh_tuning().swd_lean_pairs > 0 ? (long)bh_tuning().swd_lean_pairs : (1L << 20));
         for (int j = 0; j < njobs; ++j) all = all && (jobs[j].K == 0 || jobs[j].igr == 0);
         if (all) lean_trials = e->swd_trials > 0 ? e->swd_trials : bh_swd_lean_trials(B, nlive);
         if (lean_trials >= 4 && bh_swd_lean_lds_bytes(lean_trials, Lmax, kmax) > lds_cap) lean_trials = 0; // (a workgroup's LDS)

@@ -240,14 +240,14 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         iom = fa::rcp(omega);
     }
     constexpr unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
-    // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG (J >= 16).  The estimate x that a round of clustered trials is centred on is, 99 times
+    // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG.  The estimate x that a round of clustered trials is centred on is, 99 times
     // in 100, within 2e-7 |x| of the root it then finds.  So only the lower half of the model's lanes carry the cluster; the upper
     // half evaluates -- at the NEXT period's frequency -- the first round of the next period's scan on the grid anchored at
     // x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x, those values ARE the next period's first
     // round (its grid is anchored 2.5e-7 relative off the root: the reference's own root is known to 1e-6, and the guard covers
     // grids that differ by 3e-6); otherwise they are dropped.  Two rounds per period instead of three.
     constexpr int H = J / 2;
-    constexpr bool can_spec = J >= 16;
+    constexpr bool can_spec = J >= 4; // (every trial count the launcher offers)
     constexpr unsigned long long maskH = (1ull << H) - 1ull;
     const double invJ1 = 1.0 / (double)(J + 1);
     unsigned nrounds = 0;
@@ -637,13 +637,17 @@ static size_t lean_wave_lds(int J, int Lmax, int Kmax)
 }
 size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax) { return LEAN_WPB * lean_wave_lds(J, Lmax, Kmax); }
 
-// Trials per model and round for a call of `nt` targets over B models: 16 while that keeps the launch within two wavefronts
-// per SIMD of an MI355X (8192 (model, target) pairs: the latency regime -- fewer rounds), 8 beyond (the throughput regime --
-// fewer evaluations that the scan does not consume).  A function of the call's shape alone, NOT of the device: a model's
-// result depends on it in the last bits (the refinement's trial points do), and a sampler's windows must not.
+// Trials per model and round for a call of `nt` targets over B models.  A round of J trials costs a wavefront what one trial
+// costs, so few models get many trials (the latency regime: fewer rounds) and many models few (the throughput regime: fewer
+// evaluations that the scan does not consume).  Measured on the c2 shape (two targets; ms per step with 4 / 8 / 16 trials):
+// 8192 pairs - / 1.02 / 0.81, 12 288: 1.69 / 1.27 / 1.28, 16 384: 1.69 / 1.29 / 1.56, 24 576: 2.14 / 2.07 / 2.19,
+// 32 768: 2.15 / 2.56 / -, 65 536: 4.31 / 4.68 / 5.49, 131 072: 7.99 / 8.98 / 10.7.
+// A function of the call's shape alone, NOT of the device: a model's result depends on it in the last bits (the refinement's
+// trial points do), and a sampler's windows must not (it pins the number: bh_engine_set_swd_trials).
 int bh_swd_lean_trials(int B, int nt)
 {
-    return ((long)B * nt <= 8192) ? 16 : 8;
+    const long pairs = (long)B * nt;
+    return pairs <= 10240 ? 16 : (pairs <= 28672 ? 8 : 4);
 }
 
 // All targets of `a` (fundamental-mode phase velocities, a.t[t].look = trials per round, gcount / glist set) in one launch.

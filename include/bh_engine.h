@@ -125,10 +125,11 @@ int bh_engine_get_swd_arith(const bh_engine *e);
  *   BH_KERNEL_GROUP  several lanes per model, layer-parallel (swd_group_kernel),
  *   BH_KERNEL_LANE   one lane per evaluation, reference-exact or FA builds (swd_kernel),
  *   BH_KERNEL_LEAN   one lane per trial velocity with the fast arithmetic (swd_lean_kernel): BH_SEARCH_FAST + BH_ARITH_FAST
- *                    calls whose targets are all fundamental-mode phase velocities, of up to 65536 (model, target) pairs, in
- *                    arrays of up to 32 layers (beyond: BH_KERNEL_LANE's builds with the fast arithmetic).  It evaluates 16 trial velocities per model and round in calls of up to 8192
- *                    (model, target) pairs and 8 beyond; a model's velocities depend on that number in their last bits
- *                    (~1e-9 relative) and on nothing else about the call. */
+ *                    calls whose targets are all fundamental-mode phase velocities, in arrays of up to 32 layers.  It
+ *                    evaluates 16 trial velocities per model and round in calls of up to 10240 (model, target) pairs, 8 up
+ *                    to 28672 and 4 beyond; a model's velocities depend on that number in their last bits (~1e-9 relative; a
+ *                    model whose guard fires under one count and not under another: the reference's 1e-6) and on nothing
+ *                    else about the call. */
 /* Trials per model and round of BH_KERNEL_LEAN: 0 (default) = by the call's shape as described above; 4, 8, 16, 32 or 64 =
  * that many in every call -- what a sampler sets whose windows and shards must give the same bits whatever their size
  * (DeviceChains: 16). */

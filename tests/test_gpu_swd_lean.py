@@ -74,7 +74,7 @@ def test_a_fresh_engine_computes_this_way(oracle):
 @pytest.mark.parametrize("ref", sorted(REFS))
 def test_within_tolerance_of_the_reference_lvz_rich(lean, oracle, ref):
     """20k models of 2..12 layers, a quarter with a low-velocity layer (the parity-statistics set of test_gpu_swd.py): 8 trials
-    per round (a call of more than 8192 models); the first 3000 again as a call of their own: 16 trials per round."""
+    per round (a call of 10 241 ... 28 672 models); the first 3000 again as a call of their own: 16 trials per round."""
     rs = np.random.RandomState(2024)
     nlay, h, vp, vs, rho = synth_models(rs, 20000, 12, lvz_frac=0.25, ragged=True)
     per = np.linspace(2, 60, 30)
@@ -118,23 +118,29 @@ def test_failure_flags_and_zero_rows_are_the_references_on_millions_of_models(le
 
 
 @pytest.mark.parametrize("ref", sorted(REFS))
-def test_calls_beyond_the_kernels_range_take_the_fast_arithmetic_elsewhere(lean, oracle, ref):
-    """More than 65536 (model, target) pairs in a call: one lane per evaluation (swd_kernel's builds with the fast arithmetic) --
-    the same guarantees."""
+def test_the_lane_per_evaluation_kernel_with_the_fast_arithmetic(lean, oracle, ref):
+    """A call kept off the trial-per-lane kernel (here by the experiment switch that bounds its calls; also: forced lanes per
+    model) takes swd_kernel's builds with the fast arithmetic -- the same guarantees."""
     rs = np.random.RandomState(4711)
     nlay, h, vp, vs, rho = synth_models(rs, 70000, 10, lvz_frac=0.25, ragged=True)
     per = np.linspace(2, 60, 30)
     iwave, igr = REFS[ref]
-    v, e = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
-    assert lean.last_swd_kernel() == "lane"
+    lean.set_tuning("swd_lean_pairs", 65536)
+    try:
+        v, e = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)
+        assert lean.last_swd_kernel() == "lane"
+    finally:
+        lean.set_tuning("swd_lean_pairs", 0)
     ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr)
     check_against_the_reference(v, e, ov, oe)
+    v4, e4 = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, igr)     # (the same call on the trial-per-lane kernel: 4 trials per round)
+    assert lean.last_swd_kernel() == "lean"
+    check_against_the_reference(v4, e4, ov, oe)
 
 
 @pytest.mark.parametrize("trials", [4, 8, 32, 64])
 def test_every_trial_count_keeps_the_guarantees(lean, oracle, trials):
-    """bh_engine_set_swd_trials: 4 / 8 trials per round (no next-period ride-along below 16), 32 / 64 (one or two models per
-    wavefront) -- the same flags, zero rows and tolerance; the setting is validated and restored."""
+    """bh_engine_set_swd_trials: 4 / 8 trials per round, 32 / 64 (two models or one per wavefront) -- the same flags, zero rows and tolerance; the setting is validated and restored."""
     from bayhunter_amd.engine import EngineError
     rs = np.random.RandomState(99 + trials)
     nlay, h, vp, vs, rho = synth_models(rs, 3000, 12, lvz_frac=0.3, ragged=True)
@@ -170,7 +176,7 @@ def test_reference_golden_vectors_within_tolerance(lean):
 
 
 def test_a_model_alone_a_window_and_a_batch_give_the_same_bits(lean):
-    """The result is a function of the model and of the trials per round (16 up to 8192 (model, target) pairs in a call): a
+    """The result is a function of the model and of the trials per round (16 up to 10 240 (model, target) pairs in a call): a
     sampler's windows of any depth and a model evaluated alone agree bit for bit."""
     rs = np.random.RandomState(77)
     nlay, h, vp, vs, rho = synth_models(rs, 1016, 12, lvz_frac=0.3, ragged=True)
