@@ -640,6 +640,7 @@ size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax) { return LEAN_WPB * lean
 // Trials per model and round for a call of `nt` targets over B models.  A round of J trials costs a wavefront what one trial
 // costs, so few models get many trials (the latency regime: fewer rounds) and many models few (the throughput regime: fewer
 // evaluations that the scan does not consume).  Measured on the c2 shape (two targets; ms per step with 4 / 8 / 16 trials):
+// 128 pairs (16 / 32 / 64 trials) 0.60 / 0.45 / 0.40, 2048: 0.64 / 0.47 / 0.50, 4096: 0.66 / 0.58 / 0.98;
 // 8192 pairs - / 1.02 / 0.81, 12 288: 1.69 / 1.27 / 1.28, 16 384: 1.69 / 1.29 / 1.56, 24 576: 2.14 / 2.07 / 2.19,
 // 32 768: 2.15 / 2.56 / -, 65 536: 4.31 / 4.68 / 5.49, 131 072: 7.99 / 8.98 / 10.7.
 // A function of the call's shape alone, NOT of the device: a model's result depends on it in the last bits (the refinement's
@@ -647,7 +648,7 @@ size_t bh_swd_lean_lds_bytes(int J, int Lmax, int Kmax) { return LEAN_WPB * lean
 int bh_swd_lean_trials(int B, int nt)
 {
     const long pairs = (long)B * nt;
-    return pairs <= 10240 ? 16 : (pairs <= 28672 ? 8 : 4);
+    return pairs <= 1024 ? 64 : (pairs <= 5120 ? 32 : (pairs <= 10240 ? 16 : (pairs <= 28672 ? 8 : 4)));
 }
 
 // All targets of `a` (fundamental-mode phase velocities, a.t[t].look = trials per round, gcount / glist set) in one launch.

@@ -87,7 +87,7 @@ class DeviceChains(object):
         "reference": the reference's bits throughout (what `ChainBatch`, the replay of recorded reference runs, uses);
         None: whatever the engine is set to.
         arith: arithmetic of those launches where every dispersion target takes the short refinement (Engine.set_swd_arith,
-        applied like `search`).  Default "fast" (the engine's own): the windows run the trial-per-lane kernel with 16 trials
+        applied like `search`).  Default "fast" (the engine's own): the windows run the trial-per-lane kernel with 32 trials
         per round whatever their size (Engine.set_swd_trials), so that windows of any depth and shards of any size walk the
         same trajectory; its guarded models (2 % of a sampler's Love proposals) are re-run by a second launch.  "exact": the
         reference's rounding points -- the windows then take the layer-parallel kernel, which restarts a guarded model in
@@ -268,7 +268,7 @@ class DeviceChains(object):
         prev_arith, prev_trials = (e.swd_arith() if self.arith is not None else None), e.swd_trials()
         if prev_arith is not None and prev_arith != self.arith:
             e.set_swd_arith(self.arith)
-        e.set_swd_trials(16)
+        e.set_swd_trials(32)
         try:
             e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
                                  t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),

@@ -281,8 +281,8 @@ class Engine(object):
         self._check(self._L.bh_engine_set_swd_arith(self._h, code))
 
     def set_swd_trials(self, trials):
-        """Trials per model and round of the trial-per-lane kernel: 0 = by the call's shape (16 up to 10240 (model, target)
-        pairs, 8 up to 28672, 4 beyond), or 4 / 8 / 16 / 32 / 64 in every call (bh_engine_set_swd_trials)."""
+        """Trials per model and round of the trial-per-lane kernel: 0 = by the call's shape (64 up to 1024 (model, target)
+        pairs, 32 up to 5120, 16 up to 10240, 8 up to 28672, 4 beyond), or 4 / 8 / 16 / 32 / 64 in every call (bh_engine_set_swd_trials)."""
         self._check(self._L.bh_engine_set_swd_trials(self._h, int(trials)))
 
     def swd_trials(self):

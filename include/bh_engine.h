@@ -126,13 +126,13 @@ int bh_engine_get_swd_arith(const bh_engine *e);
  *   BH_KERNEL_LANE   one lane per evaluation, reference-exact or FA builds (swd_kernel),
  *   BH_KERNEL_LEAN   one lane per trial velocity with the fast arithmetic (swd_lean_kernel): BH_SEARCH_FAST + BH_ARITH_FAST
  *                    calls whose targets are all fundamental-mode phase velocities, in arrays of up to 32 layers.  It
- *                    evaluates 16 trial velocities per model and round in calls of up to 10240 (model, target) pairs, 8 up
- *                    to 28672 and 4 beyond; a model's velocities depend on that number in their last bits (~1e-9 relative; a
+ *                    evaluates 64 trial velocities per model and round in calls of up to 1024 (model, target) pairs, 32 up
+ *                    to 5120, 16 up to 10240, 8 up to 28672 and 4 beyond; a model's velocities depend on that number in their last bits (~1e-9 relative; a
  *                    model whose guard fires under one count and not under another: the reference's 1e-6) and on nothing
  *                    else about the call. */
 /* Trials per model and round of BH_KERNEL_LEAN: 0 (default) = by the call's shape as described above; 4, 8, 16, 32 or 64 =
  * that many in every call -- what a sampler sets whose windows and shards must give the same bits whatever their size
- * (DeviceChains: 16). */
+ * (DeviceChains: 32). */
 int bh_engine_set_swd_trials(bh_engine *e, int trials);
 int bh_engine_get_swd_trials(const bh_engine *e);
 #define BH_KERNEL_GROUP 0
