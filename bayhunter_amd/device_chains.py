@@ -91,8 +91,8 @@ class DeviceChains(object):
         per round whatever their size (Engine.set_swd_trials), so that windows of any depth and shards of any size walk the
         same trajectory; its guarded models (2 % of a sampler's Love proposals) are re-run by a second launch.  "exact": the
         reference's rounding points -- the windows then take the layer-parallel kernel, which restarts a guarded model in
-        place.  Measured on MI355X (chain-iterations/s, "fast" / "exact"): 8 chains 6.8e4 / 5.2e4, a 64-chain tempered rung
-        1.99e5 / 1.83e5, 512 chains 4.1e5 / 3.9e5.  None: whatever the engine is set to."""
+        place.  Measured on MI355X (chain-iterations/s, "fast" / "exact"): 8 chains 7.4e4 / 5.2e4, a 64-chain tempered rung
+        2.18e5 / 1.83e5, 512 chains 4.6e5 / 3.9e5.  None: whatever the engine is set to."""
         import torch
         self.torch = torch
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)

@@ -25,4 +25,4 @@ print("dispersion family %.3f ms; evaluations R %d (%.1f per model and period) L
 nw = c[7]
 for nm, o in (("Rayleigh", 1), ("Love", 4)):
     print("  %-8s rounds: sum %d, most %d; cycles per round %.0f, of which the evaluation %.0f" % (nm, c[o], c[o + 2], c[o + 1] / max(c[o], 1), c[12 if o == 1 else 13] / max(c[o], 1)))
-print("  wavefronts", nw & 0xffffffff, " periods whose first estimate was within 2e-7 of the root: %d of %d; within 1e-6: %d" % (c[14], c[15], nw >> 32))
+print("  wavefronts", nw)
