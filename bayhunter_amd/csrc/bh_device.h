@@ -201,6 +201,7 @@ struct RfKernelArgs {
     // yobs, formed in like_kernel's own order (same bits) -- to sums[B][4]; null: the trace is written
     const double *yobs;
     double *sums;
+    double *zwork; // traces beyond BH_RF_MAX_LDS: workspace [B][nsamp / 2] complex (16 bytes each) for the half-length spectra, else null
     int lds_min;   // lower bound of the synthesis kernel's LDS request in bytes (0 = what the trace needs), see bh_engine.hip
     int no_realc;  // experiment switch: 1 = always the general (complex-coefficient) recursion
     int coef_small; // 1: the 96-register build of the coefficient kernel (fused call: resident beside the dispersion wavefronts)
@@ -210,6 +211,9 @@ struct RfKernelArgs {
 size_t bh_rf_coef_doubles(int Lmax);
 // LDS of one workgroup of the synthesis kernel for traces of nsamp samples; a CU has 160 KB, one workgroup may use all
 constexpr size_t BH_RF_MAX_LDS = 160 * 1024;
+// Longer traces (nsamp > 16384) keep the half-length spectrum in an HBM workspace (RfKernelArgs::zwork) and run the same
+// butterflies there; the largest transform served (the second twiddle table, nsamp / 128 entries, stays in LDS)
+constexpr int BH_RF_MAX_NSAMP = 1 << 18;
 size_t bh_rf_lds_bytes(int nsamp);
 int bh_launch_rf(const RfKernelArgs &a, hipStream_t stream); // 0, or -1 when the trace does not fit a workgroup's LDS
 

@@ -130,7 +130,7 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter, sph, perm, board, nevhi;
+        misfits, err_t, probe_in, probe_out, counter, sph, perm, board, nevhi, rfz;
     unsigned swd_stamp = 0;                // launch counter of the group kernel (marks its progress-board entries)
     // targets
     int nt = 0;
@@ -707,6 +707,10 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     a.p_s_per_deg = p; a.gauss = gauss; a.fsamp = fsamp; a.tshift = tshift; a.nsv = nsv;
     a.coef = (double *)e->coef.p; a.rf = rf; a.ldr = ldr;
     a.yobs = yobs; a.sums = sums; // (fused likelihood: the sums instead of the trace)
+    if (bh_rf_lds_bytes(nsamp) > BH_RF_MAX_LDS) { // a trace longer than a workgroup's LDS holds: the spectra go through a workspace
+        if ((rc = ensure(e, e->rfz, (size_t)B * (size_t)(nsamp / 2) * 2 * sizeof(double)))) return rc;
+        a.zwork = (double *)e->rfz.p;
+    }
     // Beside a dispersion launch (fused call, second stream): the synthesis workgroups must not take wave slots before
     // the dispersion kernel's wavefronts are resident -- that kernel counts on all of them being co-resident (one round
     // of wavefronts; displaced ones wait for a whole lifetime: 3.6 -> 7 ms measured when the 17.7 KB workgroups of
@@ -724,7 +728,7 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     ev_begin(e, 1, st);
     const int lrc = bh_launch_rf(a, st);
     ev_end(e, 1, st);
-    if (lrc != 0) return fail(e, BH_EUNSUPPORTED, "receiver function: nsamp does not fit a workgroup's LDS");
+    if (lrc != 0) return fail(e, BH_EUNSUPPORTED, "receiver function: nsamp above 262144 is not supported");
     HIPCHK(e, hipGetLastError());
     return BH_OK;
 }
@@ -757,10 +761,10 @@ int rf_args_ok(bh_engine *e, int nsamp, int nkeep, double gauss, double fsamp, i
 {
     if (nsamp < 4 || (nsamp & (nsamp - 1)) != 0)
         return fail(e, BH_EINVAL, "nsamp must be a power of two >= 4");
-    // rfmini_modrf.py:62 derives nsamp = 2^ceil(log2(2 ndata)) with no upper bound; here one workgroup holds a
-    // model's half-length complex spectrum in LDS: up to 16384 samples (observed traces of up to 8192 samples)
-    if (bh_rf_lds_bytes(nsamp) > BH_RF_MAX_LDS)
-        return fail(e, BH_EUNSUPPORTED, "nsamp above 16384 is not supported (the spectrum of one model must fit a CU's 160 KB of LDS)");
+    // rfmini_modrf.py:62 derives nsamp = 2^ceil(log2(2 ndata)) with no upper bound; here one workgroup holds a model's
+    // half-length complex spectrum in LDS up to 16384 samples and in an HBM workspace beyond, up to 2^18 samples
+    if (nsamp > BH_RF_MAX_NSAMP)
+        return fail(e, BH_EUNSUPPORTED, "nsamp above 262144 is not supported");
     if (nkeep < 0 || nkeep > nsamp) return fail(e, BH_EINVAL, "nkeep must be 0..nsamp");
     if (!(gauss > 0.0) || !(fsamp > 0.0)) return fail(e, BH_EINVAL, "gauss and fsamp must be > 0");
     if (waveno != BH_RF_P && waveno != BH_RF_SV) return fail(e, BH_EINVAL, "waveno must be 0 (P) or 1 (SV)");
@@ -954,7 +958,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard, &e->rfz})
         release(*b);
     for (auto &t : e->targets) {
         release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);

@@ -660,7 +660,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // Twiddles: w^k = TW1[k >> 6] TW0[k & 63] (two small tables instead of N/4 entries: one more complex product per
 // butterfly, 1-3 KB of LDS instead of 8-64 KB).  LDS per workgroup: 8 N + 16 + 1024 + N/8 bytes --
 // 17.7 KB at nsamp = 2048 (round 2: 40 KB), 134 KB at nsamp = 16384, the largest trace one workgroup holds.
-template <bool BESIDE>
+// GLOBALZ: the half-length spectrum lives in the model's slice of A.zwork (HBM / L2) instead of LDS -- traces longer than a
+// workgroup's LDS holds (nsamp > 16384).  Same bins, same butterflies, same order; a workgroup's barrier orders its own
+// global accesses (all its wavefronts share the CU's cache).
+template <bool BESIDE, bool GLOBALZ = false>
 __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, int jcut)
 {
     if (BESIDE) { // issue priority of a wavefront that runs beside dispersion wavefronts (those alternate between 3 and 1)
@@ -671,8 +674,8 @@ __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, i
     }
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = A.nsamp, M = N / 2;
-    double2 *z = reinterpret_cast<double2 *>(smem);       // [M]
-    double2 *nyq = z + M;                                  // [1]   Re X[N/2]
+    double2 *z = GLOBALZ ? reinterpret_cast<double2 *>(A.zwork) + (size_t)blockIdx.x * (size_t)M : reinterpret_cast<double2 *>(smem); // [M]
+    double2 *nyq = GLOBALZ ? reinterpret_cast<double2 *>(smem) : z + M;                                                               // [1]   Re X[N/2]
     double2 *tw0 = nyq + 1;                                // [64]  w^r
     double2 *tw1 = tw0 + 64;                               // [max(1, N/128)]  w^(64 q)
     const int ib = blockIdx.x;
@@ -817,6 +820,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // 96 registers: what two dispersion wavefronts of 208 leave of a SIMD's 512.  In the fused call (bh_evaluate_batch) one
 // such workgroup per CU runs BESIDE the dispersion kernel's eight wavefronts, at the lowest issue priority: it takes the
 // issue slots those leave idle (their FP64 pipe is busy 62 % of the time) instead of waiting for them to end.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_synth_kernel_long(RfKernelArgs A, int logm, int jcut)
+{
+    rf_synth_body<false, true>(A, logm, jcut);
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rf_synth_kernel_beside(RfKernelArgs A, int logm, int jcut)
 {
     rf_synth_body<true>(A, logm, jcut);
@@ -842,7 +849,13 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     int logm = 0;
     while ((1 << logm) < half) ++logm;
     size_t lds = bh_rf_lds_bytes(a.nsamp); // half-length complex spectrum + Nyquist bin + two twiddle tables
-    if (lds > BH_RF_MAX_LDS) return -1;
+    const bool longtrace = lds > BH_RF_MAX_LDS;
+    if (longtrace) {
+        if (a.zwork == nullptr || a.nsamp > BH_RF_MAX_NSAMP) return -1;
+        lds -= (size_t)(a.nsamp / 2) * 16; // (the spectrum is in the workspace)
+        a.lds_min = 0;
+        a.beside = 0;
+    }
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;
     if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit: a workgroup may take the CU's whole 160 KB
         static std::atomic<unsigned long long> allowed{0};
@@ -870,7 +883,9 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     const double dw = 2.0 * M_PI * a.fsamp / a.nsamp;
     const double jc = std::floor(RF_CUT_WA * a.gauss / dw) + 1.0;
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
-    if (a.beside)
+    if (longtrace)
+        hipLaunchKernelGGL(rf_synth_kernel_long, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
+    else if (a.beside)
         hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else if (tun.rf_waves == 3)
         hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);

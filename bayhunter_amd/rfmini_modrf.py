@@ -33,7 +33,7 @@ class RFminiModRF(object):
             self._engine = _engine.default_engine()
         return self._engine
 
-    MAX_NSAMP = 16384   # transform length the synthesis kernel holds in a workgroup's LDS (csrc/rf_kernel.hip: bh_rf_lds_bytes)
+    MAX_NSAMP = 1 << 18   # longest transform of the synthesis kernel (csrc/bh_device.h: BH_RF_MAX_NSAMP)
 
     def _init_obsparams(self):
         """fsamp [Hz], tshft [s], nsamp (power of two >= 2*ndata); rfmini_modrf.py:41-62."""
@@ -43,10 +43,10 @@ class RFminiModRF(object):
         self.fsamp = 1.0 / float(steps[0])
         self.tshft = -self.obsx[0]
         self.nsamp = 2 ** int(np.ceil(np.log2(self.obsx.size * 2)))
-        # The reference has no bound here (rfmini_modrf.py:62; fork.cpp:11-60 transforms any power of two).  The engine's
-        # synthesis kernel keeps the whole spectrum of a trace in ONE workgroup's LDS (8 N + N / 8 + 1 KB of a CU's 160 KB):
-        # nsamp <= MAX_NSAMP = 16384, i.e. observed traces of up to 8192 samples.  Longer ones would need a four-step FFT through
-        # HBM; they are refused here, by name, before any native call (the C ABI answers BH_EUNSUPPORTED).
+        # The reference has no bound here (rfmini_modrf.py:62; fork.cpp:11-60 transforms any power of two).  The engine's synthesis
+        # kernel keeps the spectrum of a trace in ONE workgroup's LDS up to nsamp = 16384 (observed traces of up to 8192 samples) and in
+        # an HBM workspace beyond, up to MAX_NSAMP = 262144 (131072 observed samples); longer ones are refused here, by name, before
+        # any native call (the C ABI answers BH_EUNSUPPORTED).
         if self.nsamp > self.MAX_NSAMP:
             raise ValueError("Target: %s. %d observed samples need a transform of %d points; the MI355X engine's receiver-function "
                              "kernel holds at most MAX_NSAMP = %d (observed traces of up to %d samples)."

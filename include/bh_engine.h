@@ -212,7 +212,7 @@ int bh_swd_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax, cons
 
 /* ---- receiver function: replaces synrf_cwrap (rfmini/wrap.cpp:58-80) ----------------------
  * For each of B models: the (Q-component) receiver function for incident `waveno`, ray
- * parameter p [s/deg], Gauss parameter `gauss`, nsamp (power of two) samples at fsamp [Hz],
+ * parameter p [s/deg], Gauss parameter `gauss`, nsamp (power of two, 4 ... 262144; BH_EUNSUPPORTED above) samples at fsamp [Hz],
  * time origin shifted by tshift [s]; the first nkeep <= nsamp samples are returned, which is
  * what rfmini_modrf.py:142 keeps.  Depths of layer tops are cumsum(h) as in
  * rfmini_modrf.py:119-123.  qp/qs: per-layer quality factors with the model-array strides, or

@@ -42,9 +42,10 @@ def test_rf_sampling_parameters():
     with pytest.raises(ValueError):
         bh.RFminiModRF(np.array([0., 1., 2.5]), "prf")
     # the engine's cap on the transform length (the reference has none, rfmini_modrf.py:62): named before any native call
-    assert bh.RFminiModRF(-5 + 0.01 * np.arange(8192), "prf").nsamp == 16384 == bh.RFminiModRF.MAX_NSAMP
-    with pytest.raises(ValueError, match="MAX_NSAMP = 16384"):
-        bh.RFminiModRF(-5 + 0.01 * np.arange(8193), "prf")
+    assert bh.RFminiModRF(-5 + 0.01 * np.arange(8193), "prf").nsamp == 32768        # (beyond 16384: the kernel's HBM workspace path)
+    assert bh.RFminiModRF(-5 + 0.01 * np.arange(131072), "prf").nsamp == 262144 == bh.RFminiModRF.MAX_NSAMP
+    with pytest.raises(ValueError, match="MAX_NSAMP = 262144"):
+        bh.RFminiModRF(-5 + 0.01 * np.arange(131073), "prf")
 
 
 def test_surfdisp_tags_and_resampling_grid():
