@@ -171,6 +171,8 @@ struct SwdLaunchInfo {
 // the launches of the builds with the fast arithmetic (swd_group_fa.hip); called by bh_launch_swd_group
 void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
                             bool adapt, bool counted, bool cntb);
+// the launches of the builds with the certified-sign scan (swd_group_prek.hip); called by bh_launch_swd_group
+void bh_launch_swd_group_prek(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds, int build);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
                         SwdPairWork *pair = nullptr);
 // swd_lean.hip: fundamental-mode phase velocities with the fast arithmetic, one lane per trial velocity (the kernel of the

@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // 96 registers: what two dispersion wavefronts of 208 leave of a SIMD's 512.  In the fused call (bh_evaluate_batch) one
 // such workgroup per CU runs BESIDE the dispersion kernel's eight wavefronts, at the lowest issue priority: it takes the
 // issue slots those leave idle (their FP64 pipe is busy 62 % of the time) instead of waiting for them to end.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rf_synth_kernel_long(RfKernelArgs A, int logm, int jcut)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rf_synth_kernel_long(RfKernelArgs A, int logm, int jcut)
 {
     rf_synth_body<false, true>(A, logm, jcut);
 }

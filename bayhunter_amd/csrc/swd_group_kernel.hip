@@ -927,7 +927,7 @@ restart_with_the_reference_sequence:
     }
 }
 
-#ifndef BH_GROUP_FA_TU
+#if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_PREK_TU)
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / (G * J);
@@ -940,7 +940,17 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 
 } // namespace
 
-#ifdef BH_GROUP_FA_TU
+#ifdef BH_GROUP_PREK_TU
+// The launches of the builds with the certified-sign scan (this translation unit: swd_group_prek.hip, ONE wavefront per SIMD:
+// the out-of-line evaluation needs more registers than two wavefronts per SIMD leave -- at two, these builds spilled).
+void bh_launch_swd_group_prek(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds, int build)
+{
+    if (build == -1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, true, true, true, true>), grid, block, lds, stream, a, redundant, wave_lds); // (see bh_launch_swd_group)
+    else if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
+    else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
+    else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
+}
+#elif defined(BH_GROUP_FA_TU)
 // The launches of the builds with the fast arithmetic (this translation unit: swd_group_fa.hip).
 void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
                             bool adapt, bool counted, bool cntb)
@@ -1252,10 +1262,8 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     if (info != nullptr) info->fast_arith = a.farith;
     if (farith) {
         bh_launch_swd_group_fa(a, grid, block, lds, stream, redundant, (int)wave_lds, adapt, counted, cntb);
-    } else if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel)
-        if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
-        else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0, false, true, false, false, true>), grid, block, lds, stream, a, redundant, (int)wave_lds);
+    } else if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel), compiled in swd_group_prek.hip
+        bh_launch_swd_group_prek(a, grid, block, lds, stream, redundant, (int)wave_lds, build);
     } else if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
         static std::atomic<unsigned long long> big_lds{0};
         if (lds > WG_LDS_CAP) {
@@ -1270,7 +1278,10 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
         else BH_GROUP_LAUNCH_ADAPT(2, false);
     } else if (adapt && build == 1) { // (both sequences in one launch: Rayleigh targets short, Love targets the reference's)
-        if (counted) BH_GROUP_LAUNCH_ADAPT(1, true);
+        // (the instrumented build with both sequences AND the counted scan needs more than 256 registers: it is compiled with
+        //  the one-wavefront-per-SIMD budget of swd_group_prek.hip -- counters and clocks are what it is for, not speed)
+        if (counted && cntb) bh_launch_swd_group_prek(a, grid, block, lds, stream, redundant, (int)wave_lds, -1);
+        else if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
         else BH_GROUP_LAUNCH_ADAPT(1, false);
     } else if (adapt) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(0, true);
