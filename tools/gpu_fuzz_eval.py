@@ -3,7 +3,9 @@
 (dispersion types, P/SV receiver functions), noise laws (uncorrelated, scaled errors, exponential), noise
 values, ragged batches (dev tool; the fixed cases live in tests/).
     python tools/gpu_fuzz_eval.py SEED NCONFIG           the reference's sequence against the oracle's (1e-8 on logL and misfits)
-    FAST=1 python tools/gpu_fuzz_eval.py SEED NCONFIG    the engine's default search (joint launches: short refinement, counted
+    LEAN=1 python tools/gpu_fuzz_eval.py SEED NCONFIG    the engine's defaults (short refinement + fast arithmetic) against the
+                                                         reference sequence: misfits, failure pattern
+    FAST=1 python tools/gpu_fuzz_eval.py SEED NCONFIG    the short refinement with the reference's arithmetic (joint launches: short refinement, counted
                                                          Love scan where BH_SCAN_AUTO picks it) against its CPU restatement, and
                                                          the failure pattern against the reference sequence's"""
 import os, sys, time
@@ -14,8 +16,11 @@ from bayhunter_amd.synth import synth_models
 from oracle import oracle as O
 
 eng = E.Engine(0)
-FAST = os.environ.get("FAST", "0") == "1"
+LEAN = os.environ.get("LEAN", "0") == "1"   # the engine's defaults (short refinement + fast arithmetic): misfits within 3e-5 absolute of the
+FAST = os.environ.get("FAST", "0") == "1" or LEAN   # reference sequence's (velocities move by <= 2e-6 relative), the same failure pattern
 eng.set_swd_search("fast" if FAST else "reference")     # (the comparison below is against the oracle's same sequence, bit-level arithmetic)
+eng.set_swd_arith("fast" if LEAN else "exact")
+nlean = 0
 flagdiff = 0
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -52,15 +57,27 @@ for it in range(ncfg):
     with O.swd_search(2 if FAST else 0):
         oL, om = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
     if FAST:   # the failure pattern is the reference sequence's
-        rL, _ = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
+        rL, rm = O.joint_batch(nlay, h.T, vp.T, vs.T, rho.T, spec, noise)
         flagdiff += int(((rL <= -1e14) != (logL <= -1e14)).sum())
+    if LEAN:
+        nlean += int(eng.last_swd_kernel() == "lean")
+        okm = (rL > -1e14) & (logL > -1e14)
+        dm = float(np.max(np.abs(misf[okm] - rm[okm]))) if okm.any() else 0.0
+        worst = max(worst, dm)
+        if dm > 3e-5:
+            bad += 1
+            print("MISMATCH", it, dict(B=B, L=L, nt=nt), [(s["kind"], s["law"], s["n"]) for s in spec], dm, flush=True)
+        continue
     relL = np.max(np.abs(logL - oL) / np.maximum(1.0, np.abs(oL)))
     relm = np.max(np.abs(misf - om) / np.maximum(1e-30, np.abs(om)))
     worst = max(worst, relL, relm)
     if not (relL <= 1e-8 and relm <= 1e-8):
         bad += 1
         print("MISMATCH", it, dict(B=B, L=L, nt=nt), [(s["kind"], s["law"], s["n"]) for s in spec], relL, relm, flush=True)
-print("%d configurations, %d beyond 1e-8, worst relative difference %.2e" % (ncfg, bad, worst))
+if LEAN:
+    print("%d configurations (%d on the trial-per-lane kernel), %d beyond 3e-5 absolute in a misfit, worst %.2e" % (ncfg, nlean, bad, worst))
+else:
+    print("%d configurations, %d beyond 1e-8, worst relative difference %.2e" % (ncfg, bad, worst))
 if FAST:
     print("failure patterns differing from the reference sequence's: %d" % flagdiff)
     bad += flagdiff
