@@ -36,6 +36,7 @@
     X(swd_redundant,     "BH_SWD_REDUNDANT",      0, "flag: every lane of a group runs the whole Rayleigh recursion")                                \
     X(swd_no_lean,       "BH_SWD_NO_LEAN",        0, "flag: fast-arithmetic launches take the group / lane kernels' FA builds, not the trial-per-lane kernel") \
     X(swd_lean_pairs,    "BH_SWD_LEAN_PAIRS",     0, "trial-per-lane kernel: largest call in (model, target) pairs that takes it (0 = 2^20)")        \
+    X(swd_lean_no_sort,  "BH_SWD_LEAN_NO_SORT",   0, "flag: trial-per-lane kernel: models by depth only, not by predicted search length")           \
     X(swd_lean_r,        "BH_SWD_LEAN_R",         0, "trial-per-lane kernel: trials per round of Rayleigh targets, power of two 4..64 (0 = planned)")  \
     X(swd_lean_l,        "BH_SWD_LEAN_L",         0, "trial-per-lane kernel: trials per round of Love targets (0 = planned)")                         \
     X(no_order,          "BH_NO_ORDER",           0, "flag: models processed in the caller's order")                                                 \
