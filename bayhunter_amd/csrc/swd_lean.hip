@@ -120,10 +120,16 @@ __device__ __forceinline__ void lean_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef BH_LEAN_CLUSTER_W
+#define BH_LEAN_CLUSTER_W 2.0e-7
+#endif
+#ifndef BH_LEAN_CLUSTER
+#define BH_LEAN_CLUSTER 2 // lanes of the cluster of trials when the next period's window rides along (16 lanes per model and more)
+#endif
 constexpr int LEAN_WPB = 4; // wavefronts per workgroup: independent (no barrier), one per SIMD of the CU the workgroup lands on
 
 template <int J> // trials per model and round: 4, 8, 16, 32 or 64 lanes = one model
-__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds)
+__global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds, int flip)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
     if (A.started != nullptr && threadIdx.x == 0) atomicAdd(A.started, 1u);
@@ -135,9 +141,15 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     if (A.wg_n1 > 0) {
         const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
         if (wid >= (int)N) return;
-        const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
-        ty = (l1 > l0) ? 1 : 0;
-        wid = (l1 > l0) ? l0 : wid - l0;
+        if ((flip & 255) > 0 && A.wg_n0 == A.wg_n1) { // (experiment) which of a pair of wavefronts is the second target's alternates with the workgroup's slot
+            ty = (wid + (int)(blockIdx.x >> ((flip & 255) - 1))) & 1;
+            wid = wid >> 1;
+        } else {
+            const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
+            ty = (l1 > l0) ? 1 : 0;
+            wid = (l1 > l0) ? l0 : wid - l0;
+        }
+        if ((flip & 256) && ty == 1) wid = A.wg_n1 - 1 - wid; // (experiment) the second target's models in the opposite order
     }
     const SwdTarget T = A.t[ty];
     constexpr int MPW = BH_WAVE / J; // models per wavefront
@@ -240,15 +252,19 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         iom = fa::rcp(omega);
     }
     constexpr unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
-    // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG.  The estimate x that a round of clustered trials is centred on is, 99 times
-    // in 100, within 2e-7 |x| of the root it then finds.  So only the lower half of the model's lanes carry the cluster; the upper
-    // half evaluates -- at the NEXT period's frequency -- the first round of the next period's scan on the grid anchored at
-    // x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x, those values ARE the next period's first
-    // round (its grid is anchored 2.5e-7 relative off the root: the reference's own root is known to 1e-6, and the guard covers
-    // grids that differ by 3e-6); otherwise they are dropped.  Two rounds per period instead of three.
-    constexpr int H = J / 2;
+    // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG.  The estimate x that a round of clustered trials is centred on -- the inverse
+    // quadratic point through the bracket's ends and the grid point before them -- is within 1e-7 |x| of the root 99 times in
+    // 100 (the scaled secular function is that smooth over three grid steps; measured on the bench's models).  So with the next
+    // period's window beside it the cluster is only NC = 2 lanes, x -+ 2e-7 |x| (a cluster that misses falls back to the J-section
+    // and the full cluster), and the other NR = J - NC lanes evaluate -- at the NEXT period's frequency -- the first round of
+    // the next period's scan on the grid anchored at x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within
+    // 2.5e-7 |x| of x, those values ARE the next period's first round (its grid is anchored 2.5e-7 relative off the root: the
+    // reference's own root is known to 1e-6, and the guard covers grids that differ by 3e-6); otherwise they are dropped.  The
+    // bench's sign change is 14.5 steps from the start value on average: a window of 14 lanes reaches it in 59 % of the periods
+    // (one round for the period), the rest take a second round of J steps.
+    constexpr int NC = (J >= 8) ? BH_LEAN_CLUSTER : J / 2, NR = J - NC;
     constexpr bool can_spec = J >= 4; // (every trial count the launcher offers)
-    constexpr unsigned long long maskH = (1ull << H) - 1ull;
+    constexpr unsigned long long maskC = (1ull << NC) - 1ull, maskR = (1ull << NR) - 1ull;
     const double invJ1 = 1.0 / (double)(J + 1);
     unsigned nrounds = 0;
     long long t_eval = 0;
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         double cev = c1, cprev = c1; // cprev: the grid point before a scan trial
         double om_l = omega, iom_l = iom;
         bool pt = false;             // this lane's value takes part in the refinement's decision
-        bool spec = false;           // the upper half of this model's lanes carries the next period's first round
+        bool spec = false;           // the model's lanes beyond the cluster's carry the next period's first round
         double xc = 0.0;             // centre of the cluster
         const int ph0 = ph;          // the phase this round's trials were laid out for
         if (ph <= PH_SCAN) {
@@ -302,14 +318,14 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             }
             spec = can_spec && k + 1 < K;
             xc = x;
-            const int nc = spec ? H : J; // lanes of the cluster
+            const int nc = spec ? NC : J; // lanes of the cluster
             if (r < nc) {
                 const int h = nc / 2;
-                const double w = 1.0e-7 * fabs(x);
+                const double w = ((spec && NC == 2) ? BH_LEAN_CLUSTER_W : 1.0e-7) * fabs(x);
                 cev = (r < h) ? x - __builtin_ldexp(w, 2 * (h - 1 - r)) : x + __builtin_ldexp(w, 2 * (r - h));
                 pt = cev > lo && cev < hi;
             } else { // the next period's first round on the grid anchored at the estimate (k + 1 >= 1: clow = cm)
-                const int s_ = r - H;
+                const int s_ = r - NC;
                 const double c1n = x - onea * dc;
                 const double basen = (c1n + dc <= cm) ? cm : c1n;
                 cprev = __builtin_fma((double)(s_ - 1), dc, basen);
@@ -336,15 +352,15 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const unsigned long long mneg = (__ballot(dneg) >> lbase) & maskJ;
         const unsigned long long m_small = (__ballot(!(fabs(del) >= fa::SIGN_FLOOR)) >> lbase) & maskJ;
         const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
-        const bool inB = ph == PH_REFC && spec && r >= H;
+        const bool inB = ph == PH_REFC && spec && r >= NC;
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
         if (ph <= PH_SCAN || inB) {
             const bool first = ph == PH_START || inB;        // the window is a period's first round: trial 0 = the start value,
-            const int rr = inB ? r - H : r;                  // the steps upward (consumed only if the start value says so)
+            const int rr = inB ? r - NC : r;                 // the steps upward (consumed only if the start value says so)
             if (!(first && rr == 0)) {
                 const bool down = !first && idir < 0;
                 const double a_ = fmin(cprev, cev), b_ = fmax(cprev, cev);
-                const bool refneg = inB ? ((mneg >> H) & 1ull) != 0ull : (first ? (mneg & 1ull) != 0ull : sign_neg(del1));
+                const bool refneg = inB ? ((mneg >> NC) & 1ull) != 0ull : (first ? (mneg & 1ull) != 0ull : sign_neg(del1));
                 const double floor_ = inB ? cm : clow;
                 if (down && cev <= floor_) ev = 1;
                 else if (dneg != refneg) ev = 2;
@@ -355,9 +371,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             ev = (pt && dneg != sign_neg(flo)) ? 2 : 0;
         }
         const unsigned long long m_ev = (__ballot(ev != 0) >> lbase) & maskJ;
-        // stage 1: the refinement's window A = all J lanes, or the cluster's H
-        const int nA = (ph == PH_REFC && spec) ? H : J;
-        const unsigned long long m_evA = (ph == PH_REFC && spec) ? (m_ev & maskH) : m_ev;
+        // stage 1: the refinement's window A = all J lanes, or the cluster's NC
+        const int nA = (ph == PH_REFC && spec) ? NC : J;
+        const unsigned long long m_evA = (ph == PH_REFC && spec) ? (m_ev & maskC) : m_ev;
         const int eA = m_evA ? (int)__builtin_ctzll(m_evA) : nA; // first trial beyond the sign change (nA: none)
         const int r0 = m_pt ? (int)__builtin_ctzll(m_pt) : 0, r1 = m_pt ? 63 - (int)__builtin_clzll(m_pt) : -1; // the trials that take part: one run of lanes
         const int i3 = (eA < nA) ? ((eA + 1 <= r1) ? eA + 1 : eA - 2) : r1 - 1; // a third point next to the new bracket
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 // the velocity of trial i of this round's window A
                 const double olo = lo, ohi = hi, oflo = flo, ofhi = fhi;
                 const int nc = nA, h = nc / 2;
-                const double w = 1.0e-7 * fabs(xc);
+                const double w = ((nA == 2) ? BH_LEAN_CLUSTER_W : 1.0e-7) * fabs(xc);
                 const bool sect = ph == PH_REF1;
                 auto ctrial = [&](int i) -> double {
                     return sect ? __builtin_fma(ohi - olo, (double)(i + 1) * invJ1, olo)
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                             c1 = xc - onea * dc; // (the grid they evaluated)
                             scan_now = true;
                             sc_first = true;
-                            w0 = H;
+                            w0 = NC;
                         }
                     }
                 }
@@ -496,8 +512,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             }
         }
         // stage 2: the scan window [w0, w0 + wn) of the models that consume one this round
-        const int wn = (w0 != 0) ? H : J;
-        const unsigned long long m_evS = (w0 != 0) ? ((m_ev >> H) & maskH) : m_ev;
+        const int wn = (w0 != 0) ? NR : J;
+        const unsigned long long m_evS = (w0 != 0) ? ((m_ev >> NC) & maskR) : m_ev;
         const int e = m_evS ? (int)__builtin_ctzll(m_evS) : wn; // first event among the window's trials (wn: none)
         const int wb = lbase + w0;
         const int ev_e = __shfl(ev, wb + (e < wn ? e : wn - 1));
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                      d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb);
         if (active && scan_now) {
             const bool start = sc_first;
-            const unsigned long long msm = (w0 != 0) ? ((m_small >> H) & maskH) : m_small;
+            const unsigned long long msm = (w0 != 0) ? ((m_small >> NC) & maskR) : m_small;
             // the velocity of trial t of the window (what its lane evaluated)
             const double base = (start && c1 + dc <= clow) ? clow : c1;
             const double step = (start || idir > 0) ? dc : -dc;
@@ -685,15 +701,16 @@ int bh_launch_swd_lean(const SwdMultiArgs &a0, hipStream_t stream, SwdLaunchInfo
         info->fast_arith = 1;
         info->restarts_in_place = 0;
     }
+    const int flip = bh_tuning().swd_lean_flip;
     const int J = a.t[0].look; // (one trial count per launch: the kernel is compiled per count)
     for (int t = 1; t < a.ntargets; ++t)
         if (a.t[t].look != J) return -1;
     switch (J) {
-    case 4: hipLaunchKernelGGL(swd_lean_kernel<4>, grid, block, lds, stream, a, (int)wave_lds); break;
-    case 8: hipLaunchKernelGGL(swd_lean_kernel<8>, grid, block, lds, stream, a, (int)wave_lds); break;
-    case 16: hipLaunchKernelGGL(swd_lean_kernel<16>, grid, block, lds, stream, a, (int)wave_lds); break;
-    case 32: hipLaunchKernelGGL(swd_lean_kernel<32>, grid, block, lds, stream, a, (int)wave_lds); break;
-    default: hipLaunchKernelGGL(swd_lean_kernel<64>, grid, block, lds, stream, a, (int)wave_lds); break;
+    case 4: hipLaunchKernelGGL(swd_lean_kernel<4>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
+    case 8: hipLaunchKernelGGL(swd_lean_kernel<8>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
+    case 16: hipLaunchKernelGGL(swd_lean_kernel<16>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
+    case 32: hipLaunchKernelGGL(swd_lean_kernel<32>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
+    default: hipLaunchKernelGGL(swd_lean_kernel<64>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
     }
     return 0;
 }
