@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     if (A.wg_n1 > 0) {
         const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
         if (wid >= (int)N) return;
-        if ((flip & 255) > 0 && A.wg_n0 == A.wg_n1) { // (experiment) which of a pair of wavefronts is the second target's alternates with the workgroup's slot
+        if ((flip & 255) > 0 && A.wg_n0 == A.wg_n1) { // (experiment: with bit 8 of the workgroup index the two wavefronts of a SIMD become the same target's: 0.80 ms)
             ty = (wid + (int)(blockIdx.x >> ((flip & 255) - 1))) & 1;
             wid = wid >> 1;
         } else {
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             ty = (l1 > l0) ? 1 : 0;
             wid = (l1 > l0) ? l0 : wid - l0;
         }
-        if ((flip & 256) && ty == 1) wid = A.wg_n1 - 1 - wid; // (experiment) the second target's models in the opposite order
+        // The second target takes the models in the OPPOSITE order: the wavefronts run longest search first (bh_launch_pair_order), and
+        // the wavefront that shares a SIMD with the longest Rayleigh searches should be the one with the shortest Love searches
+        // (c2: 0.668 -> 0.656 ms/step).  Scheduling only.
+        if ((flip & 256) && ty == 1) wid = A.wg_n1 - 1 - wid;
     }
     const SwdTarget T = A.t[ty];
     constexpr int MPW = BH_WAVE / J; // models per wavefront
