@@ -123,6 +123,9 @@ __device__ __forceinline__ void lean_wave_sync()
 #ifndef BH_LEAN_CLUSTER_W
 #define BH_LEAN_CLUSTER_W 2.0e-7
 #endif
+#ifndef BH_LEAN_CLUSTER_BIG
+#define BH_LEAN_CLUSTER_BIG 8 // the same with 32 and 64 lanes per model
+#endif
 #ifndef BH_LEAN_CLUSTER
 #define BH_LEAN_CLUSTER 2 // lanes of the cluster of trials when the next period's window rides along (16 lanes per model and more)
 #endif
@@ -256,16 +259,20 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     }
     constexpr unsigned long long maskJ = (J >= 64) ? ~0ull : ((1ull << J) - 1ull);
     // THE NEXT PERIOD'S FIRST ROUND RIDES ALONG.  The estimate x that a round of clustered trials is centred on -- the inverse
-    // quadratic point through the bracket's ends and the grid point before them -- is within 1e-7 |x| of the root 99 times in
-    // 100 (the scaled secular function is that smooth over three grid steps; measured on the bench's models).  So with the next
-    // period's window beside it the cluster is only NC = 2 lanes, x -+ 2e-7 |x| (a cluster that misses falls back to the J-section
-    // and the full cluster), and the other NR = J - NC lanes evaluate -- at the NEXT period's frequency -- the first round of
-    // the next period's scan on the grid anchored at x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within
-    // 2.5e-7 |x| of x, those values ARE the next period's first round (its grid is anchored 2.5e-7 relative off the root: the
-    // reference's own root is known to 1e-6, and the guard covers grids that differ by 3e-6); otherwise they are dropped.  The
+    // quadratic point through the bracket's ends and the grid point before them -- is within 2e-7 |x| of the root in 99.9 %
+    // (Rayleigh) / 99 % (Love) of the periods of the bench's models (tools/cpu_scan_steps.py): the scaled secular function is that
+    // smooth over three grid steps, except next to a layer velocity.  So with the next period's window beside it the cluster is
+    // only NC lanes and the other NR = J - NC lanes evaluate -- at the NEXT period's frequency -- the first round of the next
+    // period's scan on the grid anchored at x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x,
+    // those values ARE the next period's first round (its grid is anchored 2.5e-7 relative off the root: the reference's own root
+    // is known to 1e-6, and the guard covers grids that differ by 3e-6); otherwise they are dropped.
+    //   NC: with 8 or 16 lanes per model 2 (x -+ 2e-7 |x|; a miss costs two rounds: J-section, then the cluster again).  The
     // bench's sign change is 14.5 steps from the start value on average: a window of 14 lanes reaches it in 59 % of the periods
-    // (one round for the period), the rest take a second round of J steps.
-    constexpr int NC = (J >= 8) ? BH_LEAN_CLUSTER : J / 2, NR = J - NC;
+    // (one round for the period), the rest take a second round of 16 steps -- c2 with clusters of 2 / 4 / 8 lanes: 0.66 / 0.70 /
+    // 0.76 ms.  With 32 and 64 lanes 8 (x -+ 1e-7 |x| 4^i, i < 4): that is where a sampler's windows run, whose models (up to 20
+    // thin layers, any order of velocities) have a layer velocity next to every tenth root -- 8 chains with clusters of
+    // 2 / 4 / 8 / 16 lanes: 66.6 / 70.0 / 73.1 / 73.1 thousand iterations/s (B = 2048 of the bench's models: 0.478 / 0.489 / 0.500 / 0.556 ms).
+    constexpr int NC = (J >= 32) ? BH_LEAN_CLUSTER_BIG : ((J >= 8) ? BH_LEAN_CLUSTER : J / 2), NR = J - NC;
     constexpr bool can_spec = J >= 4; // (every trial count the launcher offers)
     constexpr unsigned long long maskC = (1ull << NC) - 1ull, maskR = (1ull << NR) - 1ull;
     const double invJ1 = 1.0 / (double)(J + 1);

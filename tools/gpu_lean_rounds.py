@@ -10,6 +10,16 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 eng = E.Engine(0)
 rs = np.random.RandomState(5)
 nlay, h, vp, vs, rho = synth_models(rs, B, 10, lvz_frac=0.1)
+if os.environ.get("MODELS", "") == "prior":   # what a sampler proposes: 2..20 layers, unsorted vs in (2, 5), interfaces anywhere in (0, 60) km
+    Lm = 20
+    nlay = rs.randint(2, Lm + 1, B).astype(np.int32)
+    h = np.zeros((Lm, B)); vp = np.zeros((Lm, B)); vs = np.zeros((Lm, B)); rho = np.zeros((Lm, B))
+    for b in range(B):
+        n = int(nlay[b])
+        z = np.sort(rs.uniform(0, 60, n - 1)) if n > 1 else np.zeros(0)
+        hh = np.diff(np.concatenate(([0.0], z)))
+        v = rs.uniform(2, 5, n); k = rs.uniform(1.4, 2.1)
+        h[:n - 1, b] = np.maximum(hh, 0.1); vs[:n, b] = v; vp[:n, b] = v * k; rho[:n, b] = 0.32 * v * k + 0.77
 yobs = 3.4 + 0.01 * SWD_PERIODS
 eng.set_targets([dict(kind=E.TARGET_SWD, law=0, n=30, x=SWD_PERIODS, yobs=yobs, iwave=2, igr=0),
                  dict(kind=E.TARGET_SWD, law=0, n=30, x=SWD_PERIODS, yobs=yobs, iwave=1, igr=0)])
