@@ -138,7 +138,7 @@ def test_the_lane_per_evaluation_kernel_with_the_fast_arithmetic(lean, oracle, r
     check_against_the_reference(v4, e4, ov, oe)
 
 
-@pytest.mark.parametrize("trials", [4, 8, 16, 64])
+@pytest.mark.parametrize("trials", [4, 8, 16, 32, 64])
 def test_every_trial_count_keeps_the_guarantees(lean, oracle, trials):
     """bh_engine_set_swd_trials: 4 / 8 trials per round, 32 / 64 (two models or one per wavefront) -- the same flags, zero rows and tolerance; the setting is validated and restored."""
     from bayhunter_amd.engine import EngineError
