@@ -157,6 +157,9 @@ struct PairOrderTarget {
     int mpw, nwaves;          // models per wavefront, wavefronts of the target
     const int32_t *slot_rank; // [nwaves - 1]: load rank of every wavefront but the last (which may be partly filled)
     int32_t *perm;            // out [B]
+    int xcd;                  // trial-per-lane kernel: > 0 = the order is sorted inside eight blocks of the batch, block x handed to the
+                              // wavefronts that run on XCD x (workgroup index mod 8); the value = wavefronts of this target per workgroup (4, or 2
+                              // where two targets alternate): every XCD's L2 then sees an eighth of the model arrays
 };
 bool bh_pair_order_fits(int B);
 void bh_launch_pair_order(int B, int Lmax, const int32_t *nlay, const double *vs, ptrdiff_t sl, ptrdiff_t sb, int nt,

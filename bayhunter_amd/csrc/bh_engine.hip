@@ -509,7 +509,13 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             // The trial-per-lane kernel: the models in the order of their PREDICTED search length, longest first (mixed depths:
             // deepest first) -- wavefronts of like models idle fewer rounds on finished ones, and the long wavefronts are
             // dispatched first with the short ones filling the launch's tail (c2: 0.79 -> 0.72 ms).  Scheduling only.
-            PairOrderTarget tg{1, B, nullptr, p + 4};
+            // Sorted inside eight blocks of the batch, block x for the wavefronts of XCD x, where the shapes divide: each XCD's L2
+            // then fetches an eighth of the model arrays instead of all of them (HBM reads of the launch 10.7 -> 1.9 MB at c2).
+            PairOrderTarget tg{1, B, nullptr, p + 4, 0};
+            const int mpw = BH_WAVE / lean_trials, per_wg = (nlive == 2) ? 2 : 4;
+            if (bh_tuning().swd_lean_xcd != 0 && bh_tuning().swd_lean_r < 4 && bh_tuning().swd_lean_l < 4 && B % mpw == 0 && B % 8 == 0 &&
+                (B / mpw) % (8 * per_wg) == 0)
+                tg = PairOrderTarget{mpw, B / mpw, nullptr, p + 4, per_wg};
             bh_launch_pair_order(B, Lmax, m.nlay, m.vs, sl, sb, 1, &tg, st);
             perm = p + 4;
         } else {

@@ -320,12 +320,16 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(int B, int Lmax, const
     }
     __syncthreads();
     const bool ragged = nmin != nmax;
+    const bool blocked = !ragged && t0.xcd > 0; // (the launcher checked the divisibilities)
+    const int per = B / 8;                      // models of a block
     const float cmin = __uint_as_float(cmin_bits), cmax = __uint_as_float(cmax_bits);
     const float scale = (cmax > cmin) ? (float)(PAIR_BUCKETS - 1) / (cmax - cmin) : 0.0f;
     auto bucket = [&](int i) { // of this thread's i-th model
         if (ragged) return (nmax - depth[i]) < PAIR_BUCKETS ? (nmax - depth[i]) : PAIR_BUCKETS - 1; // deepest first
         int k = (int)((cmax - cost[i]) * scale); // longest first
-        return k < 0 ? 0 : (k > PAIR_BUCKETS - 1 ? PAIR_BUCKETS - 1 : k);
+        k = k < 0 ? 0 : (k > PAIR_BUCKETS - 1 ? PAIR_BUCKETS - 1 : k);
+        if (blocked) k = ((tid + 1024 * i) / per) * (PAIR_BUCKETS / 8) + (k >> 3); // block-major: eight sorted lists one after the other
+        return k;
     };
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i)
@@ -365,6 +369,11 @@ __global__ __launch_bounds__(1024) void pair_order_kernel(int B, int Lmax, const
             const int wid = pos / T.mpw, m = pos - wid * T.mpw;
             int src = pos; // the last (possibly partly filled) wavefront and mixed-depth batches: sorted order as it is
             if (!ragged && T.slot_rank != nullptr && wid < T.nwaves - 1) src = T.slot_rank[wid] * T.mpw + m;
+            if (blocked) { // wavefront wid runs on XCD x as that XCD's q-th wavefront of the target: the q-th group of block x
+                const int x = (T.xcd == 2) ? (wid >> 1) & 7 : (wid >> 2) & 7;
+                const int q = (T.xcd == 2) ? (((wid >> 4) << 1) | (wid & 1)) : (((wid >> 5) << 2) | (wid & 3));
+                src = x * per + q * T.mpw + m;
+            }
             T.perm[pos] = sorted[src];
         }
     }

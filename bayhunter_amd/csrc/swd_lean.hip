@@ -12,10 +12,11 @@
 //   * THE SCAN IS THE REFERENCE'S (getsol, :437-460): the same start value c(k-1) - 1.5 dc, the same grid (repeated additions of
 //     dc), the same direction rule, floor (clow), bounds (cm, betmx + dc) and first sign change -- but a round evaluates the
 //     next J grid points at once and the first event among them (sign change, bound, floor) is found with one ballot.
-//   * Inside the bracket the root is located by J-section (one round: the step of 0.005 km/s shrinks to dc / (J + 1)), then
-//     by a round of trials clustered geometrically (1e-7 |x| * 4^i) around the inverse-quadratic estimate; the root returned
-//     is the inverse-quadratic point of the final bracket (<= 1.3e-6 |c| wide, typically 2e-7) and its nearest neighbour.  The reference (nevill) stops at a
-//     bracket of 1e-6 c1 and returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
+//   * Inside the bracket the root is located by a round of trials clustered around the inverse-quadratic estimate through the
+//     bracket's ends and the grid point before them (1e-7 |x| * 4^i both sides; beside the next period's window the cluster is
+//     2 or 8 lanes, see the kernel), by J-section where a cluster does not close in; the root returned is the inverse-quadratic
+//     point of the final bracket (<= 1.3e-6 |c| wide, typically 4e-7).  The reference (nevill) stops at a bracket of 1e-6 c1 and
+//     returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
 //   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
 //     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
 //     contains betmx -- plus the rule of the fast arithmetic: a scan or probe value that is not a number or below fa::SIGN_FLOOR fires it.  A
@@ -155,7 +156,15 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         // The second target takes the models in the OPPOSITE order: the wavefronts run longest search first (bh_launch_pair_order), and
         // the wavefront that shares a SIMD with the longest Rayleigh searches should be the one with the shortest Love searches
         // (c2: 0.668 -> 0.656 ms/step).  Scheduling only.
-        if ((flip & 256) && ty == 1) wid = A.wg_n1 - 1 - wid;
+        if ((flip & 256) && ty == 1) {
+            if (flip & 2048) { // inside the wavefront's XCD (the models may be ordered per XCD, bh_launch_pair_order): its q-th wavefront of the
+                               // target takes the (Q - 1 - q)-th group
+                const int x = (wid >> 1) & 7, q = ((wid >> 4) << 1) | (wid & 1), qr = A.wg_n1 / 8 - 1 - q;
+                wid = ((qr >> 1) << 4) + 2 * x + (qr & 1);
+            } else {
+                wid = A.wg_n1 - 1 - wid;
+            }
+        }
     }
     const SwdTarget T = A.t[ty];
     constexpr int MPW = BH_WAVE / J; // models per wavefront
@@ -287,7 +296,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         bool pt = false;             // this lane's value takes part in the refinement's decision
         bool spec = false;           // the model's lanes beyond the cluster's carry the next period's first round
         double xc = 0.0;             // centre of the cluster
-        const int ph0 = ph;          // the phase this round's trials were laid out for
         if (ph <= PH_SCAN) {
             // The grid of getsol's scan (:437-446).  The reference forms it by repeated additions of dc; here point n is
             // base + n dc in one fused operation -- the two differ in the last bits (1e-16 relative: a thousandth of what the
@@ -622,7 +630,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 active = false;
             }
         }
-        (void)ph0;
     }
     if (writer) {
         T.err[ib] = errflag;
@@ -650,8 +657,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             atomicAdd(A.neval + (ifunc == 2 ? 12 : 13), (unsigned long long)t_eval); // cycles inside the secular evaluations
         }
         if (writer && guard) atomicAdd(A.neval + 14, 1ull << (8 * (greason & 7)) ); // guard reasons, a byte each
-        if (false) {
-        }
     }
 }
 } // namespace
@@ -711,7 +716,8 @@ int bh_launch_swd_lean(const SwdMultiArgs &a0, hipStream_t stream, SwdLaunchInfo
         info->fast_arith = 1;
         info->restarts_in_place = 0;
     }
-    const int flip = bh_tuning().swd_lean_flip;
+    int flip = bh_tuning().swd_lean_flip;
+    if (a.ntargets == 2 && nw[0] == nw[1] && nw[1] % 16 == 0) flip |= 2048; // (the opposite order can stay inside the XCDs)
     const int J = a.t[0].look; // (one trial count per launch: the kernel is compiled per count)
     for (int t = 1; t < a.ntargets; ++t)
         if (a.t[t].look != J) return -1;

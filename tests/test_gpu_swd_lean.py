@@ -194,6 +194,43 @@ def test_a_model_alone_a_window_and_a_batch_give_the_same_bits(lean):
         assert np.array_equal(vp_, va[perm]) and np.array_equal(ep_, ea[perm])
 
 
+def test_the_order_per_xcd_is_scheduling_only(lean, oracle):
+    """Where the shapes divide (4096 models with 16 trials per round, 2048 with 32 ...) the models are ordered inside eight blocks of
+    the batch, a block per XCD, and the second target runs them in the opposite order inside the XCDs (bh_tuning.h: swd_lean_xcd,
+    swd_lean_flip): the same bits as with one order for the chip and as in batch order -- one target, two targets, a shape that
+    does not divide -- and the reference's flags."""
+    from bayhunter_amd import engine as E
+    per = np.linspace(2, 60, 30)
+    yobs = 3.4 + 0.01 * per
+    rs = np.random.RandomState(123)
+    try:
+        for B in (4096, 2048, 4100, 512):
+            nlay, h, vp, vs, rho = synth_models(rs, B, 10, lvz_frac=0.2)
+            noise = np.tile([0, 0.05, 0, 0.05], (B, 1))
+            out = {}
+            for xcd, flip, nosort in ((1, 256, 0), (0, 256, 0), (1, 0, 0), (0, 0, 1)):
+                lean.set_tuning("swd_lean_xcd", xcd)
+                lean.set_tuning("swd_lean_flip", flip)
+                lean.set_tuning("swd_lean_no_sort", nosort)
+                lean.set_targets([dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=2, igr=0),
+                                  dict(kind=E.TARGET_SWD, law=0, n=30, x=per, yobs=yobs, iwave=1, igr=0)])
+                two = lean.evaluate_batch(nlay, h, vp, vs, noise, want_ymod=True)
+                assert lean.last_swd_kernel() == "lean"
+                one = lean.swd_batch(nlay, h, vp, vs, rho, per, 2, 0)
+                out[(xcd, flip, nosort)] = (two, one)
+            ref = out[(0, 0, 1)]
+            for k, (two, one) in out.items():
+                for a, b in zip(two, ref[0]):
+                    assert np.array_equal(a, b, equal_nan=True), (B, k)
+                assert np.array_equal(one[0], ref[1][0]) and np.array_equal(one[1], ref[1][1]), (B, k)
+            ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, 2, 0)
+            check_against_the_reference(ref[1][0], ref[1][1], ov, oe)
+    finally:
+        lean.set_tuning("swd_lean_xcd", 1)
+        lean.set_tuning("swd_lean_flip", 256)
+        lean.set_tuning("swd_lean_no_sort", 0)
+
+
 def test_earth_flattening_deep_models_and_many_periods(lean, oracle):
     rs = np.random.RandomState(9)
     for L, B, fl, K in ((12, 300, 1, 30), (32, 60, 0, 60), (21, 100, 0, 7), (50, 40, 0, 30)):

@@ -85,12 +85,13 @@ for sh in c3 tut t512u t512r n16384; do
 done
 $TR -d "$OUT/trace_gauss" -o t -- python $R/tools/gpu_gauss_perf.py 4096 1024 20 > "$OUT/trace_gauss.log" 2>&1
 fi
-if has pmc; then
+if has pmc || has pmcfast; then   # (pmcfast: only the passes of the default settings, c2 and c3)
 stamp "counter passes"
+SMS="fast reference"; has pmc || SMS="fast"
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_SMEM"
 SQ2="SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"
 PM="rocprofv3 --output-format csv"
-for WL in c2 c3; do for SM in fast reference; do      # (keys: c2fast / c3fast = the engine's default search, c2 / c3 = the reference's sequence)
+for WL in c2 c3; do for SM in $SMS; do      # (keys: c2fast / c3fast = the engine's default search, c2 / c3 = the reference's sequence)
   KEY=$WL; [ $SM = fast ] && KEY=${WL}fast
   CMD="python $R/bench.py --workload $WL --search $SM --steps 4 --warmup 1 $NB --no-rf-roofline"
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -99,6 +100,8 @@ for WL in c2 c3; do for SM in fast reference; do      # (keys: c2fast / c3fast =
   $PM --pmc $SQ -d "$OUT/pmc_${KEY}_SQ" -o pmc -- $CMD > "$OUT/pmc_${KEY}_SQ.log" 2>&1
   $PM --pmc $SQ2 -d "$OUT/pmc_${KEY}_SQ2" -o pmc -- $CMD > "$OUT/pmc_${KEY}_SQ2.log" 2>&1
 done; done
+fi
+if has pmc; then
 CMD="python $R/bench.py --workload c2 --search fast --arith exact --steps 4 --warmup 1 $NB"   # the short refinement in the reference's arithmetic
 for C in FETCH_SIZE WRITE_SIZE; do $PM --pmc $C -d "$OUT/pmc_c2fastexact_$C" -o pmc -- $CMD > "$OUT/pmc_c2fastexact_$C.log" 2>&1; done
 $PM --pmc $SQ -d "$OUT/pmc_c2fastexact_SQ" -o pmc -- $CMD > "$OUT/pmc_c2fastexact_SQ.log" 2>&1
