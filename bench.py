@@ -617,9 +617,8 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
             "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": pmc.get("source"),
             **pmc_stamp(pmc, swd_ms_per_launch),
             "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
-            "traffic_note": ("what exceeds the algorithmic bytes: the wavefronts take the models in the order of their predicted search length (each "
-                             "target in its own direction), so the 8-byte elements of the layer-major arrays are gathered through 64-byte sectors "
-                             "(22 GB/s in all: 0.3 % of the HBM peak; in batch order the ratio is 1.10 and the kernel 8 % slower)" if lean else
+            "traffic_note": ("below the algorithmic bytes: those count the model arrays once per target, the second target finds them in L2 (the models "
+                             "are ordered inside eight blocks of the batch, a block per XCD: every L2 fetches an eighth of the arrays)" if lean else
                              "what exceeds the algorithmic bytes is not model data: the wavefronts' progress board (a word per hardware "
                              "wavefront slot, polled every 8 rounds) -- ~10 GB/s, a thousandth of the HBM peak"),
             "kernel": {"lean": "swd_lean_kernel (one lane per trial velocity; all dispersion targets of a step in one launch)",
