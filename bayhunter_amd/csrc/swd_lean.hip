@@ -122,7 +122,10 @@ __device__ __forceinline__ void lean_wave_sync()
 }
 
 #ifndef BH_LEAN_CLUSTER_W
-#define BH_LEAN_CLUSTER_W 2.0e-7
+#define BH_LEAN_CLUSTER_W 4.0e-7 // half width (relative) of the two-lane cluster: 1e-7 0.683, 2e-7 0.652, 4e-7 0.646, 6e-7 0.647 ms (c2)
+#endif
+#ifndef BH_LEAN_RIDE_TOL
+#define BH_LEAN_RIDE_TOL 4.0e-7   // the window that rode along is taken over if the root is within this (relative) of the estimate it was anchored on
 #endif
 #ifndef BH_LEAN_CLUSTER_BIG
 #define BH_LEAN_CLUSTER_BIG 8 // the same with 32 and 64 lanes per model
@@ -272,10 +275,10 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     // (Rayleigh) / 99 % (Love) of the periods of the bench's models (tools/cpu_scan_steps.py): the scaled secular function is that
     // smooth over three grid steps, except next to a layer velocity.  So with the next period's window beside it the cluster is
     // only NC lanes and the other NR = J - NC lanes evaluate -- at the NEXT period's frequency -- the first round of the next
-    // period's scan on the grid anchored at x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 2.5e-7 |x| of x,
-    // those values ARE the next period's first round (its grid is anchored 2.5e-7 relative off the root: the reference's own root
+    // period's scan on the grid anchored at x - 1.5 dc instead of root - 1.5 dc.  If the root comes out within 4e-7 |x| of x,
+    // those values ARE the next period's first round (its grid is anchored 4e-7 relative off the root: the reference's own root
     // is known to 1e-6, and the guard covers grids that differ by 3e-6); otherwise they are dropped.
-    //   NC: with 8 or 16 lanes per model 2 (x -+ 2e-7 |x|; a miss costs two rounds: J-section, then the cluster again).  The
+    //   NC: with 8 or 16 lanes per model 2 (x -+ 4e-7 |x|; a miss costs two rounds: J-section, then the cluster again).  The
     // bench's sign change is 14.5 steps from the start value on average: a window of 14 lanes reaches it in 59 % of the periods
     // (one round for the period), the rest take a second round of 16 steps -- c2 with clusters of 2 / 4 / 8 lanes: 0.66 / 0.70 /
     // 0.76 ms.  With 32 and 64 lanes 8 (x -+ 1e-7 |x| 4^i, i < 4): that is where a sampler's windows run, whose models (up to 20
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         c1 = ck - onea * dc;
                         clow = cm;
                         ph = PH_START;
-                        if (!probed && spec && fabs(c3 - xc) <= 2.5e-7 * fabs(c3)) { // the upper lanes' values are this period's first round
+                        if (!probed && spec && fabs(c3 - xc) <= BH_LEAN_RIDE_TOL * fabs(c3)) { // the upper lanes' values are this period's first round
                             c1 = xc - onea * dc; // (the grid they evaluated)
                             scan_now = true;
                             sc_first = true;

@@ -85,6 +85,11 @@ for sh in c3 tut t512u t512r n16384; do
 done
 $TR -d "$OUT/trace_gauss" -o t -- python $R/tools/gpu_gauss_perf.py 4096 1024 20 > "$OUT/trace_gauss.log" 2>&1
 fi
+if has tracefast && ! has trace; then   # (only the traces of the default settings, c2 and c3)
+stamp "kernel traces (default settings)"
+$TR -d "$OUT/trace_c3fast" -o t -- python $R/bench.py --workload c3 --search fast --steps 10 --warmup 2 $NB --no-rf-roofline > "$OUT/trace_c3fast.log" 2>&1
+$TR -d "$OUT/trace_c2fast" -o t -- python $R/bench.py --workload c2 --search fast --steps 10 --warmup 2 $NB > "$OUT/trace_c2fast.log" 2>&1
+fi
 if has pmc || has pmcfast; then   # (pmcfast: only the passes of the default settings, c2 and c3)
 stamp "counter passes"
 SMS="fast reference"; has pmc || SMS="fast"
