@@ -15,7 +15,7 @@
 //   * Inside the bracket the root is located by a round of trials clustered around the inverse-quadratic estimate through the
 //     bracket's ends and the grid point before them (1e-7 |x| * 4^i both sides; beside the next period's window the cluster is
 //     2 or 8 lanes, see the kernel), by J-section where a cluster does not close in; the root returned is the inverse-quadratic
-//     point of the final bracket (<= 1.3e-6 |c| wide, typically 4e-7).  The reference (nevill) stops at a bracket of 1e-6 c1 and
+//     point of the final bracket (<= 1.3e-6 |c| wide, typically 8e-7).  The reference (nevill) stops at a bracket of 1e-6 c1 and
 //     returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
 //   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
 //     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
