@@ -61,13 +61,17 @@ class _Chain(object):
 class ChainBatch(object):
     """`nchains` independent rj-McMC chains sharing one set of targets and one engine."""
 
-    def __init__(self, targets, seeds, initparams=None, modelpriors=None, search="reference", arith="exact"):
-        """search: root refinement of the dispersion search in the chains' evaluation calls (Engine.set_swd_search).  The
+    def __init__(self, targets, seeds, initparams=None, modelpriors=None, search="reference", arith="exact", trials=None):
+        """trials: trials per round of the trial-per-lane kernel in the chains' evaluation calls (Engine.set_swd_trials; None =
+        the engine's setting, i.e. by the call's shape unless pinned).  A driver whose results must not depend on how many
+        chains an evaluation call holds pins it (DeviceChains: 32, for its windows AND for this initial state).
+        search: root refinement of the dispersion search in the chains' evaluation calls (Engine.set_swd_search).  The
         default is the REFERENCE's sequence, whatever the engine's own setting: these chains walk in the reference's order
         from the reference's seeds, and a recorded run of `SingleChain` replays exactly only with the reference's bits.
         arith: the arithmetic where every dispersion target of a call takes the short refinement (Engine.set_swd_arith)."""
         self.search = search
         self.arith = arith
+        self.trials = trials
         self.targets = targets if isinstance(targets, JointTarget) else JointTarget(targets)
         self.priors = dict(DEFAULT_PRIORS)
         self.priors.update(modelpriors or {})
@@ -231,7 +235,7 @@ class ChainBatch(object):
             nlay[b] = n
             h[:n, b], vp[:n, b], vs[:n, b] = ph, pvp, pvs
             noise[b] = nz
-        with self.targets.engine.searching(self.search), self.targets.engine.computing(self.arith):
+        with self.targets.engine.searching(self.search), self.targets.engine.computing(self.arith), self.targets.engine.trying(self.trials):
             logL, misfits, err = self.targets.evaluate_batch(nlay, h, vp, vs, noise)
         return list(logL), [m for m in misfits]
 

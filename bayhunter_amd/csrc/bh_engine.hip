@@ -4,7 +4,7 @@
 // host buffers when the caller asks for memspace = BH_HOST and launches the gfx950 kernels of
 // swd_kernel.hip / rf_kernel.hip / like_kernel.hip.  There is no CPU code path in here: if no
 // HIP device is usable, bh_engine_create fails.
-#include "../../include/bh_engine.h"
+#include "../../include/bh_engine_debug.h"
 #include "bh_device.h"
 
 #include <cmath>
@@ -34,18 +34,22 @@ int tuning_value(const char *env, const char *txt, int dflt)
     if (end == txt) return 1; // a flag set to some text
     return (int)v;
 }
+// bounds: a switch can cost time, never memory safety (after the environment is parsed and after every bh_tuning_set)
+void tuning_clamp()
+{
+    if (g_tuning.rf_lds_gated < 0 || g_tuning.rf_lds_gated > 160 * 1024) g_tuning.rf_lds_gated = 0;
+    if (g_tuning.rf_lds_beside > 160 * 1024) g_tuning.rf_lds_beside = -1;
+    if (g_tuning.swd_love_inlook < 0 || g_tuning.swd_love_inlook > 4) g_tuning.swd_love_inlook = 0;
+    if (g_tuning.swd_wpb != 4) g_tuning.swd_wpb = 2;
+    g_tuning.rf_beside_prio &= 3;
+}
 void tuning_parse()
 {
 #ifndef BH_NO_EXPERIMENTS
 #define X(field, env, dflt, doc) g_tuning.field = tuning_value(env, std::getenv(env), dflt);
     BH_TUNING_TABLE(X)
 #undef X
-    // bounds: a switch can cost time, never memory safety
-    if (g_tuning.rf_lds_gated < 0 || g_tuning.rf_lds_gated > 160 * 1024) g_tuning.rf_lds_gated = 0;
-    if (g_tuning.rf_lds_beside > 160 * 1024) g_tuning.rf_lds_beside = -1;
-    if (g_tuning.swd_love_inlook < 0 || g_tuning.swd_love_inlook > 4) g_tuning.swd_love_inlook = 0;
-    if (g_tuning.swd_wpb != 4) g_tuning.swd_wpb = 2;
-    g_tuning.rf_beside_prio &= 3;
+    tuning_clamp();
 #endif
     g_tuning.under_pmc = std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr ? 1 : 0;
 }
@@ -63,7 +67,7 @@ int bh_tuning_set(const char *name, int value)
 #else
     (void)bh_tuning();
     if (!name) return -1;
-#define X(field, env, dflt, doc) if (!std::strcmp(name, #field)) { g_tuning.field = value; return 0; }
+#define X(field, env, dflt, doc) if (!std::strcmp(name, #field)) { g_tuning.field = value; tuning_clamp(); return 0; }
     BH_TUNING_TABLE(X)
 #undef X
     return -1;
@@ -211,6 +215,12 @@ void release(DevBuf &b)
 }
 
 // number of elements spanned by a strided [Lmax][B] view (strides must be positive)
+// every device buffer a registered target owns
+void release_target(TargetHost &t)
+{
+    for (DevBuf *b : {&t.x, &t.yobs, &t.yerr_scaled, &t.rinv, &t.quad, &t.sums, &t.x60, &t.vel60}) release(*b);
+}
+
 size_t span_elems(int B, int Lmax, ptrdiff_t sl, ptrdiff_t sb)
 {
     return (size_t)((ptrdiff_t)(Lmax - 1) * sl + (ptrdiff_t)(B - 1) * sb + 1);
@@ -976,7 +986,7 @@ void bh_engine_destroy(bh_engine *e)
                       &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard, &e->rfz})
         release(*b);
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);
+        release_target(t);
     }
     for (auto &s : e->evsets)
         for (auto &ev : s.ev)
@@ -1171,7 +1181,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (auto &t : e->targets) {
-        release(t.x); release(t.yobs); release(t.yerr_scaled); release(t.rinv); release(t.quad); release(t.x60); release(t.vel60);
+        release_target(t);
     }
     e->targets.clear();
     e->nt = 0;
@@ -1241,9 +1251,7 @@ int bh_targets_set(bh_engine *e, int nt, const bh_target_desc *td)
             if (!rc && hipMemcpy(t.rinv.p, d.rinv, nb * (size_t)d.n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(e, BH_EHIP, "copy rinv");
         }
         if (rc) {
-            for (auto &u : tmp) {
-                release(u.x); release(u.yobs); release(u.yerr_scaled); release(u.rinv); release(u.quad); release(u.x60); release(u.vel60);
-            }
+            for (auto &u : tmp) release_target(u);
             return rc;
         }
         // the engine keeps no host pointers

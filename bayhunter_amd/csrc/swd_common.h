@@ -977,10 +977,13 @@ struct SearchT {
             have_p = have_p && has(F_SEED3);
             put(F_SEEDED, have_p);
             fit = 0;
-            // A bracket that contains betmx can hold THREE sign changes (the root, its mirror image and the first of the
-            // unphysical ones above the half-space velocity); which of them nevill ends at depends on its whole
-            // sequence.  The short sequence does not try: the guard fires (the model is run again with the reference's).
-            if (cell_hi > betmxd && cell_lo < betmxd) {
+            // A bracket that contains betmx or a half-space velocity can hold THREE sign changes (the root, its mirror image
+            // above the half-space velocity -- the half-space term takes |k - k_beta| -- and the first of the unphysical ones
+            // beyond); which of them nevill ends at depends on its whole sequence.  The short sequence does not try: the guard
+            // fires (the model is run again with the reference's).  (Round 6: the half-space velocities as well -- on models
+            // drawn from a sampler's prior, whose half-space need not be the fastest layer, one in 10^4 came back with another
+            // root of such a cell than the reference's.  The trial-per-lane kernel counts the cell's sign changes instead.)
+            if ((cell_hi > betmxd && cell_lo < betmxd) || (cell_hi > vh0 && cell_lo < vh0) || (cell_hi > vh1 && cell_lo < vh1)) {
                 flg |= F_GUARD;
                 return 0;
             }

@@ -2,7 +2,7 @@
 // Same search, same bits as swd_kernel.hip (one lane per model); see the block comment at the kernel.
 // Built with -mllvm -disable-machine-licm (Makefile): the round loop carries ~60 distinct f64 constants of the
 // glibc-exact sincos / exp; hoisted out of the loop they cost more registers than the kernel has.
-#include "../../include/bh_engine.h"
+#include "../../include/bh_engine_debug.h"
 #include "bh_device.h"
 #include "bh_tuning.h"
 #include <algorithm>
@@ -247,7 +247,16 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(B
     // Rayleigh wavefronts runs them up to 30 % slower than a mixed one (LDS traffic: 150 LDS instructions per
     // Rayleigh round, 61 per Love round).  A workgroup's wavefronts only share the libm tables.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / BH_WAVE));
-    int wid = (int)blockIdx.x * WPB + wave, ty = (int)blockIdx.y;
+    // PASSES (the re-run of the models a guard listed, one model per wavefront, reference sequence): the launch is a SMALL grid
+    // (bh_launch_swd_group: bh_tuning.h swd_rerun_wgs = 64 per target) whose workgroups stride over the list, whose length lives on
+    // the device -- nearly always it is empty or a handful of models, and a launch sized for the worst case (one wavefront per
+    // model of the batch: 2048 workgroups at B = 4096) had to be dispatched workgroup by workgroup only to leave at once (4.5 us
+    // alone, 0.2 ms when receiver-function workgroups of the other stream were waiting for the same wave slots).
+    constexpr bool PASSES = ADAPT && FASTM == 0;
+    int pass = 0;
+next_pass:
+    const int wg_x = (int)blockIdx.x + ((PASSES && A.rerun != 0) ? pass * (int)gridDim.x : 0);
+    int wid = wg_x * WPB + wave, ty = (int)blockIdx.y;
     bool beyond = false; // (interleaved grid: a last, odd wavefront may have nothing to do)
     if (A.wg_n1 > 0) {
         const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
@@ -297,9 +306,9 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(B
         if (cls == 0) hi = ndeep;
         else lo = ndeep;
     }
-    if (A.wg_n1 == 0 && lo + (int)blockIdx.x * WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
-    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * WPB);
-    __syncthreads();
+    if (A.wg_n1 == 0 && lo + wg_x * WPB * MPW >= hi) return; // whole workgroup beyond the range (grid = worst case)
+    const LibmTabs LT = stage_libm_tables(smem_all, threadIdx.x, BH_WAVE * WPB); // (a later pass writes the same values again)
+    if (pass == 0) __syncthreads();
     if (beyond || lo + wid * MPW >= hi) return;
     unsigned char *smem = smem_all + LIBM_TAB_PAD + (size_t)wave * wave_lds;
     const bool spare = lane >= MPW * LPM;
@@ -925,6 +934,10 @@ restart_with_the_reference_sequence:
             }
         }
     }
+    if (PASSES && A.rerun != 0) { // the next entries of the list
+        ++pass;
+        goto next_pass;
+    }
 }
 
 #if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_PREK_TU)
@@ -1284,6 +1297,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         else if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
         else BH_GROUP_LAUNCH_ADAPT(1, false);
     } else if (adapt) {
+        if (a.rerun && tun.swd_rerun_wgs > 0 && grid.x > (unsigned)tun.swd_rerun_wgs) grid.x = (unsigned)tun.swd_rerun_wgs; // (the kernel's PASSES: its workgroups stride over the list)
         if (counted) BH_GROUP_LAUNCH_ADAPT(0, true);
         else BH_GROUP_LAUNCH_ADAPT(0, false);
     } else if (build == 2 && simple) {

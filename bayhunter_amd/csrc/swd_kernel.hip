@@ -28,7 +28,7 @@
 //     arithmetic of the start value and of the group-velocity formula follow the reference exactly
 //     (SURVEY.md App. A), and sin/cos/exp (and log/powf of the flattening transform) are
 //     restatements of the host libm the reference links (bh_libm.h): results are bit-identical.
-#include "../../include/bh_engine.h"
+#include "../../include/bh_engine_debug.h"
 #include "bh_device.h"
 #include "bh_tuning.h"
 #include <cmath>

@@ -23,7 +23,7 @@
 //     guarded model is listed and run again by the engine with the reference's sequence in the reference's arithmetic
 //     (launch_swd_rerun), so failure flags and zero rows are the reference's.
 //   * A model with a water layer (unreachable from BayHunter) is guarded at once.
-#include "../../include/bh_engine.h"
+#include "../../include/bh_engine_debug.h"
 #include "bh_device.h"
 #include "bh_tuning.h"
 #include <algorithm>
@@ -109,7 +109,9 @@ enum : int {
     PH_REF1 = 2,       // J-section of the bracket
     PH_REFC = 3,       // trials clustered around the estimate
     PH_PROBE_STEP = 4, // the guard's probes of a scan step over a half-space velocity (ST_GS1 / ST_GS2 of SearchT)
-    PH_PROBE_ACC = 5   // the guard's probes outside an accepted bracket (ST_GH / ST_GL)
+    PH_PROBE_ACC = 5,  // the guard's probes outside an accepted bracket (ST_GH / ST_GL)
+    PH_SPECIAL = 6,    // a bracket that contains betmx or a half-space velocity: how many sign changes it holds, and where (see the kernel)
+    PH_PROBE_START = 7 // the guard's probes next to a start value that lies next to a root
 };
 
 __device__ __forceinline__ bool sign_neg(double x) { return __double_as_longlong(x) < 0; }
@@ -135,7 +137,11 @@ __device__ __forceinline__ void lean_wave_sync()
 #endif
 constexpr int LEAN_WPB = 4; // wavefronts per workgroup: independent (no barrier), one per SIMD of the CU the workgroup lands on
 
-template <int J> // trials per model and round: 4, 8, 16, 32 or 64 lanes = one model
+// J: trials per model and round: 4, 8, 16, 32 or 64 lanes = one model.
+// CNT: the build with the evaluation counters and the round clocks (launches with A.neval set: bh_engine_set_instrumentation's
+// `counting`).  The counters cost 12 registers; without them the <16> build needs 197 (200 allocated), so that an 88-register
+// receiver-function wavefront fits beside the two dispersion wavefronts of a SIMD (2 x 200 + 88 <= 512).
+template <int J, bool CNT>
 __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiArgs A, int wave_lds, int flip)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -148,14 +154,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     if (A.wg_n1 > 0) {
         const long long n1 = A.wg_n1, N = (long long)A.wg_n0 + n1;
         if (wid >= (int)N) return;
-        if ((flip & 255) > 0 && A.wg_n0 == A.wg_n1) { // (experiment: with bit 8 of the workgroup index the two wavefronts of a SIMD become the same target's: 0.80 ms)
-            ty = (wid + (int)(blockIdx.x >> ((flip & 255) - 1))) & 1;
-            wid = wid >> 1;
-        } else {
-            const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
-            ty = (l1 > l0) ? 1 : 0;
-            wid = (l1 > l0) ? l0 : wid - l0;
-        }
+        const int l0 = (int)(((long long)wid * n1) / N), l1 = (int)((((long long)wid + 1) * n1) / N);
+        ty = (l1 > l0) ? 1 : 0;
+        wid = (l1 > l0) ? l0 : wid - l0;
         // The second target takes the models in the OPPOSITE order: the wavefronts run longest search first (bh_launch_pair_order), and
         // the wavefront that shares a SIMD with the longest Rayleigh searches should be the one with the shortest Love searches
         // (c2: 0.668 -> 0.656 ms/step).  Scheduling only.
@@ -239,11 +240,23 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     cc1 = 0.90f * cc1;
     const double cm = (double)cc1, betmxd = (double)betmx;
     const double vh0 = md.Bv(mmax - 1), vh1 = (ifunc == 2) ? md.A(mmax - 1) : betmxd, vsafe = fmin(vh0, vh1);
+    // The velocities at which the secular function is not smooth in c or at which getsol's acceptance changes: the half-space's S
+    // (and, Rayleigh, P) velocity -- above it the half-space term takes |k - k_beta|: a root below has a mirror image above -- and
+    // betmx (a root above it fails the period).  The one of them inside the open cell (lo, hi), 0 if none, -1 if more than one.
+    auto special_in_cell = [&](double lo_, double hi_) -> double {
+        double sp = 0.0;
+        int n = 0;
+        if (lo_ < betmxd && betmxd < hi_) sp = betmxd, ++n;
+        if (vh0 != betmxd && lo_ < vh0 && vh0 < hi_) sp = vh0, ++n;
+        if (vh1 != betmxd && vh1 != vh0 && lo_ < vh1 && vh1 < hi_) sp = vh1, ++n;
+        return n > 1 ? -1.0 : sp;
+    };
     double *vel = T.vel + (size_t)ib * T.ldv;
     const bool writer = valid && r == 0;
     bool active = valid && K > 0 && sane, guard = false;
+#define LEAN_GUARD(n) do { guard = true; if (CNT) greason = (n); } while (0)
     int greason = 0; // (development aid: which rule fired the guard -- 1 water layer, 2 / 3 small start / scan value, 4 step probes, 5 bracket
-                     //  probes, 6 bracket contains betmx, 7 root at a bracket end or at betmx)
+                     //  probes, 6 a bracket that contains betmx with sign changes on both sides of it or next to it, 7 root at a bracket end or at betmx)
     int errflag = 0;
     if (valid && !sane) {
         errflag = 1;
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             for (int i = 0; i < K; ++i) vel[i] = 0.0;
     }
     if (active && md.Bv(0) <= 0.0) { // water layer on top: the reference's sequence
-        guard = true, greason = 1;
+        LEAN_GUARD(1);
         active = false;
     }
     // ---- search state, the same in every lane of the model
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     double lo = 0.0, hi = 0.0, flo = 0.0, fhi = 0.0, p3 = 0.0, fp3 = 0.0, c3 = 0.0, wprev = 0.0;
     bool have3 = false;
     double cell_lo = 0.0, cell_hi = 0.0, pb = 0.0, delb = 0.0;
-    bool flo_neg = false;
+    bool flo_neg = false, chk = false; // chk: this period's start value has been probed (PH_PROBE_START)
     unsigned evals = 0;
     if (active) {
         omega = omg[0];
@@ -287,10 +300,10 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     constexpr int NC = (J >= 32) ? BH_LEAN_CLUSTER_BIG : ((J >= 8) ? BH_LEAN_CLUSTER : J / 2), NR = J - NC;
     constexpr bool can_spec = J >= 4; // (every trial count the launcher offers)
     constexpr unsigned long long maskC = (1ull << NC) - 1ull, maskR = (1ull << NR) - 1ull;
-    const double invJ1 = 1.0 / (double)(J + 1);
+    const double invJ1 = 1.0 / (double)(J + 1), invJm1 = 1.0 / (double)(J - 1);
     unsigned nrounds = 0;
     long long t_eval = 0;
-    const long long t_start = (A.neval != nullptr) ? clock64() : 0;
+    const long long t_start = ((CNT && A.neval != nullptr)) ? clock64() : 0;
     while (__ballot(active) != 0ull) {
         ++nrounds;
         // ---- this lane's trial velocity (and frequency)
@@ -354,6 +367,12 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 om_l = omg[k + 1];
                 iom_l = fa::rcp(om_l);
             }
+        } else if (ph == PH_SPECIAL) {
+            // lanes 0 / 1: just below / just above the special velocity of the cell; the others: J - 2 section points of the cell
+            const double sp = special_in_cell(cell_lo, cell_hi);
+            cev = (r == 0) ? sp - guard_rel * sp : ((r == 1) ? sp + guard_rel * sp : __builtin_fma(cell_hi - cell_lo, (double)(r - 1) * invJm1, cell_lo));
+        } else if (ph == PH_PROBE_START) {
+            cev = (r == 0) ? c1 - guard_rel * c1 : ((r == 1) ? c1 + guard_rel * c1 : c1);
         } else if (ph == PH_PROBE_STEP) {
             const double l_ = fmin(c1, pb), h_ = fmax(c1, pb);
             cev = (r == 0) ? l_ + guard_rel * h_ : h_ - guard_rel * h_;
@@ -361,10 +380,10 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             cev = (r == 0) ? cell_hi + guard_rel * fabs(c3) : cell_lo - guard_rel * fabs(c3);
         }
         if (!active || !(cev > 0.0)) cev = 1.0; // (finished or broken models compute on a harmless value)
-        const long long te0 = (A.neval != nullptr) ? clock64() : 0;
+        const long long te0 = ((CNT && A.neval != nullptr)) ? clock64() : 0;
         const double wvno = om_l * fa::rcp(cev);
         const double del = (ifunc == 2) ? lean_rayleigh(wvno, om_l, iom_l, md, mmax, mtop) : lean_love(wvno, om_l, md, mmax, mtop);
-        if (A.neval != nullptr) t_eval += clock64() - te0;
+        if ((CNT && A.neval != nullptr)) t_eval += clock64() - te0;
 
         // ---- the round's decision.  Signs and "not a number" travel as ballots; one event code per lane and a ballot give the
         // first event of a window of lanes; the VALUES at the events are fetched by two small sets of exchanges (all outside the
@@ -405,15 +424,81 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         bool scan_now = false; // stage 2 consumes a scan window for this model
         int w0 = 0;            // its first lane
         bool sc_first = false; // it is a period's first round
+        // A bracket with betmx or a half-space velocity inside (rare: the round's wavefront-uniform branch).  Above the half-space's
+        // S velocity the half-space term takes |k - k_beta|: a root just below it has a mirror image just above, and further sign
+        // changes may follow up to betmx -- the reference's function has them, and getsol takes whatever nevill ends at provided it
+        // is not above betmx (:468-471).  A cell with SEVERAL sign changes is therefore a matter of nevill's sequence (which root;
+        // with betmx inside: whether the period fails), a cell with ONE is not.  The cell's J - 2 section points and the two
+        // points s (1 -+ 3e-6) next to the special velocity s say which it is:
+        //   * one sign change in the whole cell: the refinement goes on in its section (s = betmx and the sign change above it: the
+        //     period fails as the reference's does -- nevill ends within 1e-6 c of a sign change above betmx (1 + 3e-6));
+        //   * s = betmx, no sign change below it, several above: the period fails whichever of them nevill ends at;
+        //   * anything else -- several sign changes, one between the two points next to s, a value that is no number -- the guard.
+        // (Before this rule a cell with betmx inside was always guarded -- 99 % of the guarded models of LVZ-rich batches,
+        // profiles/r05_lean_guard.txt -- and a cell with a half-space velocity below betmx inside was refined like any other:
+        // on models drawn from a sampler's prior, one in 10^4 then came back with another root of the cell than the reference's,
+        // up to 1.5e-3 away.)
+        bool special_now = false;
+        if (__ballot(active && ph == PH_SPECIAL) != 0ull) {
+            const double sp = special_in_cell(cell_lo, cell_hi);
+            const double pm = sp - guard_rel * sp, pp = sp + guard_rel * sp;
+            const unsigned long long m_b = (__ballot(r >= 2 && cev < pm) >> lbase) & maskJ, m_a = (__ballot(r >= 2 && cev > pp) >> lbase) & maskJ;
+            const int nb = __builtin_popcountll(m_b), na = __builtin_popcountll(m_a); // section points below pm: lanes 2 .. nb + 1; above pp: the last na lanes
+            const unsigned long long s_b = (mneg >> 2) & ((1ull << nb) - 1ull), s_a = (na > 0) ? ((mneg >> (J - na)) & ((1ull << na) - 1ull)) : 0ull;
+            // Signs in the order of the velocities, in two sequences (with 64 lanes per model one would not fit 64 bits).  Below:
+            // element 0 = cell_lo, 1 .. nb = the section points (lanes 2 .. nb + 1), nb + 1 = pm (lane 0).  Above: element 0 = pp
+            // (lane 1), 1 .. na = the section points (lanes J - na .. J - 1), na + 1 = cell_hi.  Bit e of ch_*: a sign change
+            // between elements e and e + 1.
+            const unsigned long long seq_b = (flo_neg ? 1ull : 0ull) | (s_b << 1) | ((mneg & 1ull) << (nb + 1));
+            const unsigned long long seq_a = ((mneg >> 1) & 1ull) | (s_a << 1) | ((sign_neg(fhi) ? 1ull : 0ull) << (na + 1));
+            const unsigned long long ch_b = (seq_b ^ (seq_b >> 1)) & ((1ull << (nb + 1)) - 1ull), ch_a = (seq_a ^ (seq_a >> 1)) & ((1ull << (na + 1)) - 1ull);
+            const bool at = ((mneg & 1ull) != 0ull) != ((mneg & 2ull) != 0ull);
+            const int n_b = __builtin_popcountll(ch_b), n_a = __builtin_popcountll(ch_a);
+            const bool below = ch_b != 0ull;                                      // the (first) sign change lies below the special velocity
+            const int te = below ? (int)__builtin_ctzll(ch_b) : (ch_a ? (int)__builtin_ctzll(ch_a) : 0); // between elements te and te + 1 of its sequence
+            // lanes of the two elements (-1: the cell's own end)
+            const int e_lo = below ? ((te == 0) ? -1 : te + 1) : ((te == 0) ? 1 : J - na + te - 1);
+            const int e_hi = below ? ((te == nb) ? 0 : te + 2) : ((te == na) ? -1 : J - na + te);
+            const int l_lo = e_lo < 0 ? 0 : e_lo, l_hi = e_hi < 0 ? 0 : e_hi;
+            const double d_lo = __shfl(del, lbase + l_lo), d_hi = __shfl(del, lbase + l_hi);
+            const double c_lo = __shfl(cev, lbase + l_lo), c_hi = __shfl(cev, lbase + l_hi);
+            if (active && ph == PH_SPECIAL) {
+                special_now = true;
+                evals += (unsigned)J;
+                const bool is_betmx = sp == betmxd;
+                if (m_small != 0ull || at || n_b + n_a == 0) {
+                    LEAN_GUARD(6);
+                } else if (is_betmx && n_b == 0) { // every sign change above betmx: getsol's "c1 > betmx" (:470)
+                    todo = 2;
+                } else if (n_b + n_a == 1) { // the one sign change of the cell
+                    if (e_lo >= 0) {
+                        lo = c_lo;
+                        flo = d_lo;
+                    }
+                    if (e_hi >= 0) {
+                        hi = c_hi;
+                        fhi = d_hi;
+                    }
+                    have3 = false;
+                    nref = 0;
+                    wprev = hi - lo;
+                    ph = PH_REF1;
+                } else {
+                    LEAN_GUARD(6);
+                }
+            }
+        }
         if (active) {
             scan_now = ph <= PH_SCAN;
             sc_first = ph == PH_START;
             bool probed = false;
-            if (ph == PH_PROBE_STEP) {
+            if (special_now) {
+                // (decided above)
+            } else if (ph == PH_PROBE_STEP) {
                 evals += 2;
                 const bool n1 = sign_neg(del1);
                 if ((m_small & 3ull) || ((mneg & 1ull) != 0ull) != n1 || ((mneg & 2ull) != 0ull) != n1) {
-                    guard = true, greason = 4;
+                    LEAN_GUARD(4);
                 } else { // the step is an ordinary one
                     cp = c1;
                     delp = del1;
@@ -477,9 +562,21 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     if (!(c3 >= lo && c3 <= hi)) c3 = 0.5 * (lo + hi);
                     todo = 3;
                 }
+            } else if (ph == PH_PROBE_START) {
+                // Signs just below (nA), at (n2) and just above (nB) the start value.  No sign change next to it: nothing hinges on
+                // it.  One sign change r, and below it the sign of the first period's start value (the fundamental mode's own
+                // polarity): harmless -- a start value below r searches upward and one above it downward (:425-435), both find r
+                // in their first cell, as this search will.  The other polarity: a start value below r searches downward and one
+                // above it upward, AWAY from r, to different roots -- which one the reference takes hangs on the last digits of
+                // its previous root: the guard.
+                evals += 3;
+                const bool nA = (mneg & 1ull) != 0ull, nB = (mneg & 2ull) != 0ull, n2 = (mneg & 4ull) != 0ull;
+                if ((m_small & 7ull) || (nA != nB && nA != s1stneg) || (nA == nB && n2 != nA)) LEAN_GUARD(2);
+                ph = PH_START; // (the start round again, its start value checked)
+                chk = true;
             } else if (ph == PH_PROBE_ACC) {
                 evals += 2;
-                if ((m_small & 3ull) || ((mneg & 1ull) != 0ull) == flo_neg || ((mneg & 2ull) != 0ull) != flo_neg) guard = true, greason = 5;
+                if ((m_small & 3ull) || ((mneg & 1ull) != 0ull) == flo_neg || ((mneg & 2ull) != 0ull) != flo_neg) LEAN_GUARD(5);
                 todo = 4;
                 probed = true; // (the period ends a round after its cluster: nothing rode along)
             }
@@ -489,7 +586,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
                     const double eps = guard_rel * fabs(c3);
                     if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
-                        guard = true, greason = 7;
+                        LEAN_GUARD(7);
                     } else {
                         ph = PH_PROBE_ACC;
                         todo = 0;
@@ -539,7 +636,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const int wb = lbase + w0;
         const int ev_e = __shfl(ev, wb + (e < wn ? e : wn - 1));
         const double d_e = __shfl(del, wb + (e < wn ? e : wn - 1)), d_em = __shfl(del, wb + (e > 0 ? e - 1 : 0)),
-                     d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb);
+                     d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb), d_second = __shfl(del, wb + 1);
         if (active && scan_now) {
             const bool start = sc_first;
             const unsigned long long msm = (w0 != 0) ? ((m_small >> NC) & maskR) : m_small;
@@ -550,9 +647,20 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             auto cgrid = [&](int t) -> double { return (start && t == 0) ? c1s : __builtin_fma((double)(start ? t : t + 1), step, base); };
             int off = 0, todo2 = 0; // 1 bracket (c1, del1) - (pb, delb) found; 2 root search failed
             bool consume = true;
-            if (start) {
+            // A root within the guard's distance of the start value: its sign there decides the direction of the search (:425-435),
+            // and the reference's start value -- its own previous root - 1.5 dc -- lies up to 3e-6 c beside this one.  |f(c1)|
+            // against the change of f over the first step (linear over a step but next to a layer velocity: a root within 3e-6 c
+            // of c1 gives a ratio of 3e-6 c / dc = 2e-3; the rule looks closer below 1e-2): the round is not consumed, the next one
+            // probes c1 (1 -+ 3e-6) -- all three signs equal: the start round again, else the guard.  (On models drawn from a
+            // sampler's prior one search in 10^6 took the other direction than the reference's, and failed where it did not.)
+            const bool look_closer = start && !chk && ifirst != 1 && !(msm & 1ull) && !(flip & 4096) && fabs(d_first) < 1.0e-2 * fabs(d_second - d_first);
+            if (look_closer) {
+                ph = PH_PROBE_START;
+                consume = false;
+            } else if (start) {
+                chk = false;
                 ++evals;
-                if (msm & 1ull) guard = true, greason = 2;
+                if (msm & 1ull) LEAN_GUARD(2);
                 del1 = d_first;
                 havep = false;
                 if (ifirst == 1) s1stneg = sign_neg(d_first);
@@ -574,7 +682,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 if (last >= off) {
                     evals += (unsigned)(last - off + 1);
                     const unsigned long long used = ((last >= 63) ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << off) - 1ull);
-                    if (msm & used) guard = true, greason = 3;
+                    if (msm & used) LEAN_GUARD(3);
                 }
                 // (c1, del1) and the point before it after the steps that precede the event (e = wn: after all of them)
                 const int ns = e - off; // steps taken before the event
@@ -615,7 +723,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 flo = (c1 < pb) ? del1 : delb;
                 fhi = (c1 < pb) ? delb : del1;
                 flo_neg = sign_neg(flo);
-                if (cell_hi > betmxd && cell_lo < betmxd) guard = true, greason = 6; // (up to three sign changes in there: the reference's sequence)
                 lo = cell_lo;
                 hi = cell_hi;
                 p3 = cp;
@@ -624,6 +731,16 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 nref = 0;
                 wprev = hi - lo;
                 ph = have3 ? PH_REFC : PH_REF1;
+                {
+                    // betmx or a half-space velocity inside the cell: the next round counts the cell's sign changes (PH_SPECIAL above).
+                    // Two of them in one cell, or one within the guard's distance of a grid point (the reference's cell may be the
+                    // neighbouring one): the reference's sequence.
+                    const double sp = special_in_cell(cell_lo, cell_hi);
+                    if (sp != 0.0) {
+                        ph = PH_SPECIAL;
+                        if (!(sp > 0.0 && sp - guard_rel * sp > cell_lo && sp + guard_rel * sp < cell_hi)) LEAN_GUARD(6);
+                    }
+                }
             }
             if (guard) active = false;
             if (todo2 == 2 && active) { // no root at period k: err, zeros from there on (:313-354)
@@ -641,7 +758,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             atomicAdd(T.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)
         }
     }
-    if (A.neval != nullptr) {
+    if ((CNT && A.neval != nullptr)) {
         unsigned long long tot = writer ? evals : 0u, lps = tot * (unsigned long long)(valid ? mmax - 1 : 0);
         for (int off = 32; off > 0; off >>= 1) {
             tot += __shfl_xor(tot, off);
@@ -659,7 +776,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             atomicAdd(A.neval + 7, 1ull);
             atomicAdd(A.neval + (ifunc == 2 ? 12 : 13), (unsigned long long)t_eval); // cycles inside the secular evaluations
         }
-        if (writer && guard) atomicAdd(A.neval + 14, 1ull << (8 * (greason & 7)) ); // guard reasons, a byte each
+        if (writer && guard && greason >= 1 && greason <= 7) // guard reasons, 16 bits each: 1 .. 4 in word 14, 5 .. 7 in word 15
+            atomicAdd(A.neval + (greason <= 4 ? 14 : 15), 1ull << (16 * ((greason - 1) & 3)));
     }
 }
 } // namespace
@@ -724,12 +842,19 @@ int bh_launch_swd_lean(const SwdMultiArgs &a0, hipStream_t stream, SwdLaunchInfo
     const int J = a.t[0].look; // (one trial count per launch: the kernel is compiled per count)
     for (int t = 1; t < a.ntargets; ++t)
         if (a.t[t].look != J) return -1;
+    const bool cnt = a.neval != nullptr; // (the build with the counters: bh_engine_set_instrumentation)
+#define LEAN_LAUNCH(JJ)                                                                                                             \
+    do {                                                                                                                            \
+        if (cnt) hipLaunchKernelGGL((swd_lean_kernel<JJ, true>), grid, block, lds, stream, a, (int)wave_lds, flip);                 \
+        else hipLaunchKernelGGL((swd_lean_kernel<JJ, false>), grid, block, lds, stream, a, (int)wave_lds, flip);                    \
+    } while (0)
     switch (J) {
-    case 4: hipLaunchKernelGGL(swd_lean_kernel<4>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
-    case 8: hipLaunchKernelGGL(swd_lean_kernel<8>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
-    case 16: hipLaunchKernelGGL(swd_lean_kernel<16>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
-    case 32: hipLaunchKernelGGL(swd_lean_kernel<32>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
-    default: hipLaunchKernelGGL(swd_lean_kernel<64>, grid, block, lds, stream, a, (int)wave_lds, flip); break;
+    case 4: LEAN_LAUNCH(4); break;
+    case 8: LEAN_LAUNCH(8); break;
+    case 16: LEAN_LAUNCH(16); break;
+    case 32: LEAN_LAUNCH(32); break;
+    default: LEAN_LAUNCH(64); break;
     }
+#undef LEAN_LAUNCH
     return 0;
 }

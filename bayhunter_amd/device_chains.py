@@ -59,6 +59,8 @@ def auto_spec_depth(nchains, budget=None):
 
 
 class DeviceChains(object):
+    TRIALS = 32  # trials per round of the trial-per-lane kernel in every evaluation call of the chains (windows and initial state)
+
     def __init__(self, targets, nchains, initparams=None, modelpriors=None, seed=0, device=None, inject=False,
                  betas=None, ladder=None, swap_every=0, dist=None, chain_offset=None, spec_depth=None, search="fast", arith="fast"):
         """`nchains` chains on THIS rank.  Sharded jobs (one process per GPU, `dist` = an initialised
@@ -144,7 +146,8 @@ class DeviceChains(object):
         # ---- initial state through the reference-order host code --------------------------------
         host = ChainBatch(self.targets, chain_seeds(seed, off, self.C), ip, pr,
                           search=self.search if self.search is not None else self.targets.engine.swd_search(),
-                          arith=self.arith if self.arith is not None else self.targets.engine.swd_arith())
+                          arith=self.arith if self.arith is not None else self.targets.engine.swd_arith(),
+                          trials=self.TRIALS)   # (the windows' count: the initial likelihoods are the windows' bits)
         self.noisepriors = host.noisepriors
         self.targets._register()  # constant target data + laws live on the device from here on
 
@@ -268,7 +271,7 @@ class DeviceChains(object):
         prev_arith, prev_trials = (e.swd_arith() if self.arith is not None else None), e.swd_trials()
         if prev_arith is not None and prev_arith != self.arith:
             e.set_swd_arith(self.arith)
-        e.set_swd_trials(32)
+        e.set_swd_trials(self.TRIALS)
         try:
             e.evaluate_batch_dev(B, self.ML, t["lay_n"].data_ptr(), t["lay_h"].data_ptr(), t["lay_vp"].data_ptr(),
                                  t["lay_vs"].data_ptr(), t["lay_rho"].data_ptr(), self.ld, 1, t["pnoise"].data_ptr(), self.logL.data_ptr(),

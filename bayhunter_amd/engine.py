@@ -150,17 +150,24 @@ def load_library():
                  "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
-    if L.bh_abi_version() != 9:
+    if L.bh_abi_version() != 10:
         raise EngineError("ABI version mismatch")
     _lib = L
     return L
 
 
+# include/bh_engine.h: the drop-in contract
 EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "bh_engine_last_error",
-                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
-                    "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                    "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
-                    "bh_chain_propose_window", "bh_chain_accept_window")
+                    "bh_engine_stream", "bh_engine_synchronize", "bh_engine_set_swd_search", "bh_engine_get_swd_search",
+                    "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials",
+                    "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+                    "bh_swd_batch", "bh_rf_batch", "bh_targets_set", "bh_evaluate_batch", "bh_loglike_batch",
+                    "bh_chain_propose", "bh_chain_accept", "bh_chain_propose_window", "bh_chain_accept_window")
+# include/bh_engine_debug.h: measurement, diagnostics, experiment switches (bench.py, tools/, tests)
+DEBUG_SYMBOLS = ("bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_last_swd_kernel", "bh_engine_set_swd_scan",
+                 "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning",
+                 "bh_engine_get_tuning", "bh_probe_math", "bh_probe_csign", "bh_engine_set_instrumentation", "bh_timing_reset",
+                 "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace")
 
 
 def _f64(a):
@@ -287,6 +294,19 @@ class Engine(object):
 
     def swd_trials(self):
         return int(self._L.bh_engine_get_swd_trials(self._h))
+
+    @contextlib.contextmanager
+    def trying(self, trials):
+        """The calls inside run the trial-per-lane kernel with this many trials per round (None: the engine's setting stays);
+        the engine's setting is restored afterwards."""
+        prev = self.swd_trials()
+        if trials is not None:
+            self.set_swd_trials(trials)
+        try:
+            yield self
+        finally:
+            if trials is not None:
+                self.set_swd_trials(prev)
 
     def last_swd_kernel(self):
         """Which dispersion kernel the most recent call launched: "group", "lane", "lean" (bh_engine_last_swd_kernel) or None."""

@@ -65,15 +65,19 @@ FLOP_PER_LPS = {2: 320.0, 1: 65.0}
 NPOOL = 4                   # distinct batches rotated through the steps
 CLOCK_WARMUP_MS = float(os.environ.get("BH_BENCH_CLOCK_WARMUP_MS", "150"))   # untimed launches of the step before the --warmup steps (clock ramp of an idle GPU)
 RF_CUT_WA = 12.5132         # csrc/rf_kernel.hip: w/a beyond which the Gauss low-pass is below 1e-17
+PRIOR_LAYERS = 21           # c2p: array capacity of models drawn from the chains' prior (layers = (1, 20) above the half-space)
 RF_FLOP_PER_LAYER_STEP = 600.0   # flop-equivalents of one layer of the reflectivity recursion for one frequency
 
 
 def build_workload(name, B, L, seed):
     """Returns (targets for the engine, targets for the oracle, batches, noise) -- host arrays."""
     from bayhunter_amd import engine as E
-    from bayhunter_amd.synth import synth_models, true_model, SWD_PERIODS, RF_TIME, SEED
+    from bayhunter_amd.synth import synth_models, prior_models, true_model, SWD_PERIODS, RF_TIME, SEED
     rs = np.random.RandomState(seed)
-    batches = [synth_models(rs, B, L, lvz_frac=0.1) for _ in range(NPOOL)]
+    if name == "c2p":   # c2's targets on models drawn from the chains' prior (what configs[3] / [4] evaluate): ragged 2 .. L layers,
+        batches = [prior_models(rs, B, L, vs=(2.0, 5.0), z=(0.0, 60.0), vpvs=(1.4, 2.1), thickmin=0.1) for _ in range(NPOOL)]   # velocities in any order
+    else:
+        batches = [synth_models(rs, B, L, lvz_frac=0.1) for _ in range(NPOOL)]
     per = SWD_PERIODS
     igr = 1 if name == "c2g" else 0     # c2g: the "second run" of SURVEY.md 8(d) with group velocities
     spec = [dict(kind=E.TARGET_SWD, law=E.LAW_NOCORR, n=per.size, x=per, iwave=2, igr=igr, name="rdispgr" if igr else "rdispph"),
@@ -97,7 +101,7 @@ def build_workload(name, B, L, seed):
             noise[:, 2 * t + 1] = rs.uniform(1e-3, 0.05, B)
         else:
             noise[:, 2 * t + 1] = rs.uniform(0.005, 0.05, B)
-    return spec, batches, noise, true_model(L), np.random.RandomState(SEED + 2)
+    return spec, batches, noise, true_model(10 if name == "c2p" else L), np.random.RandomState(SEED + 2)
 
 
 def observed_data(eng, spec, truth, nrs):
@@ -525,7 +529,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     steps between barrier + synchronize on both sides, max over ranks.  Returns the result block on rank 0."""
     import torch
     from bayhunter_amd import engine as E
-    B, L = args.batch, args.layers
+    B, L = args.batch, (PRIOR_LAYERS if workload == "c2p" else args.layers)
     spec, batches, noise, truth, nrs = build_workload(workload, B, L, seed=20260927 + 1000 * rank)
     observed_data(eng, spec, truth, nrs)
     eng.set_targets(spec)
@@ -588,6 +592,8 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
     eng.set_instrumentation(timing=False, counting=False)
     eng.set_model_order(sort_by_depth=True)
     n_failed = int((d_err != 0).sum().item())
+    # models of the LAST step that the short refinement's guard sent back to the reference's sequence (the second launch of the step)
+    n_guarded = int(sum(eng.guard_stats()[0])) if eng.swd_search() != "reference" else 0
     finite = bool(torch.isfinite(d_logL).all().item())
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
@@ -647,10 +653,12 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
         "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic" if not dryrun else "synthetic (DRY RUN: all ranks on one GPU, gloo)",
-        "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
-                                "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), 10-layer, batch=4096 models/step/GPU, exp law on RF",
-                                "c2g": "joint Rayleigh+Love GROUP dispersion, 10-layer, 30 periods, batch=4096 models/step/GPU, nocorr law",
-                                "c3g": "c3 with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF"}[workload],
+        "config": {"workload": {"c2": "joint Rayleigh+Love phase dispersion, %d-layer, 30 periods, batch=%d models/step/GPU, nocorr law" % (L, B),
+                                "c2p": "c2's targets on models drawn from the chains' prior: ragged 2..%d layers, velocities in any order, thickmin 0.1, "
+                                       "batch=%d models/step/GPU" % (L, B),
+                                "c3": "joint Rayleigh+Love phase dispersion + P-RF (gauss 2.5, nsamp 2048), %d-layer, batch=%d models/step/GPU, exp law on RF" % (L, B),
+                                "c2g": "joint Rayleigh+Love GROUP dispersion, %d-layer, 30 periods, batch=%d models/step/GPU, nocorr law" % (L, B),
+                                "c3g": "c3 (%d-layer, batch=%d) with the Gauss law (fixed r = 0.92, rcond 1e-6) on the RF" % (L, B)}[workload],
                    "batch_per_gpu": B, "layers": L, "periods": int(K), "targets": [s["name"] for s in spec],
                    "search": eng.swd_search(),
                    "parallelism": "models sharded one batch per GPU, no data-path collective"},
@@ -660,7 +668,7 @@ def run_eval(args, eng, rank, world, dist, dev, workload, dryrun, with_cpu=True,
         "roofline": roof,
         "kernel_ms_per_step": {k: v / max(1, ncalls) for k, v in fam_ms.items()},
         "gpu_ms_per_step": tot_ms / max(1, ncalls),
-        "failed_models_last_step": n_failed, "logL_finite": finite,
+        "failed_models_last_step": n_failed, "guarded_models_last_step": n_guarded, "logL_finite": finite,
     }
     if world > 1:
         out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
@@ -726,6 +734,8 @@ def make_summary(out):
     for w in ("c3", "c2g", "c3g", "c4", "c5", "c5_full"):
         if w in out:
             sm[w] = vm(out[w])
+    if isinstance(out.get("c2p"), dict) and out["c2p"].get("value") is not None:   # [value, ms/step, guarded fraction of the last step]
+        sm["c2p"] = vm(out["c2p"]) + [float("%.3g" % (out["c2p"].get("guarded_models_last_step", 0) / max(1, out["c2p"]["config"]["batch_per_gpu"])))]
     for name, tag in (("reference_search", "_ref"), ("fast_search", "_fast")):
         fs = out.get(name, {})
         for w in ("c2", "c3", "c4", "c5", "c5_full"):
@@ -744,7 +754,7 @@ def make_summary(out):
         if isinstance(out.get(w), dict) and "config" in out[w]:
             sm[w + "_swaps"] = out[w]["config"].get("accepted_swaps")
     sm["search"] = out["config"].get("search")
-    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..)"
+    sm["units"] = "[value, ms/step]; evals/s (c2..c3g), chain-it/s (c4..); c2p: + guarded fraction"
     return sm
 
 
@@ -774,7 +784,7 @@ def compact_line(full, full_path=None):
     """The ONE line rank 0 prints: the contract's keys, `roofline` (+ binding), `cpu_baseline`, a five-key `parity_check`
     and the summary -- a whitelist, so that whatever the blocks grow by lands in the full record and never in the line."""
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                        "vs_baseline", "dtype", "data", "error"))
+                        "vs_baseline", "dtype", "data", "error", "failed_models_last_step", "guarded_models_last_step"))
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, ("workload", "batch_per_gpu", "layers", "periods", "targets", "search", "parallelism",
                                  "chains_per_gpu", "accepted_swaps"))
@@ -820,7 +830,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="all", choices=["all", "c2", "c3", "c2g", "c3g", "c4", "c5", "c5_full"],
+    ap.add_argument("--workload", default="all", choices=["all", "c2", "c2p", "c3", "c2g", "c3g", "c4", "c5", "c5_full"],
                     help="all (default): the c2 line (headline) with the other configs in its summary; or one workload")
     ap.add_argument("--chains", type=int, default=0, help="c4/c5: chains per GPU (default 8 / 64)")
     ap.add_argument("--chain-steps", type=int, default=0, help="c4/c5: timed iterations per chain (default: --steps with "
@@ -915,7 +925,7 @@ def main():
         # region), c4 / c5 = configs[3] / [4] per-GPU shares
         out = run_eval(args, eng, rank, world, dist, dev, "c2", dryrun)
         blocks = {}
-        for w in ("c3", "c2g", "c3g"):       # configs[2] and the "second runs" of SURVEY.md 8(d) (no CPU leg)
+        for w in ("c3", "c2g", "c3g", "c2p"):       # configs[2], the "second runs" of SURVEY.md 8(d), c2 on prior-like models (no CPU leg)
             try:
                 blocks[w] = run_eval(args, eng, rank, world, dist, dev, w, dryrun, with_cpu=False, rf_roof=(w == "c3"))
             except Exception as ex:

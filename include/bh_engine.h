@@ -36,6 +36,8 @@
  *     never read.
  *   - The caller owns every buffer it passes.  The engine keeps no pointer after a call
  *     returns, except copies of the constant target data registered by bh_targets_set.
+ *   - Measurement, diagnostic and experiment entry points (timing, counters, launch-geometry knobs, probes) live in
+ *     include/bh_engine_debug.h: not part of this contract.
  *   - One engine = one GPU = one stream; calls on one engine must be serialised by the caller
  *     (the reference is single-threaded per chain as well).
  */
@@ -49,7 +51,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 9
+#define BH_ABI_VERSION 10
 
 enum { BH_OK = 0, BH_EINVAL = -1, BH_EHIP = -2, BH_ENOMEM = -3, BH_EUNSUPPORTED = -4 };
 enum { BH_HOST = 0, BH_DEVICE = 1 };
@@ -74,27 +76,27 @@ int bh_abi_version(void);
 int bh_engine_create(int device, bh_engine **out);
 void bh_engine_destroy(bh_engine *e);
 const char *bh_engine_last_error(const bh_engine *e);
-/* Tuning knob: lanes of a wavefront that cooperate on ONE model in the dispersion kernel
- * (1..32; 0 = choose from the batch size and layer count, the default).  Results do not depend on it. */
-int bh_engine_set_swd_group(bh_engine *e, int lanes_per_model);
-/* Tuning knob: trial phase velocities evaluated per round of the root search in the dispersion
- * kernel (1..16; 0 = choose from the batch size, the default; with one lane per model -- group 1 -- the
- * largest power of two not above it is used).  The search (surfdisp96.f:390-686) asks
- * for one secular-function value at a time; with look-ahead the kernel also evaluates, on further
- * lanes, the velocities the search will most probably ask for next and hands them over if and only
- * if it does.  Results do not depend on it. */
-int bh_engine_set_swd_lookahead(bh_engine *e, int trials_per_round);
 /* Root refinement of the dispersion search (surfdisp96.f:390-686).
  *   BH_SEARCH_REFERENCE  the reference's sequence of secular-function evaluations (getsol + nevill), evaluation for
  *                        evaluation: velocities and failure flags bit-identical to the reference's.
- *   BH_SEARCH_FAST       (the default) the reference's bracket scan -- the same bracket, hence the same root -- and inside the
- *                        bracket three evaluations instead of nevill's ten to twelve.  GUARANTEES: velocities within 1e-5
- *                        relative of the reference's (achieved: 1.2e-6); the failure flag and the period from which a failed
- *                        model's row is zero are the reference's (a model whose outcome could hinge on the last bits of a
- *                        root is detected and run again with the reference's sequence inside the same call;
- *                        bh_engine_guard_stats counts them); the result is a function of the model alone (not of the batch
- *                        or the launch).  NOT the reference's bits.  Applies to fundamental-mode phase-velocity targets;
- *                        group-velocity targets and targets with higher modes always take the reference's sequence.
+ *   BH_SEARCH_FAST       (the default) the reference's bracket scan -- the same grid, the same bracket -- and inside the
+ *                        bracket a few evaluations instead of nevill's ten to twelve.  GUARANTEES: velocities within 1e-5
+ *                        relative of the reference's (asserted: 2e-6); the failure flag and the period from which a failed
+ *                        model's row is zero are the reference's.  A model whose outcome could hinge on the last digits of a
+ *                        root, or on WHICH of several roots of one scan cell nevill ends at (a cell that holds a half-space
+ *                        velocity or betmx can hold a root, its mirror image and more), is detected and run again with the
+ *                        reference's sequence inside the same call; bh_engine_guard_stats counts them.  NOT the reference's
+ *                        bits.  WHAT A RESULT DEPENDS ON: the model, and -- in its last digits, ~1e-9 relative, up to the
+ *                        reference's own 1e-6 where the guard fires under one setting and not under another -- the kernel that
+ *                        ran and its trials per round.  With BH_ARITH_EXACT that is the model alone.  With BH_ARITH_FAST
+ *                        (the default) the trial-per-lane kernel picks its trials per round from the call's shape (64 up to
+ *                        1024 (model, target) pairs, 32 up to 5120, 16 up to 10240, 8 up to 28672, 4 beyond; arrays deeper
+ *                        than 32 layers, or whose LDS need exceeds a workgroup's, take the lane-per-evaluation kernel): the SAME
+ *                        model in calls of different shapes may differ in those last digits.  bh_engine_set_swd_trials pins the
+ *                        number: then a model's result does not depend on the batch it is in, its position, or the launch
+ *                        (tests/test_gpu_swd_lean.py::test_result_is_a_function_of_the_model_and_the_trials).  Applies to
+ *                        fundamental-mode phase-velocity targets; group-velocity targets and targets with higher modes always
+ *                        take the reference's sequence.
  *   BH_SEARCH_FAST_RAYLEIGH  BH_SEARCH_FAST for Rayleigh targets, BH_SEARCH_REFERENCE for Love targets.
  * A replay against chains recorded with the reference needs BH_SEARCH_REFERENCE. */
 #define BH_SEARCH_REFERENCE 0
@@ -113,65 +115,20 @@ int bh_engine_get_swd_search(const bh_engine *e);
  *                   ones (|f_fast - f_exact| <= 1.2e-8 of the vector's max-norm, below 1e-11 in 99.6 % of 10^8 sampled
  *                   evaluations) -- a root moves by ~1e-13 relative; a scan's sign pattern can differ from the exact one's
  *                   only where a root lies within ~1e-8 of a grid point (the bracket then moves one step around the same
- *                   root).  The GUARANTEES of BH_SEARCH_FAST are asserted for this arithmetic as well: velocities within
- *                   1e-5 of the reference's (achieved 2e-6), failure flags and zero rows the reference's on 1.7 million
- *                   LVZ-rich models; a value that is not a number (an argument beyond the reduction's range) sends the model
- *                   back to the reference's sequence and arithmetic, like any guarded model. */
+ *                   root).  The GUARANTEES of BH_SEARCH_FAST (tolerance, failure flags, zero rows) are asserted for this
+ *                   arithmetic on 1.7 million fixed LVZ-rich models and, in every run of the suite, on 200 000 fresh ones
+ *                   incl. models drawn from a sampler's prior (tests/test_gpu_fuzz.py); a value that is not a number (an
+ *                   argument beyond the reduction's range) sends the model back to the reference's sequence and arithmetic,
+ *                   like any guarded model. */
 #define BH_ARITH_EXACT 0
 #define BH_ARITH_FAST 1
 int bh_engine_set_swd_arith(bh_engine *e, int arith);
 int bh_engine_get_swd_arith(const bh_engine *e);
-/* Which dispersion kernel the most recent call with dispersion targets launched (diagnostic; -1: none yet):
- *   BH_KERNEL_GROUP  several lanes per model, layer-parallel (swd_group_kernel),
- *   BH_KERNEL_LANE   one lane per evaluation, reference-exact or FA builds (swd_kernel),
- *   BH_KERNEL_LEAN   one lane per trial velocity with the fast arithmetic (swd_lean_kernel): BH_SEARCH_FAST + BH_ARITH_FAST
- *                    calls whose targets are all fundamental-mode phase velocities, in arrays of up to 32 layers.  It
- *                    evaluates 64 trial velocities per model and round in calls of up to 1024 (model, target) pairs, 32 up
- *                    to 5120, 16 up to 10240, 8 up to 28672 and 4 beyond; a model's velocities depend on that number in their last bits (~1e-9 relative; a
- *                    model whose guard fires under one count and not under another: the reference's 1e-6) and on nothing
- *                    else about the call. */
-/* Trials per model and round of BH_KERNEL_LEAN: 0 (default) = by the call's shape as described above; 4, 8, 16, 32 or 64 =
- * that many in every call -- what a sampler sets whose windows and shards must give the same bits whatever their size
- * (DeviceChains: 32). */
+/* Trials per model and round of the trial-per-lane kernel (BH_SEARCH_FAST + BH_ARITH_FAST): 0 (default) = by the call's shape
+ * as described at BH_SEARCH_FAST; 4, 8, 16, 32 or 64 = that many in every call -- what a sampler sets whose windows, initial
+ * state and shards must give the same bits whatever their size (DeviceChains: 32). */
 int bh_engine_set_swd_trials(bh_engine *e, int trials);
 int bh_engine_get_swd_trials(const bh_engine *e);
-#define BH_KERNEL_GROUP 0
-#define BH_KERNEL_LANE 1
-#define BH_KERNEL_LEAN 2
-int bh_engine_last_swd_kernel(const bh_engine *e);
-/* The bracket scan of Love targets (any root refinement).  Results never depend on this setting.
- * getsol's scan (surfdisp96.f:437-460) evaluates every step of its grid until the secular function changes sign.  For Love
- * waves the number of sign changes below a trial velocity is read off the recursion that evaluates the function (a Sturm
- * count), so two evaluations prove that the steps between them hold no sign change (they are skipped) or exactly one (it is
- * located by a search over the step index).  Grid points, bracket and every bit after it are the reference's.
- *   BH_SCAN_STEPS    every step evaluated, as the reference does.
- *   BH_SCAN_COUNTED  the counted scan wherever a launch holds a Love target -- except launches of several models per
- *                    wavefront that mix both root refinements (that kernel build does not carry it).
- *   BH_SCAN_AUTO     (default) the counted scan in the launches where it is measured to pay (docs/HISTORY.md 3.1a).
- * Rayleigh targets always step; the trial-per-lane kernel (BH_KERNEL_LEAN) steps for both wave types, sixteen steps a round. */
-#define BH_SCAN_STEPS 0
-#define BH_SCAN_COUNTED 1
-#define BH_SCAN_AUTO 2
-int bh_engine_set_swd_scan(bh_engine *e, int scan);
-int bh_engine_get_swd_scan(const bh_engine *e);
-
-/* The certified-sign scan (OFF by default).  Results never depend on this setting.
- * getsol's bracket scan consumes only the SIGN of the secular function at its grid points.  With this on, a search first
- * evaluates the grid ahead with a cheap evaluation of the same recursion that carries an error bound (one lane per grid
- * point) and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's; the
- * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
- * step-by-step scan.  Applies to both root refinements and all target types in launches of several models per wavefront
- * (a few thousand models per call); ignored elsewhere.  Measured not to pay (the look-ahead costs what the skipped rounds
- * cost): off. */
-int bh_engine_set_swd_prescan(bh_engine *e, int on);
-int bh_engine_get_swd_prescan(const bh_engine *e);
-
-/* Experiment switches (csrc/bh_tuning.h lists them: name, environment variable, default, meaning).  They change scheduling
- * and launch geometry, never a result.  The table is filled once per process from the environment; this call changes one
- * entry for the calls that follow (process-wide).  BH_EINVAL for an unknown name, and always in a build with
- * -DBH_NO_EXPERIMENTS.  Not needed by a caller that only wants results. */
-int bh_engine_set_tuning(bh_engine *e, const char *name, int value);
-int bh_engine_get_tuning(bh_engine *e, const char *name, int *value);
 /* BH_SEARCH_FAST statistics: counts[t] (BH_MAX_TARGETS entries; may be NULL) = models of target t of the most recent
  * dispersion call that its guard sent back to the reference's sequence (listed for the re-run launch, or restarted in place
  * in a launch of one model per wavefront); *rerun_launches (may be NULL) = re-run launches
@@ -365,46 +322,6 @@ int bh_chain_propose_window(void *stream, const bh_chain_config *cfg, const bh_c
                             int depth, ptrdiff_t ld);
 int bh_chain_accept_window(void *stream, const bh_chain_config *cfg, const bh_chain_state *state, int C, int iiter,
                            int depth, ptrdiff_t ld, const double *logL, const double *misfits);
-
-/* ---- diagnostics -------------------------------------------------------------------------
- * Evaluate one elementary function on the device for n float64 inputs (host pointers):
- * op 0 sqrt, 1 sin, 2 cos, 3 exp, 4 log, 5 1/x; op 6 / 7: in holds n pairs (a, b), out[i] = a/b
- * through the shared-reciprocal sequence of the kernels (6) or the plain operator (7); op 8 / 9 / 10:
- * sin / cos / exp through the kernels' glibc-exact restatement (csrc/bh_libm.h).  Used by the tests to document how far the
- * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
-int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
-/* Diagnostic: the certified-sign evaluation (see bh_engine_set_swd_prescan) of n (omega, c) points of one model of nlay
- * layers (host float arrays): val = the surface value under the per-layer max-norm scaling, bound = its error bound,
- * certified = |val| > 2 bound.  tests/test_gpu_csign.py compares the three with oracle/csign_oracle.c bit for bit. */
-int bh_probe_csign(bh_engine *e, int iwave, int nlay, const float *h, const float *vp, const float *vs, const float *rho,
-                   int n, const double *omega, const double *c, double *val, double *bound, int32_t *certified);
-
-/* Instrumentation (off by default; bench.py and the tests turn it on).
- *   timing:   HIP events are recorded on the stream the kernels are launched on, around each
- *             kernel family of every *_batch call made after bh_timing_reset().  Nothing is
- *             synchronised until bh_timing_collect(), which waits for the events and returns the
- *             number of calls, the SUM over those calls of the span first-kernel-start ->
- *             last-kernel-end (total_ms) and of the time inside each kernel family:
- *             family_ms[0] dispersion (swd), [1] receiver function, [2] likelihood.
- *   counting: the dispersion kernels add up their secular-function evaluations; bh_last_neval()
- *             returns the count of the most recent call (the flop model of SURVEY.md 8(d) is
- *             layer-propagator steps = evaluations x (nlay-1)). */
-int bh_engine_set_instrumentation(bh_engine *e, int timing, int counting);
-int bh_timing_reset(bh_engine *e);
-int bh_timing_collect(bh_engine *e, int *ncalls, double *total_ms, double family_ms[3]);
-/* Per-call timing of the calls since bh_timing_reset(), from the same events: step_ms[i] = start of call i -> start of
- * call i+1 (back-to-back calls: one "step" each, gaps included), for the last call its own span.  Writes at most
- * `max` entries and returns their number in *n.  (No further events: a marker recorded on the launch stream between
- * two calls changes how the next call's two lane-kernel launches pair up on the SIMDs -- 8.1 -> 10.6 ms at B = 16 384.) */
-int bh_timing_steps(bh_engine *e, int max, double *step_ms, int *n);
-int bh_last_neval(bh_engine *e, uint64_t *neval);
-/* raw counter block of the last counted call: [0] secular evaluations, [1..3] / [4..6] wave-cycles per phase
- * (development aid), [7] wavefronts, [8] / [9] evaluations of the Rayleigh / Love targets, [10] / [11] their
- * layer-propagator steps (evaluations x finite layers: the flop model of the roofline block in bench.py) */
-int bh_debug_counters(bh_engine *e, uint64_t out[16]);
-/* development aid: one record of 4 words per traced wavefront of the last counted dispersion launch
- * (start, end [100 MHz ticks], core cycles, rounds | wave type << 32 | HW_ID << 36); counter [7] = wavefronts */
-int bh_debug_trace(bh_engine *e, uint64_t *out, int nwaves);
 
 #ifdef __cplusplus
 }

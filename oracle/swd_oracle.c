@@ -665,15 +665,18 @@ static void guard_after_root(const medium *md, double omega, double c1, double c
 }
 
 /* A bracketed root: the refinement (+ the guard of search mode 2).  Returns 1 ok / -1 failed / -2 the guard fired.
- * A bracket that contains betmx can hold THREE sign changes (the root, its mirror image, and the first of the unphysical
- * ones above the half-space velocity): which of them nevill ends at depends on its whole sequence, so the short sequence
- * does not try -- the guard fires. */
+ * A bracket that contains betmx or a half-space velocity can hold THREE sign changes (the root, its mirror image above the
+ * half-space velocity, and the first of the unphysical ones beyond): which of them nevill ends at depends on its whole
+ * sequence, so the short sequence does not try -- the guard fires (SearchT::bracketed, swd_common.h: the same rule). */
 static int refine_bracket(const medium *md, double t1, double omega, double c1, double c2, double del1, double del2,
                           double betmx, int fast, guard_t *gd, double *c1io, double cp, double delp, int have_p)
 {
-    if (fast && gd && gd->on && fmax(c1, c2) > betmx && fmin(c1, c2) < betmx) {
-        gd->hit = 1;
-        return -2;
+    if (fast && gd && gd->on) { /* betmx or a half-space velocity (gd->vh: S, P / betmx, betmx) inside the bracket */
+        const double lo = fmin(c1, c2), hi = fmax(c1, c2);
+        if ((hi > betmx && lo < betmx) || (hi > gd->vh[0] && lo < gd->vh[0]) || (hi > gd->vh[1] && lo < gd->vh[1])) {
+            gd->hit = 1;
+            return -2;
+        }
     }
     const double cn = fast ? refine_root_fast(md, t1, c1, c2, del1, del2, betmx, cp, delp, have_p) : refine_root(md, t1, c1, c2, del1, del2);
     *c1io = cn;

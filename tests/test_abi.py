@@ -1,5 +1,5 @@
-"""The C-ABI shared library: builds for gfx950, loads, and exports exactly what
-include/bh_engine.h declares.  No compute calls (runs without a GPU)."""
+"""The C-ABI shared library: builds for gfx950, loads, and exports exactly what include/bh_engine.h (the drop-in contract) and
+include/bh_engine_debug.h (measurement and diagnostics) declare.  No compute calls (runs without a GPU)."""
 import ctypes
 import os
 import re
@@ -9,8 +9,8 @@ import pytest
 from conftest import REPO
 
 
-def declared_symbols():
-    txt = open(os.path.join(REPO, "include", "bh_engine.h")).read()
+def declared_symbols(header="bh_engine.h"):
+    txt = open(os.path.join(REPO, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(bh_[a-z_]+)\s*\(", txt)))
 
@@ -20,19 +20,22 @@ def test_library_built_and_exports_every_declared_symbol():
     assert os.path.exists(E.LIB_PATH), "run __graft_entry__.build() first"
     lib = ctypes.CDLL(E.LIB_PATH)
     decl = declared_symbols()
-    assert len(decl) >= 14
-    for name in decl:
+    assert 14 <= len(decl) <= 25           # the contract stays small: everything else lives in the debug header
+    dbg = declared_symbols("bh_engine_debug.h")
+    assert not set(decl) & set(dbg)
+    for name in decl + dbg:
         assert hasattr(lib, name), "missing export %s" % name
     assert sorted(E.EXPORTED_SYMBOLS) == decl
-    assert lib.bh_abi_version() == 9
+    assert sorted(E.DEBUG_SYMBOLS) == dbg
+    assert lib.bh_abi_version() == 10
 
 
 def test_python_constants_mirror_the_header():
     """Enumerations the ctypes layer restates (error codes, target kinds, laws, search modes, ABI version)."""
     from bayhunter_amd import engine as E
-    txt = open(os.path.join(REPO, "include", "bh_engine.h")).read()
+    txt = open(os.path.join(REPO, "include", "bh_engine.h")).read() + open(os.path.join(REPO, "include", "bh_engine_debug.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"^#define\s+(BH_[A-Z0-9_]+)\s+(-?\d+)\b", txt, flags=re.M)}
-    assert defs["BH_ABI_VERSION"] == 9
+    assert defs["BH_ABI_VERSION"] == 10
     assert (defs["BH_SEARCH_REFERENCE"], defs["BH_SEARCH_FAST"], defs["BH_SEARCH_FAST_RAYLEIGH"]) == (E.SEARCH_REFERENCE, E.SEARCH_FAST, E.SEARCH_FAST_RAYLEIGH) == (0, 1, 2)
     assert (defs["BH_SCAN_STEPS"], defs["BH_SCAN_COUNTED"], defs["BH_SCAN_AUTO"]) == (E.SCAN_STEPS, E.SCAN_COUNTED, E.SCAN_AUTO) == (0, 1, 2)
     assert defs["BH_CHAIN_MAXDEPTH"] == E.BH_CHAIN_MAXDEPTH

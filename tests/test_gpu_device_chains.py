@@ -401,3 +401,32 @@ def test_baseline_config4_shape_tempered_transdimensional_ladder():
     s = dc.samples("p2", cold_only=True)
     assert s["models"].shape[:2] == (len(dc.snap["p2"]), nl) and (s["beta"] == 1.0).all()
     assert s["models"].shape[2] == 2 * 21
+
+
+def test_initial_state_and_windows_do_not_depend_on_the_shard_size():
+    """the chains' evaluation calls run the trial-per-lane kernel with the trials per round PINNED (DeviceChains.TRIALS)
+    -- the windows AND the host-driven initial state -- so a shard's chains get the bits they get in the whole job whatever the
+    shard's size.  600 chains x 2 dispersion targets are 1200 (model, target) pairs (32 trials by the call's shape), a shard of
+    150 of them 300 pairs (64 by shape): initial likelihoods and the states after a few windows agree bit for bit."""
+    g = golden("chain_golden.npz")
+    su = SETUPS["exp"]
+
+    def targets():
+        t1 = bh.RayleighDispersionPhase(g["xsw"], g["ysw"])
+        t2 = bh.LoveDispersionPhase(g["xsw"], 1.05 * g["ysw"])
+        return bh.JointTarget([t1, t2])
+    priors = dict(su["priors"])
+    init = dict(su["init"], iter_burnin=60, iter_main=20, maxmodels=5)
+    whole = DeviceChains(targets(), 600, init, priors, seed=11)
+    shard = DeviceChains(targets(), 150, init, priors, seed=11, chain_offset=300)
+    a, b = whole.state_host(), shard.state_host()
+    sl = slice(300, 450)
+    assert np.array_equal(a["like"][sl], b["like"]) and np.array_equal(a["misfits"][:, sl], b["misfits"])
+    assert np.array_equal(a["vs"][:, sl], b["vs"], equal_nan=True)
+    for _ in range(4):
+        whole.iterate()
+        shard.iterate()
+    assert whole.iiter == shard.iiter
+    a, b = whole.state_host(), shard.state_host()
+    assert np.array_equal(a["like"][sl], b["like"]) and np.array_equal(a["n"][sl], b["n"])
+    assert np.array_equal(a["vs"][:, sl], b["vs"], equal_nan=True) and np.array_equal(a["accepted"][:, sl], b["accepted"])

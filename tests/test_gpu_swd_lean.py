@@ -194,6 +194,38 @@ def test_a_model_alone_a_window_and_a_batch_give_the_same_bits(lean):
         assert np.array_equal(vp_, va[perm]) and np.array_equal(ep_, ea[perm])
 
 
+@pytest.mark.parametrize("trials", [16, 32])
+def test_result_is_a_function_of_the_model_and_the_trials(lean, trials):
+    """What include/bh_engine.h promises of the default path: with the trials per round PINNED
+    (bh_engine_set_swd_trials) a model's velocities and flag do not depend on the call it is in -- calls on either side of the
+    shape thresholds (1024 / 5120 / 10240 (model, target) pairs), a model alone, a slice, prior-like models.  With the number
+    left to the call's shape (0) the same model may differ in its last digits between shapes: asserted to stay within the
+    reference's own 1e-6 scatter (2e-6), never a different flag."""
+    from bayhunter_amd.synth import prior_models
+    rs = np.random.RandomState(4242 + trials)
+    a = synth_models(rs, 6000, 12, lvz_frac=0.3, ragged=True)
+    b = prior_models(rs, 6000, 12)
+    nlay, h, vp, vs, rho = [np.concatenate((x, y), axis=-1) for x, y in zip(a, b)]   # 12 000 models: 16 trials per round by shape
+    per = np.linspace(2, 60, 30)
+    cuts = [(0, 12000), (0, 900), (900, 5000), (5000, 5001), (6000, 6700), (6700, 12000)]   # 64 / 32 / 64 / 64 / 16 ... by shape
+    for iwave in (2, 1):
+        lean.set_swd_trials(trials)
+        try:
+            va, ea = lean.swd_batch(nlay, h, vp, vs, rho, per, iwave, 0)
+            assert lean.last_swd_kernel() == "lean"
+            for lo, hi in cuts[1:]:
+                sl = slice(lo, hi)
+                v, e = lean.swd_batch(nlay[sl], h[:, sl], vp[:, sl], vs[:, sl], rho[:, sl], per, iwave, 0)
+                assert np.array_equal(v, va[sl]) and np.array_equal(e, ea[sl]), (iwave, lo, hi)
+        finally:
+            lean.set_swd_trials(0)
+        for lo, hi in cuts[1:]:       # by the call's shape: last digits only
+            sl = slice(lo, hi)
+            v, e = lean.swd_batch(nlay[sl], h[:, sl], vp[:, sl], vs[:, sl], rho[:, sl], per, iwave, 0)
+            assert np.array_equal(e, ea[sl]) and np.array_equal(v == 0, va[sl] == 0)
+            assert worst_rel(v, va[sl], (v != 0) & (va[sl] != 0)) <= ACHIEVED
+
+
 def test_the_order_per_xcd_is_scheduling_only(lean, oracle):
     """Where the shapes divide (4096 models with 16 trials per round, 2048 with 32 ...) the models are ordered inside eight blocks of
     the batch, a block per XCD, and the second target runs them in the opposite order inside the XCDs (bh_tuning.h: swd_lean_xcd,

@@ -9,6 +9,7 @@ hints (dev tool; the fixed cases live in tests/).
                                                    to ITS CPU restatement (oracle search mode 2), and against the reference
                                                    sequence: failure flags and zero patterns (both must be the reference's),
                                                    worst relative difference; how many models the guard re-ran
+    PRIOR=1 ...                                    models drawn from a sampler's prior (bayhunter_amd.synth.prior_models) instead of sorted velocities
     SCAN=steps|counted ...                         every scan step evaluated / the counted Love scan wherever a Love target is
                                                    (default: the engine's BH_SCAN_AUTO)"""
 import os, sys, time
@@ -16,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from bayhunter_amd import engine as E
-from bayhunter_amd.synth import synth_models
+from bayhunter_amd.synth import synth_models, prior_models
 from oracle import oracle as O
 
 eng = E.Engine(0)
@@ -26,11 +27,13 @@ dev = torch.device("cuda:0")
 bad = 0
 LEAN = os.environ.get("LEAN", "0") == "1"      # the engine's defaults: short refinement + fast arithmetic, the planner's own launch
 FAST = os.environ.get("FAST", "0") == "1" or LEAN
+PRIOR = os.environ.get("PRIOR", "0") == "1"
 eng.set_swd_search("fast" if FAST else "reference")
 eng.set_swd_arith("fast" if LEAN else "exact")   # (FAST = 1 alone: the reference's arithmetic, compared bit for bit with its restatement)
 if os.environ.get("SCAN", "auto") in ("steps", "counted"):     # (default: the engine's BH_SCAN_AUTO)
     eng.set_swd_scan(os.environ["SCAN"])
 nguard = 0
+nbad_dumped = 0
 worst, flagdiff, zerodiff, nmodels = 0.0, 0, 0, 0
 t0 = time.time()
 for it in range(ncfg):
@@ -40,6 +43,8 @@ for it in range(ncfg):
     nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=float(rs.choice([0.0, 0.2, 0.5])), ragged=ragged)
     if L > 10:
         h[:-1] *= 10.0 / L
+    if PRIOR and L >= 2:   # models as a sampler proposes them: velocities in any order, thin layers (PRIOR=1)
+        nlay, h, vp, vs, rho = prior_models(rs, B, L, nmin=2 if ragged else L)
     K = int(rs.choice([1, 5, 21, 30, 60]))
     per = np.sort(rs.uniform(1.0, 80.0, K)) if rs.rand() < 0.5 else np.linspace(2, 60, K)
     iwave, igr = int(rs.choice([1, 2])), int(rs.choice([0, 1]))
@@ -78,6 +83,15 @@ for it in range(ncfg):
             if w > 1e-5:
                 print("TOLERANCE", w, dict(B=B, L=L, K=K, iwave=iwave, igr=igr, mode=mode, flsph=flsph), flush=True)
             worst = max(worst, w)
+        # (dev aid: the worst models of the configurations that miss the tolerance or a flag, for a look on the CPU: BH_FUZZ_DUMP=dir)
+        if os.environ.get("BH_FUZZ_DUMP") and nbad_dumped < 12:
+            rel = np.zeros_like(v); rel[both] = np.abs(v[both] - rv[both]) / np.abs(rv[both])
+            badm = np.where((rel.max(axis=1) > 1e-5) | (e != re_) | ((v == 0) != (rv == 0)).any(axis=1))[0]
+            for b_ in badm[:2]:
+                os.makedirs(os.environ["BH_FUZZ_DUMP"], exist_ok=True)
+                np.savez(os.path.join(os.environ["BH_FUZZ_DUMP"], "bad_%d_%d.npz" % (it, b_)), nlay=nlay[b_], h=h[:, b_], vp=vp[:, b_], vs=vs[:, b_], rho=rho[:, b_],
+                         per=per, iwave=iwave, flsph=flsph, lean=v[b_], ref=rv[b_], elean=e[b_], eref=re_[b_], k=int(np.argmax(rel[b_])))
+                nbad_dumped += 1
         flagdiff += int((e != re_).sum())
         zerodiff += int(((v == 0) != (rv == 0)).any(axis=1).sum())
         nmodels += B
