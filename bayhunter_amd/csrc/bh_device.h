@@ -131,7 +131,6 @@ struct SwdMultiArgs {
                        // own model (swd_group_kernel<.., ADAPT>); 0: the caller fixed lanes or trials (experiments)
     int counted;       // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
     int rerun;         // 1: the launch re-runs listed models (SwdTarget::count): plain two-dimensional grid, no SIMD pairing
-    int prescan;       // 1: scans look ahead over their grid with the certified-sign evaluation (SearchT<.., PRE>; same bits)
     int farith;        // 1: launches in which every target takes the short refinement evaluate the secular functions with the fast
                        //    arithmetic (swd_fa.h, swd_group_kernel<.., FA>); set to what took effect by the launcher
     int restart;       // 1: in a launch of one model per wavefront a model the guard fires on starts again with the reference's
@@ -174,8 +173,8 @@ struct SwdLaunchInfo {
 // the launches of the builds with the fast arithmetic (swd_group_fa.hip); called by bh_launch_swd_group
 void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
                             bool adapt, bool counted, bool cntb);
-// the launches of the builds with the certified-sign scan (swd_group_prek.hip); called by bh_launch_swd_group
-void bh_launch_swd_group_prek(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds, int build);
+// the launch of the build that needs one wavefront per SIMD as its register budget (swd_group_big.hip); called by bh_launch_swd_group
+void bh_launch_swd_group_big(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,
                         SwdPairWork *pair = nullptr);
 // swd_lean.hip: fundamental-mode phase velocities with the fast arithmetic, one lane per trial velocity (the kernel of the
@@ -211,7 +210,6 @@ struct RfKernelArgs {
     int no_realc;  // experiment switch: 1 = always the general (complex-coefficient) recursion
     int coef_small; // 1: the 96-register build of the coefficient kernel (fused call: resident beside the dispersion wavefronts)
     int no_rot;    // experiment switch: 1 = no rotation of the bins over a workgroup's wavefronts
-    int beside;    // > 0: the 96-register build that runs beside two dispersion wavefronts per SIMD, at issue priority beside - 1
 };
 size_t bh_rf_coef_doubles(int Lmax);
 // LDS of one workgroup of the synthesis kernel for traces of nsamp samples; a CU has 160 KB, one workgroup may use all
@@ -246,6 +244,5 @@ struct LikeKernelArgs {
 void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream);
 
 void bh_launch_probe(int op, int n, const double *in, double *out, hipStream_t stream);
-// the certified-sign evaluation (swd_csign.h) of n (omega, c) points of ONE model (mdl: h, vp, vs, rho, nlay floats each):
+
 // out = [val n][bound n][certified n]
-void bh_launch_csign_probe(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out, hipStream_t stream);

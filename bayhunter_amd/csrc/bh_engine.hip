@@ -40,8 +40,6 @@ void tuning_clamp()
     if (g_tuning.rf_lds_gated < 0 || g_tuning.rf_lds_gated > 160 * 1024) g_tuning.rf_lds_gated = 0;
     if (g_tuning.rf_lds_beside > 160 * 1024) g_tuning.rf_lds_beside = -1;
     if (g_tuning.swd_love_inlook < 0 || g_tuning.swd_love_inlook > 4) g_tuning.swd_love_inlook = 0;
-    if (g_tuning.swd_wpb != 4) g_tuning.swd_wpb = 2;
-    g_tuning.rf_beside_prio &= 3;
 }
 void tuning_parse()
 {
@@ -116,8 +114,6 @@ struct bh_engine {
     // co-resident receiver function (see bh_evaluate_batch): the dispersion kernel counts its started workgroups here
     unsigned *started = nullptr;           // device word (signal memory where available), cumulative over launches
     unsigned started_expected = 0;         // value after every launch enqueued so far has started
-    bool rf_beside = false;                // BH_RF_BESIDE env turns the co-resident mode on (measured slower, see bh_evaluate_batch)
-    int rf_beside_prio = 0;                // BH_RF_BESIDE_PRIO env: issue priority (0..3) of the co-resident RF wavefronts
     int swd_prio_low = 1;                  // BH_SWD_PRIO_LOW env: dispersion wavefronts' low priority while RF wavefronts run beside them
     SwdPairWork pairwork{};                // SIMD-pairing order of the group kernel (bh_device.h)
     bool no_pair = false;                  // BH_SWD_NO_PAIR env: order by depth only (A/B testing)
@@ -127,9 +123,6 @@ struct bh_engine {
     int last_swd_wpb = 2;                  // its wavefronts per workgroup
     int err_t_nt = -1, err_t_B = -1;       // layout for which err_t's untouched rows are known to be zero
     int swd_prio_low_now = 0;              // per call: what the next dispersion launch gets
-    int swd_wpb_now = 2;                   // per call: wavefronts per workgroup of the next dispersion launch
-    int swd_wpb_default = 2;               // BH_SWD_WPB env (2 or 4; experiment switch)
-    bool rf_coresident_now = false;        // per call: RF kernels run in the co-resident mode
     bool rf_gated_now = false;             // per call: the RF stream waits for the dispersion kernel's workgroups to be resident
     std::string err;
     // staging / workspace
@@ -150,7 +143,6 @@ struct bh_engine {
     int hint_layers = 0; // bh_engine_set_typical_layers: typical layer count of device-resident batches
     int swd_search = BH_SEARCH_FAST;  // bh_engine_set_swd_search / BH_SWD_SEARCH=reference|fast|fast_rayleigh: the short refinement (with its guard) for fundamental-mode phase-velocity targets unless told otherwise
     int swd_arith = BH_ARITH_FAST; // bh_engine_set_swd_arith / BH_SWD_ARITH=exact|fast: fast arithmetic in launches where every target takes the short refinement
-    int swd_prescan = 0; // bh_engine_set_swd_prescan / BH_SWD_PRESCAN=0|1: scans look ahead with the certified-sign evaluation (same bits; off by default: measured not to pay)
     int swd_scan = 2;    // bh_engine_set_swd_scan / BH_SWD_SCAN=steps|counted|auto: Love scans skip the steps a mode count proves empty (same bits)
     DevBuf guard;        // short refinement: per target a count and a list of the models its guard fired on (re-run, see launch_swd_rerun)
     uint64_t rerun_launches = 0; // re-run launches enqueued so far (statistics)
@@ -556,7 +548,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         e->guard_last = any_fast;
         if (any_fast && (rc = guard_space(e, st, B, &gcounts, &glists))) return rc;
         SwdMultiArgs ra{}; // (the re-run of guarded models goes through the group kernel)
-        ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan; ra.prescan = e->swd_prescan;
+        ra.B = B; ra.Lmax = Lmax; ra.nlay = m.nlay; ra.neval = counter; ra.counted = e->swd_scan;
         if (any_fast) {
             if (!e->board.p) {
                 if ((rc = ensure(e, e->board, (size_t)BH_BOARD_WORDS * sizeof(unsigned)))) return rc;
@@ -641,7 +633,6 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         return t.igr == 0 && t.mode <= 1 && (e->swd_search == BH_SEARCH_FAST || (e->swd_search == BH_SEARCH_FAST_RAYLEIGH && t.iwave == BH_WAVE_RAYLEIGH));
     };
     a.counted = e->swd_scan;
-    a.prescan = e->swd_prescan;
     a.farith = e->swd_arith == BH_ARITH_FAST ? 1 : 0;
     for (int t = 0; t < a.ntargets; ++t) {
         if (e->look_r > 0 && a.t[t].iwave == BH_WAVE_RAYLEIGH) a.t[t].look = e->look_r;
@@ -694,9 +685,9 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         e->last_swd_kernel = BH_KERNEL_LEAN;
     } else {
         e->last_swd_kernel = BH_KERNEL_GROUP;
-        lrc = bh_launch_swd_group(a, G, st, &e->last_swd, e->swd_wpb_now, use_pair ? &e->pairwork : nullptr);
+        lrc = bh_launch_swd_group(a, G, st, &e->last_swd, 2, use_pair ? &e->pairwork : nullptr);
     }
-    e->last_swd_wpb = e->swd_wpb_now;
+    e->last_swd_wpb = lean ? 4 : 2; // (wavefronts per workgroup of the kernel that was launched)
     if (lrc != 0) {
         ev_end(e, 0, st);
         return fail(e, BH_EINVAL, "model too deep for LDS");
@@ -743,12 +734,11 @@ int launch_rf(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, pt
     // that remainder keeps them out of CUs whose dispersion wavefronts are still running, as in round 2 (40 KB).
     // (with the start gate of bh_evaluate_batch in force the LDS floor is not needed: RF workgroups are dispatched
     // after every dispersion wavefront is resident and only take what finished wavefronts have freed)
-    a.lds_min = (beside_swd && !e->rf_coresident_now && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
+    a.lds_min = (beside_swd && !e->rf_gated_now) ? e->rf_lds_beside_swd : 0;
     {   // (bh_tuning.h: LDS floor of the synthesis workgroups of a GATED fused call -- fewer of them per CU at a time)
         const int gated_floor = bh_tuning().rf_lds_gated;
         if (beside_swd && e->rf_gated_now && gated_floor > 0) a.lds_min = gated_floor;
     }
-    a.beside = (beside_swd && e->rf_coresident_now) ? 1 + e->rf_beside_prio : 0;
     a.coef_small = (beside_swd && e->rf_gated_now && bh_tuning().rf_coef_big == 0) ? 1 : 0;
     ev_begin(e, 1, st);
     const int lrc = bh_launch_rf(a, st);
@@ -825,14 +815,11 @@ int bh_engine_create(int device, bh_engine **out)
     const BhTuning &tun = bh_tuning(); // (the experiment switches: parsed once per process, bh_tuning.h)
     if (tun.no_overlap) e->overlap_rf = false;
     if (tun.rf_lds_beside >= 0) e->rf_lds_beside_swd = tun.rf_lds_beside;
-    if (tun.rf_beside) e->rf_beside = true;
     if (tun.swd_no_pair) e->no_pair = true;
     {
         hipDeviceProp_t prop;
         e->pairwork.ncu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
     }
-    e->swd_wpb_default = e->swd_wpb_now = tun.swd_wpb;
-    e->rf_beside_prio = tun.rf_beside_prio;
     if (tun.swd_prio_low >= 0) e->swd_prio_low = tun.swd_prio_low != 0 ? 1 : 0;
     {   // the counter the dispersion kernel's workgroups bump at start; hipStreamWaitValue32 polls it from the RF stream
         int can = 0;
@@ -854,7 +841,6 @@ int bh_engine_create(int device, bh_engine **out)
     e->force_group = tun.swd_group;
     e->force_look = tun.swd_lookahead;
     if (tun.swd_search >= 0) e->swd_search = tun.swd_search;
-    if (tun.swd_prescan >= 0) e->swd_prescan = tun.swd_prescan != 0 ? 1 : 0;
     if (tun.swd_arith >= 0) e->swd_arith = tun.swd_arith != 0 ? BH_ARITH_FAST : BH_ARITH_EXACT;
     if (tun.swd_scan >= 0) e->swd_scan = tun.swd_scan;
     e->love_inlook = tun.swd_love_inlook;
@@ -932,14 +918,6 @@ int bh_engine_set_swd_trials(bh_engine *e, int trials)
     return BH_OK;
 }
 int bh_engine_get_swd_trials(const bh_engine *e) { return e ? e->swd_trials : 0; }
-int bh_engine_set_swd_prescan(bh_engine *e, int on)
-{
-    if (!e) return BH_EINVAL;
-    e->swd_prescan = on ? 1 : 0;
-    return BH_OK;
-}
-int bh_engine_get_swd_prescan(const bh_engine *e) { return e ? e->swd_prescan : 0; }
-
 int bh_engine_guard_stats(bh_engine *e, int32_t *counts, uint64_t *rerun_launches, uint64_t *total)
 {
     if (!e) return BH_EINVAL;
@@ -1358,17 +1336,10 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     // that kernel's span by 0.3 ms in round 2.  The kernel's workgroups therefore count themselves in `started` as they
     // begin, and the RF stream waits for the count (hipStreamWaitValue32) before anything of the RF is dispatched:
     // c3 4.15 -> 4.04 ms, the dispersion kernel's time inside c3 = its time in c2 (3.62 ms).
-    // Co-resident receiver function (BH_RF_BESIDE=1, an experiment that is NOT the default).  The dispersion wavefronts
-    // leave the FP64 pipe idle 38 % of the time, but RF workgroups of the usual build (128 registers) cannot become
-    // resident beside two 208-register wavefronts per SIMD and run in the kernel's tail.  A 96-register build fits
-    // (2 x 208 + 96 = 512; LDS: dispersion workgroups of four wavefronts, two copies of the libm tables per CU instead of
-    // four), one workgroup per CU.  Measured (c3, round 3): such a workgroup -- one wavefront per SIMD, 43 spilled
-    // registers -- advances at a tenth of the RF's full-chip rate whatever its issue priority, 60 % of the RF is
-    // done when the dispersion kernel ends, that kernel is 3 % slower and the rest still runs in the tail with the
-    // slower build: 4.33 ms instead of 4.04.  Kept behind the switch with these numbers; what would make it pay is an
-    // RF recursion that needs half the registers per lane (a frequency spread over two lanes).
+    // (Round 6: the dispersion kernel of the default settings allocates 200-208 registers and the synthesis kernel 88, so an RF
+    // wavefront becomes resident beside the two dispersion wavefronts of a SIMD and takes the issue slots they leave idle; the
+    // 96-register "beside" build of rounds 3-5 -- docs/HISTORY.md -- is gone.)
     const bool want_gate = fork && e->started != nullptr;
-    const bool want_beside = want_gate && e->rf_beside;
     if (e->started != nullptr && e->started_expected > 0x70000000u) { // (the counter is cumulative: rewind it long before it wraps)
         HIPCHK(e, hipStreamSynchronize(st));
         HIPCHK(e, hipStreamSynchronize(e->aux));
@@ -1378,28 +1349,13 @@ int bh_evaluate_batch(bh_engine *e, int memspace, void *stream, int B, int Lmax,
     // (RF wavefronts move in beside the last dispersion wavefronts of a SIMD as its short ones end: the dispersion
     // wavefronts' unfavoured phase runs at priority 1 then, above the RF's 0)
     e->swd_prio_low_now = want_gate ? e->swd_prio_low : 0;
-    e->swd_wpb_now = want_beside ? 4 : e->swd_wpb_default; // (4: two copies of the libm tables per CU instead of four: LDS room for an RF workgroup)
     e->last_swd = SwdLaunchInfo{};
     rc = launch_swd_jobs(e, st, B, Lmax, m, sl, sb, njobs, jobs);
     e->swd_prio_low_now = 0;
-    e->swd_wpb_now = e->swd_wpb_default;
     if (rc) return rc;
-    e->rf_coresident_now = false;
     e->rf_gated_now = false;
     if (want_gate && e->last_swd.workgroups > 0) {
         e->rf_gated_now = bh_tuning().rf_keep_floor == 0;
-        size_t rf_lds = 0;
-        for (int t = 0; t < nt; ++t)
-            if (e->targets[(size_t)t].d.kind == BH_TARGET_RF) {
-                const size_t l = bh_rf_lds_bytes(e->targets[(size_t)t].d.nsamp);
-                rf_lds = l > rf_lds ? l : rf_lds;
-            }
-        // more than one dispersion wavefront per SIMD (else the usual build finds room by itself), and the LDS fits
-        e->rf_coresident_now = want_beside && e->last_swd.waves > 1024 && 2 * e->last_swd.lds + rf_lds <= BH_RF_MAX_LDS;
-        const bool dbg = bh_tuning().debug_plan != 0;
-        if (dbg)
-            std::fprintf(stderr, "[bh] fused call B=%d: dispersion launch %u workgroups, %ld wavefronts, %zu B LDS per workgroup; RF LDS %zu B; "
-                         "co-resident RF: %d\n", B, e->last_swd.workgroups, e->last_swd.waves, e->last_swd.lds, rf_lds, (int)e->rf_coresident_now);
         // all workgroups of the launch, or -- a launch of more workgroups than the chip holds at once (2048 wavefronts) --
         // as many as can be resident together (the rest start as others end: waiting for them would be waiting for the kernel)
         const unsigned resident = 2048u / (unsigned)(e->last_swd.lds > 0 && e->last_swd.workgroups > 0 ? (e->last_swd_wpb > 0 ? e->last_swd_wpb : 2) : 2);
@@ -1515,37 +1471,6 @@ int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out)
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(out, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    return BH_OK;
-}
-
-int bh_probe_csign(bh_engine *e, int iwave, int nlay, const float *h, const float *vp, const float *vs, const float *rho,
-                   int n, const double *omega, const double *c, double *val, double *bound, int32_t *certified)
-{
-    if (!e || n < 0 || nlay < 2 || nlay > 100 || !h || !vp || !vs || !rho || !omega || !c || !val || !bound || !certified ||
-        (iwave != BH_WAVE_LOVE && iwave != BH_WAVE_RAYLEIGH))
-        return BH_EINVAL;
-    if (n == 0) return BH_OK;
-    int rc;
-    HIPCHK(e, hipSetDevice(e->device));
-    // in: [4 * nlay floats, padded to doubles][omega n][c n]; out: [val n][bound n][certified n (as doubles)]
-    const size_t mwords = ((size_t)4 * nlay + 1) / 2;
-    if ((rc = ensure(e, e->probe_in, (mwords + (size_t)2 * n) * sizeof(double)))) return rc;
-    if ((rc = ensure(e, e->probe_out, (size_t)3 * n * sizeof(double)))) return rc;
-    char *in = (char *)e->probe_in.p;
-    const float *src[4] = {h, vp, vs, rho};
-    for (int k = 0; k < 4; ++k)
-        HIPCHK(e, hipMemcpyAsync(in + (size_t)k * nlay * sizeof(float), src[k], (size_t)nlay * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    double *din = (double *)e->probe_in.p + mwords;
-    HIPCHK(e, hipMemcpyAsync(din, omega, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(din + n, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    bh_launch_csign_probe(iwave, nlay, (const float *)e->probe_in.p, n, din, din + n, (double *)e->probe_out.p, e->stream);
-    HIPCHK(e, hipGetLastError());
-    std::vector<double> tmp((size_t)n);
-    HIPCHK(e, hipMemcpyAsync(val, e->probe_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(bound, (double *)e->probe_out.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(tmp.data(), (double *)e->probe_out.p + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    for (int i = 0; i < n; ++i) certified[i] = tmp[(size_t)i] != 0.0 ? 1 : 0;
     return BH_OK;
 }
 

@@ -6,22 +6,20 @@
 // inside a process use bh_engine_set_tuning(name, value) (the name is the field's name below).  A build with
 // -DBH_NO_EXPERIMENTS ignores the environment and refuses bh_engine_set_tuning: every switch has its default.
 //
-// The ENGINE SETTINGS with an API of their own (bh_engine_set_swd_search / _scan / _prescan / _arith / _group / _lookahead) take their
-// initial value from the first six entries; an API call afterwards wins.
+// The ENGINE SETTINGS with an API of their own (bh_engine_set_swd_search / _scan / _arith / _group / _lookahead) take their
+// initial value from the first five entries; an API call afterwards wins.
 #pragma once
 
 //        field              environment variable        default  meaning (value: flag = set to anything / integer)
 #define BH_TUNING_TABLE(X)                                                                                                          \
     X(swd_search,        "BH_SWD_SEARCH",        -1, "initial root refinement: r(eference) / f(ast) / fast_rayleigh; -1 = the library's default")    \
     X(swd_scan,          "BH_SWD_SCAN",          -1, "initial scan mode: s(teps) / c(ounted) / a(uto); -1 = auto")                                  \
-    X(swd_prescan,       "BH_SWD_PRESCAN",       -1, "initial certified-sign scan: 0 / 1; -1 = off")                                                \
     X(swd_arith,         "BH_SWD_ARITH",         -1, "initial arithmetic of short-refinement launches: e(xact) / f(ast); -1 = the library's default") \
     X(swd_group,         "BH_SWD_GROUP",          0, "lanes per model of the dispersion kernel (0 = planned per launch)")                           \
     X(swd_lookahead,     "BH_SWD_LOOKAHEAD",      0, "trial velocities per round (0 = planned per launch)")                                         \
     X(swd_look_r,        "BH_SWD_LOOK_R",         0, "trials per round of Rayleigh wavefronts only (0 = planned)")                                  \
     X(swd_look_l,        "BH_SWD_LOOK_L",         0, "trials per round of Love wavefronts only (0 = planned)")                                      \
     X(swd_love_inlook,   "BH_SWD_LOVE_INLOOK",    0, "Love trials inside a lane group, 1..4 (0 = automatic)")                                       \
-    X(swd_wpb,           "BH_SWD_WPB",            2, "wavefronts per workgroup of the group kernel: 2 or 4")                                        \
     X(swd_prio_low,      "BH_SWD_PRIO_LOW",      -1, "issue priority of a dispersion wavefront's unfavoured phase beside RF wavefronts (-1 = 1)")    \
     X(swd_pair_minwaves, "BH_SWD_PAIR_MINWAVES", -1, "wavefronts from which the SIMD-pairing order of the models is used (-1 = 7 x CUs)")           \
     X(swd_slice,         "BH_SWD_SLICE",          0, "lane-per-model kernel: rounds between priority changes (0 = default)")                        \
@@ -48,8 +46,6 @@
     X(no_mfma,           "BH_NO_MFMA",            0, "flag: Gauss-law quadratic form in like_kernel instead of the MFMA contraction")                \
     X(err_memset,        "BH_ERR_MEMSET",         0, "flag: zero the per-target failure flags on every call")                                        \
     X(gauss_tile,        "BH_GAUSS_TILE",         0, "tile of the Gauss-law contraction: 64 / 128 (0 = automatic)")                                  \
-    X(rf_beside,         "BH_RF_BESIDE",          0, "flag: the 96-register receiver-function build co-resident with dispersion wavefronts")          \
-    X(rf_beside_prio,    "BH_RF_BESIDE_PRIO",     0, "issue priority 0..3 of that build")                                                            \
     X(rf_lds_beside,     "BH_RF_LDS_BESIDE",     -1, "LDS floor (bytes) of receiver-function workgroups beside an ungated dispersion launch (-1 = default)") \
     X(rf_lds_gated,      "BH_RF_LDS_GATED",       0, "LDS floor (bytes) of receiver-function workgroups of a gated fused call (0 = none)")           \
     X(rf_keep_floor,     "BH_RF_KEEP_FLOOR",      0, "flag: keep the ungated LDS floor in a gated fused call")                                       \

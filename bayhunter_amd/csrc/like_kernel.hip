@@ -253,8 +253,11 @@ void bh_launch_like(const LikeKernelArgs &a, hipStream_t stream)
     for (int t = 0; t < a.nt; ++t)
         if (a.t[t].law == 3 && a.t[t].quad == nullptr && (size_t)a.t[t].n * sizeof(double) > lds)
             lds = (size_t)a.t[t].n * sizeof(double);
-    bool small = true; // every target fits one wavefront (and a Gauss law has its slab sums from the MFMA contraction)
-    for (int t = 0; t < a.nt; ++t) small = small && a.t[t].n <= 64 && !(a.t[t].law == 3 && a.t[t].quad == nullptr);
+    // every target fits one wavefront -- or comes with its sums already formed by the forward kernel (a receiver function's fused
+    // likelihood: nothing of its trace is read here) -- and a Gauss law has its slab sums from the MFMA contraction
+    bool small = true;
+    for (int t = 0; t < a.nt; ++t)
+        small = small && (a.t[t].n <= 64 || (a.t[t].pre != nullptr && a.t[t].law != 3)) && !(a.t[t].law == 3 && a.t[t].quad == nullptr);
     if (small) hipLaunchKernelGGL(like_small_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(like_kernel, dim3(a.B), dim3(256), lds, stream, a);
 }

@@ -663,15 +663,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // GLOBALZ: the half-length spectrum lives in the model's slice of A.zwork (HBM / L2) instead of LDS -- traces longer than a
 // workgroup's LDS holds (nsamp > 16384).  Same bins, same butterflies, same order; a workgroup's barrier orders its own
 // global accesses (all its wavefronts share the CU's cache).
-template <bool BESIDE, bool GLOBALZ = false>
+template <bool GLOBALZ = false>
 __device__ __forceinline__ void rf_synth_body(const RfKernelArgs &A, int logm, int jcut)
 {
-    if (BESIDE) { // issue priority of a wavefront that runs beside dispersion wavefronts (those alternate between 3 and 1)
-        if (A.beside == 1) __builtin_amdgcn_s_setprio(0);
-        else if (A.beside == 2) __builtin_amdgcn_s_setprio(1);
-        else if (A.beside == 3) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(3);
-    }
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = A.nsamp, M = N / 2;
     double2 *z = GLOBALZ ? reinterpret_cast<double2 *>(A.zwork) + (size_t)blockIdx.x * (size_t)M : reinterpret_cast<double2 *>(smem); // [M]
@@ -817,14 +811,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
     rf_synth_body<false>(A, logm, jcut);
 }
-// 96 registers: what two dispersion wavefronts of 208 leave of a SIMD's 512.  In the fused call (bh_evaluate_batch) one
-// such workgroup per CU runs BESIDE the dispersion kernel's eight wavefronts, at the lowest issue priority: it takes the
-// issue slots those leave idle (their FP64 pipe is busy 62 % of the time) instead of waiting for them to end.
+// Traces longer than a workgroup's LDS holds: the spectrum in the HBM workspace (GLOBALZ)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void rf_synth_kernel_long(RfKernelArgs A, int logm, int jcut)
-{
-    rf_synth_body<false, true>(A, logm, jcut);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void rf_synth_kernel_beside(RfKernelArgs A, int logm, int jcut)
 {
     rf_synth_body<true>(A, logm, jcut);
 }
@@ -854,14 +842,12 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
         if (a.zwork == nullptr || a.nsamp > BH_RF_MAX_NSAMP) return -1;
         lds -= (size_t)(a.nsamp / 2) * 16; // (the spectrum is in the workspace)
         a.lds_min = 0;
-        a.beside = 0;
     }
     if (lds < (size_t)a.lds_min) lds = (size_t)a.lds_min;
     if (lds > 64 * 1024) { // beyond the default dynamic-LDS limit: a workgroup may take the CU's whole 160 KB
         static std::atomic<unsigned long long> allowed{0};
-        const void *k[3] = {reinterpret_cast<const void *>(rf_synth_kernel), reinterpret_cast<const void *>(rf_synth_kernel_w3),
-                            reinterpret_cast<const void *>(rf_synth_kernel_beside)};
-        if (!bh_allow_big_lds(&allowed, k, 3, (int)BH_RF_MAX_LDS)) return -1;
+        const void *k[2] = {reinterpret_cast<const void *>(rf_synth_kernel), reinterpret_cast<const void *>(rf_synth_kernel_w3)};
+        if (!bh_allow_big_lds(&allowed, k, 2, (int)BH_RF_MAX_LDS)) return -1;
     }
     if (a.Lmax <= 16 && a.coef_small)
         hipLaunchKernelGGL((rf_coef_layers_kernel_small<16>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
@@ -885,8 +871,6 @@ int bh_launch_rf(const RfKernelArgs &a_in, hipStream_t stream)
     const int jcut = (no_cut || !(jc < (double)half)) ? half + 1 : (int)jc;
     if (longtrace)
         hipLaunchKernelGGL(rf_synth_kernel_long, dim3(a.B), dim3(256), lds, stream, a, logm, jcut);
-    else if (a.beside)
-        hipLaunchKernelGGL(rf_synth_kernel_beside, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else if (tun.rf_waves == 3)
         hipLaunchKernelGGL(rf_synth_kernel_w3, dim3(a.B), dim3(nthr), lds, stream, a, logm, jcut);
     else

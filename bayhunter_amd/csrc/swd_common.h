@@ -31,7 +31,6 @@ __device__ __forceinline__ double bh_exp(double x, const LibmTabs &T)
 }
 
 
-#include "swd_csign.h"
 
 constexpr int NEV_MAX = 11; // Neville table entries: order grows to m <= 10 (surfdisp96.f:655)
 
@@ -57,14 +56,6 @@ using ModelLds = ModelLdsT<BH_WAVE>;
 struct ModelLdsRt { // same, with the column count known only at run time
     const float *d, *a, *b, *rho;
     int S;
-    // the certified-sign evaluation's per-layer reciprocals (csign::rcp_fast of the binary32 values), [4][rows][S]: 1/a, 1/b,
-    // 1/rho, 1/d; LS = rows * S
-    const double *inv = nullptr;
-    int LS = 0;
-    __device__ __forceinline__ double IA(int m) const { return inv[m * S]; }
-    __device__ __forceinline__ double IB(int m) const { return inv[LS + m * S]; }
-    __device__ __forceinline__ double IR(int m) const { return inv[2 * LS + m * S]; }
-    __device__ __forceinline__ double ID(int m) const { return inv[3 * LS + m * S]; }
     __device__ __forceinline__ float Df(int m) const { return d[m * S]; }
     __device__ __forceinline__ float Af(int m) const { return a[m * S]; }
     __device__ __forceinline__ float Bf(int m) const { return b[m * S]; }
@@ -509,11 +500,7 @@ enum : int {
     ST_GH = 11,   // just above the accepted bracket's upper end
     ST_GL = 12,   // just below its lower end
     ST_GS1 = 13,  // just inside the lower end of a scan step that contains a half-space velocity and showed no sign change
-    ST_GS2 = 14,  // just inside its upper end
-    // the certified-sign scan (SearchT<.., PRE>; see there): same brackets, same bits
-    ST_PRE = 15,  // a period's search is set up, nothing requested yet: the kernel looks ahead over the scan's grid first
-    ST_PJ1 = 16,  // landing: the grid point the scan leaves behind (two steps before the first unproven one)
-    ST_PJ2 = 17   // landing: the grid point before the first unproven one -- the scan steps on from here
+    ST_GS2 = 14   // just inside its upper end
 };
 
 // ---- the per-model search state machine -------------------------------------------------------
@@ -564,19 +551,7 @@ enum : int {
 //     end or of betmx, or a sign change within eps OUTSIDE a bracket end (the image right behind it).
 // A model the guard fires on (`guard`) is run again with the REFERENCE's sequence by the engine (a second, small launch):
 // failure flags and zero-from-period-k rows are then the reference's by construction.
-//
-// THE CERTIFIED-SIGN SCAN (PRE = true builds: the group kernel; bh_engine_set_swd_prescan, on by default).  The scan consumes
-// only the SIGN of the secular function at its grid points g_i = g_(i-1) + dc.  A search that starts a period (ST_PRE) first
-// has the kernel evaluate the grid ahead with the cheap certified-sign evaluation (swd_csign.h), one lane per grid point: j =
-// the first index whose sign is not PROVEN equal to the start value's, or at which the scan would do anything but step on
-// (its bounds cm, betmx + dc, clow; with the guard on, a step that reaches a half-space velocity).  j >= 3 and an upward scan:
-// the reference's scan is known to walk from g_0 to g_(j-1) without a sign change, so the search LANDS there -- reference-
-// exact values at g_(j-2) (the point left behind: third point of the short refinement's seeded estimate; only where that is
-// used) and at g_(j-1) -- and steps on as before.  Anything else (start value not proven, downward scan, j < 3, the counted
-// scan in charge): the reference's steps from the start value.  Same brackets, same values in them, hence the same bits,
-// with 2-3 reference-exact evaluations per scan instead of ~15.  oracle/swd_oracle.c (bracket_and_refine, g_prescan)
-// restates it.
-template <int XSC, int NLO = NEV_MAX, int FASTM = 0, bool SIMPLE = false, bool PRE = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
+template <int XSC, int NLO = NEV_MAX, int FASTM = 0, bool SIMPLE = false> // XSC > 0: compile-time lane stride of the Neville tables in LDS; 0: run-time (member XS)
 struct SearchT {
     static constexpr bool FAST = FASTM != 0, PHASE_ONLY = FASTM == 2, NOGROUP = PHASE_ONLY || SIMPLE;
     // counted scan
@@ -586,11 +561,8 @@ struct SearchT {
     enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u,
                       F_SEED3 = 64u,   // Rayleigh, short refinement: the scan's last replaced point seeds the first estimate
                       F_SEEDED = 128u, // this bracket's refinement started with a third point
-                      F_PRE_ON = 256u, // the certified-sign scan is wanted (PRE builds)
                       F_FA = 512u      // the values come from the fast arithmetic (swd_fa.h): values that are not numbers (below fa::SIGN_FLOOR) fire the guard
     };
-    // the certified-sign scan: grid points one look covers at most (the kernel: looks x the lanes of a model)
-    static constexpr int pre_max_points = 128;
     // (F_GUARD_ON doubles as "this search takes the short refinement": in a build with both sequences (FASTM = 1) a phase-velocity
     //  target can be told to keep the reference's -- init(.., refseq) --, e.g. the Love targets under BH_SEARCH_FAST_RAYLEIGH)
     unsigned flg = 0u;
@@ -682,7 +654,7 @@ struct SearchT {
     __device__ void init(const MD &md, int mmax, bool valid, int igr, int K_, const double *per_,
                          double *xl_, double *yl_, double *vel_, bool writer_, int mode_ = 1,
                          double *cper_ = nullptr, double *cbper_ = nullptr, int ifunc = 2, bool counted = false, bool refseq = false,
-                         bool prescan = false, bool farith = false)
+                         bool farith = false)
     {
         float betmx = -1.e20f, betmn = 1.e20f;
         int jmn = 0, jsol = 1;
@@ -744,7 +716,6 @@ struct SearchT {
         t1 = 1.0; omega = 1.0;
         evals = 0;
         put(F_CNT_ON, counted && ifunc == 1);
-        put(F_PRE_ON, PRE && prescan && !(counted && ifunc == 1));
         put(F_FA, FAST && farith);
         flg &= ~(F_CNT_OK | F_JUMP_READY);
         iprev = iprevb = 0;
@@ -758,32 +729,7 @@ struct SearchT {
         vsafe = has(F_GUARD_ON) ? fmin(vh0, vh1) : 1.0e300;
         if (active) set_period(0);
         ceval = c1;
-        if (PRE && has(F_PRE_ON)) st = ST_PRE;
         if (counted) plan_first_jump();
-    }
-
-    // ---- the certified-sign scan (see the struct's comment) ----
-    // what the kernel's look-ahead asks of a grid point g that the scan would step to (not the start value): may the scan
-    // simply step on there, given that the sign does not change?
-    __device__ __forceinline__ bool pre_plain(double g) const { return !(g < cm || g >= betmxd + dc) && g > clow && g < vsafe; }
-    // an upward scan, given the proven sign of the start value?
-    __device__ __forceinline__ bool pre_upward(bool neg0) const { return ifirst == 1 || neg0 == signs_differ(del1st, 0.0); }
-    // the look-ahead found nothing to skip: the reference's steps from the start value
-    __device__ __forceinline__ void pre_decline() { st = ST_FIRST; }
-    // land: gm2 = g_(j-2), gm1 = g_(j-1), neg0 = the proven sign of g_0 .. g_(j-1)
-    __device__ __forceinline__ void pre_land(double gm2, double gm1, bool neg0)
-    {
-        if (ifirst == 1) del1st = neg0 ? -1.0 : 1.0; // (only its sign is ever used)
-        idir = +1;
-        have_p = false;
-        cnext = gm1;
-        if (FAST && has(F_SEED3)) {
-            ceval = gm2;
-            st = ST_PJ1;
-        } else {
-            ceval = gm1;
-            st = ST_PJ2;
-        }
     }
 
     // The grid point `want` steps above `from` by the reference's repeated additions, stopping below vlim.
@@ -864,7 +810,7 @@ struct SearchT {
             c1 = cper[(k - 1) * XS] - onea * dc;
             clow = cm;
         }
-        st = (PRE && has(F_PRE_ON)) ? ST_PRE : ST_FIRST;
+        st = ST_FIRST;
         ceval = c1;
         if (CNT) plan_first_jump();
     }
@@ -878,17 +824,6 @@ struct SearchT {
     __device__ __forceinline__ double candidate(int r) const
     {
         double q = ceval;
-        if (PRE && st >= ST_PRE) { // landing of the certified-sign scan: g_(j-2), g_(j-1), then the scan's next steps
-            if (r >= 1) {
-                int n = r;
-                if (st == ST_PJ1) {
-                    q = cnext;
-                    n = r - 1;
-                }
-                for (int i = 0; i < n; ++i) q = q + dc;
-            }
-            return q;
-        }
         if ((CNT || FAST) && st >= ST_JUMP) { // the counted scan (guard probes: nothing to foresee)
             // The requests after the pending one are grid points around it: after the jump (k = jn steps above c1) the index
             // search starts, most probably, a step or a few below the target (the stride aims one step beyond the last period's
@@ -1008,19 +943,6 @@ struct SearchT {
         // fast arithmetic: a scan or guard value whose sign the rounding error could decide (or a poisoned one) is not trusted --
         // the guard fires (inside the refinement small values are what is expected: they move the root by < 1e-9 relative)
         if (FAST && has(F_FA) && !(fabs(del) >= fa::SIGN_FLOOR) && !(st >= ST_FX && st <= ST_FP2 && del == del)) flg |= F_GUARD;
-        if (PRE && st >= ST_PRE) { // landing of the certified-sign scan (ST_PRE itself never has an evaluation pending)
-            if (st == ST_PJ1) {
-                cp = ceval;
-                delp = del;
-                have_p = true;
-                ceval = cnext;
-                st = ST_PJ2;
-            } else {
-                c1 = ceval;
-                del1 = del;
-                todo = 1;
-            }
-        } else
         if ((CNT || FAST) && st >= ST_JUMP) {
             if (CNT && st == ST_JUMP) { // the grid point jn steps above c1
                 if (nv < 0 || nv < n1) { // no usable count (the value is not used): the reference's steps from c1 on
@@ -1336,7 +1258,7 @@ struct SearchT {
                         ifirst = 0;
                         clow = ((mode > 1) ? cbper[k * XS] : 0.0) + one * dc; // cb(k) of the previous mode
                         c1 = c1 - onea * dc;
-                        st = (PRE && has(F_PRE_ON)) ? ST_PRE : ST_FIRST;
+                        st = ST_FIRST;
                         ceval = c1;
                         if (CNT) plan_first_jump();
                     } else {

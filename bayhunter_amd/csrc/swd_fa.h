@@ -5,7 +5,7 @@
 // normc) -- the same formulas, the same per-layer max-norm scaling -- evaluated with what the chip does quickly instead of
 // with the reference's rounding points: fused multiply-adds, reciprocals and square roots from the hardware seed
 // (v_rcp_f64 / v_rsq_f64) refined by Newton / Goldschmidt steps, sin / cos / exp from two-part Cody-Waite reductions and
-// polynomials (swd_csign.h), e^-(p+q) as a product of the two wave types' exponentials.  Every result is within a few
+// polynomials, e^-(p+q) as a product of the two wave types' exponentials.  Every result is within a few
 // units in the last place of the exactly rounded formula, i.e. it differs from the reference-exact evaluation by what that
 // evaluation's own rounding error is; about a third of its instructions.
 //
@@ -52,7 +52,7 @@ __device__ __forceinline__ double rcp1(double x) // one step (~2^-45): scale fac
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 }
 
-// sin and cos of 0 <= x < 1e5 and exp(-x), 0 <= x <= 700: the reductions and coefficients of swd_csign.h (fdlibm's kernels on
+// sin and cos of 0 <= x < 1e5 and exp(-x), 0 <= x <= 700: fdlibm's kernels on
 // [-pi/4, pi/4]; Taylor to r^12 on |r| <= ln 2 / 2), the polynomials summed by Estrin's scheme -- half the depth of the chain of
 // dependent operations, which is what two wavefronts per SIMD cannot hide.
 __device__ __forceinline__ void sincos(double x, double &sn, double &cs)

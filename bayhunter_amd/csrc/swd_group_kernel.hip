@@ -40,29 +40,6 @@ namespace {
 // only pins the compiler's ordering.  Look-ahead, Love's in-group trials, the processing order and the
 // two depth classes of ragged batches are described at their code.
 // =================================================================================================
-// The certified-sign evaluation of ONE grid point by one lane (swd_csign.h), OUT OF LINE: it needs ~160 registers of its own,
-// the round loop around it keeps ~200 live; as a call the loop's values stay in their registers (or are saved around the call
-// by the calling convention) and the loop itself is compiled as before.  The model is read from the wavefront's LDS region:
-// mdl / inv = byte offsets of its [4][Lmax][MPW] float block and of the [4][Lmax][MPW] block of per-layer reciprocals inside the
-// workgroup's dynamic LDS, col = the model's column.
-// Returns bit 0 = certified, bit 1 = the value is negative.
-__device__ __attribute__((noinline)) int csign_point(int ifunc, int mdl, int inv, int rows_x_mpw, int mpw, int col, int mmax, int llw, double omega, double c)
-{
-    extern __shared__ __align__(16) unsigned char smem_all[];
-    const float *m0 = reinterpret_cast<const float *>(smem_all + mdl);
-    ModelLdsRt md;
-    md.S = mpw;
-    md.inv = reinterpret_cast<const double *>(smem_all + inv) + col;
-    md.LS = rows_x_mpw;
-    md.d = m0 + col;
-    md.a = m0 + rows_x_mpw + col;
-    md.b = m0 + 2 * rows_x_mpw + col;
-    md.rho = m0 + 3 * rows_x_mpw + col;
-    double v, bd;
-    const bool cert = (ifunc == 2) ? csign::rayleigh(md, mmax, llw, omega, c, v, bd) : csign::love(md, mmax, llw, omega, c, v, bd);
-    return (cert ? 1 : 0) | ((v < 0.0) ? 2 : 0);
-}
-
 constexpr int CA_STRIDE = 26;
 constexpr int LOVE_TERMS = 6; // doubles per parked Love layer and trial (5 used): up to 4 trials share a row
 
@@ -226,16 +203,13 @@ constexpr int ADAPT_MAX_TRIALS = 8;
 // size, scalar registers), so it is compiled into the launches where it pays -- one model per wavefront (ADAPT: a single
 // model, the chains' windows), launches of Love targets only -- and not where Rayleigh wavefronts set the time anyway
 // (c2: Rayleigh + Love at B = 4096: 3.37 ms without, 3.47 with; the Rayleigh wavefront alone on its SIMD takes 3.06).
-// PREK: the build with the certified-sign scan (SearchT<.., PRE>, the look-ahead at the top of the round loop).  Its out-of-line
-// evaluation takes the kernel to 256 registers, so it is a build of its own, launched only when the scan is asked for
-// (bh_engine_set_swd_prescan; the general builds of launches with several models per wavefront).
 // FA: the build with the fast arithmetic (swd_fa.h; bh_engine_set_swd_arith): launches in which every target takes the short
 // refinement (FASTM = 2) -- tolerance-level parity, a guard for signs the rounding error could decide.
 // (the FA builds are compiled in a translation unit of their own, swd_group_fa.hip, which includes this file: own flags)
 #ifndef BH_GROUP_WAVES
 #define BH_GROUP_WAVES 2
 #endif
-template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB, bool PREK = false, bool FA = false>
+template <int WPB, int FASTM, bool SIMPLE, bool PROF, bool ADAPT, bool CNTB, bool FA = false>
 __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(BH_GROUP_WAVES, BH_GROUP_WAVES))) void swd_group_kernel(SwdMultiArgs A, int Gflags, int wave_lds)
 {
     // "this workgroup is resident": what a second stream waits for before it dispatches wavefronts beside these
@@ -333,9 +307,6 @@ next_pass:
     float *mdl = reinterpret_cast<float *>(per + ((K + 1) & ~1));  // [4][Lmax][MPW]
     unsigned char *after = reinterpret_cast<unsigned char *>(mdl) + (((size_t)4 * Lmax * MPW * sizeof(float) + 15) & ~(size_t)15);
     double *cpl = reinterpret_cast<double *>(after); // [2][Kmax][MPW], only if a target has mode > 1
-    // The certified-sign scan's per-layer reciprocals 1/a, 1/b, 1/rho, 1/d, [4][Lmax][MPW]: they live in the parked-layer rows,
-    // which are free between two rounds (4 Lmax <= 26 J (Lmax - 1) for every Lmax >= 2), and are formed anew at every look-ahead.
-    double *inv = ca;
 
     for (int k = lane; k < K; k += BH_WAVE) per[k] = T.periods[k];
     // stage the models of this wave: consecutive lanes -> consecutive models (coalesced for
@@ -378,7 +349,7 @@ next_pass:
 
     constexpr bool FAST = FASTM != 0;
     constexpr bool BULK = FAST; // runs of plain bracket steps consumed in one go (the short-refinement build only)
-    SearchT<0, NEV_MAX, FASTM, SIMPLE, PREK> S;
+    SearchT<0, NEV_MAX, FASTM, SIMPLE> S;
     S.XS = MPW;
     // RESTART (one model per wavefront, the build with both sequences, SwdMultiArgs::restart): when the guard of the short
     // refinement fires, the model starts again right here with the reference's sequence -- what the engine's re-run launch
@@ -388,7 +359,7 @@ next_pass:
     unsigned evals_before = 0u; // (evaluations of the abandoned first search: they count, as the re-run launch's would)
 restart_with_the_reference_sequence:
     S.init(md, mmax, valid, T.igr, K, per, xs + g, ys + g, T.vel + (size_t)ib * T.ldv, li == 0 && rr == 0 && !spare,
-           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, PREK && A.prescan != 0, FA);
+           T.mode, cpl + g, cpl + (size_t)K * MPW + g, ifunc, CNTB && A.counted != 0, refseq_now, FA);
     S.evals += evals_before;
 
     // per-period constants of this lane's first layer (m = li) and of the half-space: they depend
@@ -442,91 +413,6 @@ restart_with_the_reference_sequence:
             else __builtin_amdgcn_s_setprio(1);
         }
         ++nrounds;
-        // ---- the certified-sign scan (SearchT, swd_csign.h): models that start a period's search look ahead over the scan's
-        // grid, one lane per grid point (the lanes of the model: LPM points a look), until a grid point is not proven to
-        // have the start value's sign; then they land two steps before it, or decline (the reference's steps).
-        if (PREK && __ballot(S.active && S.st == ST_PRE) != 0ull) {
-            const long long tp0 = prof ? clock64() : 0;
-            // Two roles per lane.  OWNER: the lane carries the search state of model g (all LPM lanes of the model alike) and
-            // keeps the look-ahead's bookkeeping for it.  EVALUATOR: the lane evaluates one grid point of model gp -- the
-            // wavefront's 64 lanes are dealt out PL = 64 / MPW per model, whatever the lane groups of the rounds are.
-            const int PL = BH_WAVE / MPW;
-            const bool ev_on = lane / PL < MPW;
-            const int gp = ev_on ? lane / PL : 0, pidx = ev_on ? lane - gp * PL : 0;
-            const int src = gp * LPM;                                                    // a lane that owns model gp
-            const unsigned long long mine = ((PL >= 64) ? ~0ull : ((1ull << PL) - 1ull)) << (g * PL); // the evaluators of MY model
-            bool pending = S.active && S.st == ST_PRE, landing = false, neg0 = false;
-            int base = 0, jj = 0;
-            unsigned npts = 0;
-            // what the evaluation needs of model gp's search (SearchT::pre_plain, pre_upward)
-            const double q_om = __shfl(S.omega, src), q_cm = __shfl(S.cm, src), q_hi = __shfl(S.betmxd, src) + S.dc,
-                         q_clow = __shfl(S.clow, src), q_vsafe = __shfl(S.vsafe, src);
-            const int q_mmax = __shfl(mmax, src), q_llw = __shfl(llw, src);
-            const bool p_first = S.ifirst == 1, p_neg1st = signs_differ(S.del1st, 0.0);
-            double gi = __shfl(S.c1, src);
-            for (int i = 0; i < pidx; ++i) gi = gi + S.dc;
-            const int o_mdl = (int)(reinterpret_cast<unsigned char *>(mdl) - smem_all), o_inv = (int)(reinterpret_cast<unsigned char *>(inv) - smem_all);
-            for (int idx = lane; idx < Lmax * MPW; idx += BH_WAVE) { // the per-layer reciprocals (see `inv`)
-                inv[0 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[1 * Lmax * MPW + idx]);
-                inv[1 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[2 * Lmax * MPW + idx]);
-                inv[2 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[3 * Lmax * MPW + idx]);
-                inv[3 * Lmax * MPW + idx] = csign::rcp_fast((double)mdl[0 * Lmax * MPW + idx]);
-            }
-            wave_sync();
-            while (__ballot(pending) != 0ull) {
-                const int cs_ = csign_point(ifunc, o_mdl, o_inv, Lmax * MPW, MPW, gp, q_mmax, q_llw, q_om, gi);
-                const bool cert = (cs_ & 1) != 0, neg = (cs_ & 2) != 0;
-                // owner: the start value's proven sign decides the direction (first look)
-                const bool c0 = __shfl((int)cert, g * PL) != 0, n0 = __shfl((int)neg, g * PL) != 0;
-                if (pending && base == 0) {
-                    neg0 = n0;
-                    if (!(c0 && (p_first || n0 == p_neg1st))) pending = false; // (declined)
-                }
-                // evaluator: is my point proven to have the start value's sign, and may the scan simply step on there?
-                const int idx = __shfl(base, src) + pidx;
-                const bool nz = __shfl((int)neg0, src) != 0;
-                const bool ok = cert && neg == nz && (idx == 0 || (!(gi < q_cm || gi >= q_hi) && gi > q_clow && gi < q_vsafe)) && idx < S.pre_max_points;
-                const unsigned long long bad = ~__ballot(ok) & mine;
-                bool more = false;
-                if (pending) {
-                    ++npts;
-                    if (bad != 0ull) {
-                        jj = base + (int)__builtin_ctzll(bad) - g * PL;
-                        pending = false;
-                        landing = true;
-                    } else {
-                        base += PL;
-                        more = true;
-                    }
-                }
-                if (__shfl((int)more, src) != 0)
-                    for (int i = 0; i < PL; ++i) gi = gi + S.dc;
-            }
-            wave_sync(); // (the rounds' phase A writes the rows the reciprocals were read from)
-            if (S.active && S.st == ST_PRE) {
-                if (landing && jj >= 3) {
-                    double gm2 = S.c1;
-                    for (int i = 0; i < jj - 2; ++i) gm2 = gm2 + S.dc;
-                    S.pre_land(gm2, gm2 + S.dc, neg0);
-                } else {
-                    S.pre_decline();
-                }
-            }
-            if (prof) {
-                const bool rep = valid && li == 0 && rr == 0 && !spare;
-                unsigned long long np = rep ? npts * (unsigned)PL : 0u, nl = (rep && landing && jj >= 3) ? 1u : 0u;
-                for (int off = 32; off > 0; off >>= 1) {
-                    np += __shfl_xor(np, off);
-                    nl += __shfl_xor(nl, off);
-                }
-                if (lane == 0) {
-                    atomicAdd(A.neval + 12, np);                                       // certified-sign evaluations
-                    atomicAdd(A.neval + 13, nl);                                       // landings
-                    atomicAdd(A.neval + 14, 1ull);                                     // wavefront-rounds with a look-ahead
-                    atomicAdd(A.neval + 15, (unsigned long long)(clock64() - tp0));    // their wave-cycles
-                }
-            }
-        }
         // All lanes take part in the evaluation (finished models compute on stale values).
         if (clocks) t0 = clock64();
         const double omg = S.omega;
@@ -940,7 +826,7 @@ restart_with_the_reference_sequence:
     }
 }
 
-#if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_PREK_TU)
+#if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_BIG_TU)
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / (G * J);
@@ -953,22 +839,20 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 
 } // namespace
 
-#ifdef BH_GROUP_PREK_TU
-// The launches of the builds with the certified-sign scan (this translation unit: swd_group_prek.hip, ONE wavefront per SIMD:
-// the out-of-line evaluation needs more registers than two wavefronts per SIMD leave -- at two, these builds spilled).
-void bh_launch_swd_group_prek(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds, int build)
+#ifdef BH_GROUP_BIG_TU
+// The build that needs more than 256 registers (this translation unit: swd_group_big.hip, ONE wavefront per SIMD as its register
+// budget): one model per wavefront, both sequences, the counted Love scan AND the counters and clocks -- an instrumented launch of a
+// sampler's window under BH_SEARCH_FAST_RAYLEIGH; counters and clocks are what it is for, not speed.
+void bh_launch_swd_group_big(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds)
 {
-    if (build == -1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, true, true, true, true>), grid, block, lds, stream, a, redundant, wave_lds); // (see bh_launch_swd_group)
-    else if (build == 2) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
-    else if (build == 1) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
-    else hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 0, false, true, false, false, true>), grid, block, lds, stream, a, redundant, wave_lds);
+    hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, true, true, true, true>), grid, block, lds, stream, a, redundant, wave_lds);
 }
 #elif defined(BH_GROUP_FA_TU)
 // The launches of the builds with the fast arithmetic (this translation unit: swd_group_fa.hip).
 void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
                             bool adapt, bool counted, bool cntb)
 {
-#define BH_FA_(PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, true, PR, AD, CN, false, true>), grid, block, lds, stream, a, redundant, wave_lds)
+#define BH_FA_(PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 2, true, PR, AD, CN, true>), grid, block, lds, stream, a, redundant, wave_lds)
 #define BH_FA(PR, AD) do { if (cntb) BH_FA_(PR, AD, true); else BH_FA_(PR, AD, false); } while (0)
     if (adapt) {
         if (counted) BH_FA(true, true);
@@ -1057,7 +941,7 @@ bool build_slot_ranks(int n0, int n1, int ncu, std::vector<int32_t> rank[2])
 
 int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdLaunchInfo *info, int wpb, SwdPairWork *pair)
 {
-    if (wpb != 4) wpb = GROUP_WPB;
+    wpb = GROUP_WPB; // (four wavefronts per workgroup were the co-resident receiver-function experiment of rounds 3-5: gone)
     int kmax = 0, maxmode = 1;
     for (int t = 0; t < a0.ntargets; ++t) {
         kmax = a0.t[t].K > kmax ? a0.t[t].K : kmax;
@@ -1257,43 +1141,28 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     // length: c2 2.51 -> 2.30 ms, c3 2.60 -> 2.49).  One model per wavefront (the trial lanes already walk the scan seven
     // steps a round: 1.25 -> 1.27 ms per window of the chains) and Rayleigh + Love launches of the reference's sequence (the
     // Rayleigh wavefronts set the time: c2 3.37 -> 3.47 ms) do not gain.
-    // (BH_SCAN_AUTO with the certified-sign scan on: that scan serves Love as well -- one look instead of jump + index search)
     // (not in a launch of several models per wavefront that mixes both refinements: that build would spill; one model per
     //  wavefront -- the chains' windows -- has it)
-    const bool cntb = any_love && wpb == GROUP_WPB && !(build == 1 && !adapt) && (a.counted == 1 || (a.counted == 2 && a.prescan == 0 && !adapt && (all_love ? build != 1 : build == 2)));
+    const bool cntb = any_love && wpb == GROUP_WPB && !(build == 1 && !adapt) && (a.counted == 1 || (a.counted == 2 && !adapt && (all_love ? build != 1 : build == 2)));
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
 #define BH_GROUP_LAUNCH_ADAPT(FM, PR) do { if (cntb) BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, true); else BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, false); } while (0)
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
-    const bool prek = a.prescan != 0 && !adapt && !cntb && wpb == GROUP_WPB;
-    a.prescan = prek ? 1 : 0;
     // the fast arithmetic (FA, see the kernel): every target of the launch takes the short refinement, the usual targets
-    const bool farith = a.farith != 0 && build == 2 && simple && !prek && wpb == GROUP_WPB;
+    const bool farith = a.farith != 0 && build == 2 && simple && wpb == GROUP_WPB;
     a.farith = farith ? 1 : 0;
     if (info != nullptr) info->fast_arith = a.farith;
     if (farith) {
         bh_launch_swd_group_fa(a, grid, block, lds, stream, redundant, (int)wave_lds, adapt, counted, cntb);
-    } else if (prek) { // the certified-sign scan: the general builds (see PREK at the kernel), compiled in swd_group_prek.hip
-        bh_launch_swd_group_prek(a, grid, block, lds, stream, redundant, (int)wave_lds, build);
-    } else if (wpb == 4) { // (the co-resident receiver-function experiment: the general builds only, without the counted scan)
-        static std::atomic<unsigned long long> big_lds{0};
-        if (lds > WG_LDS_CAP) {
-            const void *k4[3] = {reinterpret_cast<const void *>(swd_group_kernel<4, 0, false, true, false, false>), reinterpret_cast<const void *>(swd_group_kernel<4, 1, false, true, false, false>),
-                                 reinterpret_cast<const void *>(swd_group_kernel<4, 2, false, true, false, false>)};
-            if (!bh_allow_big_lds(&big_lds, k4, 3, 160 * 1024)) return -1;
-        }
-        if (build == 2) BH_GROUP_LAUNCH_(4, 2, false, true, false, false);
-        else if (build == 1) BH_GROUP_LAUNCH_(4, 1, false, true, false, false);
-        else BH_GROUP_LAUNCH_(4, 0, false, true, false, false);
     } else if (adapt && build == 2) {
         if (counted) BH_GROUP_LAUNCH_ADAPT(2, true);
         else BH_GROUP_LAUNCH_ADAPT(2, false);
     } else if (adapt && build == 1) { // (both sequences in one launch: Rayleigh targets short, Love targets the reference's)
         // (the instrumented build with both sequences AND the counted scan needs more than 256 registers: it is compiled with
-        //  the one-wavefront-per-SIMD budget of swd_group_prek.hip -- counters and clocks are what it is for, not speed)
-        if (counted && cntb) bh_launch_swd_group_prek(a, grid, block, lds, stream, redundant, (int)wave_lds, -1);
+        //  the one-wavefront-per-SIMD budget of swd_group_big.hip -- counters and clocks are what it is for, not speed)
+        if (counted && cntb) bh_launch_swd_group_big(a, grid, block, lds, stream, redundant, (int)wave_lds);
         else if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
         else BH_GROUP_LAUNCH_ADAPT(1, false);
     } else if (adapt) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
 
     SearchT<BH_WAVE, NEV_LO, FAST, SIMPLE> S;
     S.init(md, mmax, valid, A.igr, K, per, xs + lane, ys + lane, A.vel + (size_t)ib * A.ldv, r == 0, A.mode,
-           cpl + lane, cpl + (size_t)K * BH_WAVE + lane, IFUNC, A.counted != 0, false, false, FA);
+           cpl + lane, cpl + (size_t)K * BH_WAVE + lane, IFUNC, A.counted != 0, false, FA);
     {
         const size_t nl = (size_t)gridDim.x * LANE_WPB * BH_WAVE; // lanes of the launch
         double *hx = A.nev_high + (size_t)wid * BH_WAVE + lane;
@@ -655,39 +655,4 @@ double bh_swd_plan(int B, int Lmax, int ntargets, const int *iwave, int Gforce, 
     *G = Gg;
     for (int t = 0; t < ntargets; ++t) look[t] = plan_fit(Gg, best_lvl[t]);
     return best;
-}
-
-
-// ---- probe of the certified-sign evaluation (tests: bit-equality with oracle/csign_oracle.c) ----
-namespace {
-struct ModelGlobalF { // the model's float arrays in global memory, the accessors of ModelLds
-    const float *d, *a, *b, *rho;
-    __device__ __forceinline__ float Df(int m) const { return d[m]; }
-    __device__ __forceinline__ float Af(int m) const { return a[m]; }
-    __device__ __forceinline__ float Bf(int m) const { return b[m]; }
-    __device__ __forceinline__ double D(int m) const { return (double)d[m]; }
-    __device__ __forceinline__ double A(int m) const { return (double)a[m]; }
-    __device__ __forceinline__ double Bv(int m) const { return (double)b[m]; }
-    __device__ __forceinline__ double R(int m) const { return (double)rho[m]; }
-    __device__ __forceinline__ double IA(int m) const { return csign::rcp_fast((double)a[m]); }
-    __device__ __forceinline__ double IB(int m) const { return csign::rcp_fast((double)b[m]); }
-    __device__ __forceinline__ double IR(int m) const { return csign::rcp_fast((double)rho[m]); }
-    __device__ __forceinline__ double ID(int m) const { return csign::rcp_fast((double)d[m]); }
-};
-__global__ void csign_probe_kernel(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out)
-{
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n) return;
-    ModelGlobalF md{mdl, mdl + nlay, mdl + 2 * nlay, mdl + 3 * nlay};
-    const int llw = (md.Bf(0) <= 0.0f) ? 2 : 1;
-    double v, bd;
-    const bool ok = (iwave == 2) ? csign::rayleigh(md, nlay, llw, omega[i], c[i], v, bd) : csign::love(md, nlay, llw, omega[i], c[i], v, bd);
-    out[i] = v;
-    out[n + i] = bd;
-    out[2 * (size_t)n + i] = ok ? 1.0 : 0.0;
-}
-} // namespace
-void bh_launch_csign_probe(int iwave, int nlay, const float *mdl, int n, const double *omega, const double *c, double *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(csign_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, iwave, nlay, mdl, n, omega, c, out);
 }

@@ -110,8 +110,9 @@ enum : int {
     PH_REFC = 3,       // trials clustered around the estimate
     PH_PROBE_STEP = 4, // the guard's probes of a scan step over a half-space velocity (ST_GS1 / ST_GS2 of SearchT)
     PH_PROBE_ACC = 5,  // the guard's probes outside an accepted bracket (ST_GH / ST_GL)
-    PH_SPECIAL = 6,    // a bracket that contains betmx or a half-space velocity: how many sign changes it holds, and where (see the kernel)
-    PH_PROBE_START = 7 // the guard's probes next to a start value that lies next to a root
+    PH_SPECIAL = 6,    // a bracket that contains betmx or a half-space velocity: the sign changes BELOW that velocity (see the kernel)
+    PH_PROBE_START = 7, // the guard's probes next to a start value that lies next to a root
+    PH_SPECIAL_B = 8   // ... and those above it
 };
 
 __device__ __forceinline__ bool sign_neg(double x) { return __double_as_longlong(x) < 0; }
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     double lo = 0.0, hi = 0.0, flo = 0.0, fhi = 0.0, p3 = 0.0, fp3 = 0.0, c3 = 0.0, wprev = 0.0;
     bool have3 = false;
     double cell_lo = 0.0, cell_hi = 0.0, pb = 0.0, delb = 0.0;
+    bool pp_neg = false; // PH_SPECIAL -> PH_SPECIAL_B: the sign just above the special velocity
+    int sp_nb = 0;       // ... and the sign changes found below it
     bool flo_neg = false, chk = false; // chk: this period's start value has been probed (PH_PROBE_START)
     unsigned evals = 0;
     if (active) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     constexpr int NC = (J >= 32) ? BH_LEAN_CLUSTER_BIG : ((J >= 8) ? BH_LEAN_CLUSTER : J / 2), NR = J - NC;
     constexpr bool can_spec = J >= 4; // (every trial count the launcher offers)
     constexpr unsigned long long maskC = (1ull << NC) - 1ull, maskR = (1ull << NR) - 1ull;
-    const double invJ1 = 1.0 / (double)(J + 1), invJm1 = 1.0 / (double)(J - 1);
+    const double invJ1 = 1.0 / (double)(J + 1);
     unsigned nrounds = 0;
     long long t_eval = 0;
     const long long t_start = ((CNT && A.neval != nullptr)) ? clock64() : 0;
@@ -367,10 +370,17 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 om_l = omg[k + 1];
                 iom_l = fa::rcp(om_l);
             }
-        } else if (ph == PH_SPECIAL) {
-            // lanes 0 / 1: just below / just above the special velocity of the cell; the others: J - 2 section points of the cell
+        } else if (J >= 32 && (ph == PH_SPECIAL || ph == PH_SPECIAL_B)) { // (fewer lanes: such a cell is guarded at once)
+            // lanes 0 / 1: the two points s (1 -+ 3e-6) next to the special velocity s of the cell; the others: J - 2 points between
+            // there and the cell's lower (PH_SPECIAL) / upper (PH_SPECIAL_B) end, their distances from s in geometric progression
+            // (the sign changes of such a cell crowd towards s: the root just below it, its image just above, the next ones at
+            // 2 - 10 times the distance)
             const double sp = special_in_cell(cell_lo, cell_hi);
-            cev = (r == 0) ? sp - guard_rel * sp : ((r == 1) ? sp + guard_rel * sp : __builtin_fma(cell_hi - cell_lo, (double)(r - 1) * invJm1, cell_lo));
+            const double g = guard_rel * sp;
+            const bool up = ph == PH_SPECIAL_B;
+            const float lg = log2f((float)(((up ? cell_hi - sp : sp - cell_lo)) / g)) * (1.0f / (float)(J - 1));
+            const double dist = g * (double)exp2f(lg * (float)(r - 1));
+            cev = (r == 0) ? (up ? sp + g : sp - g) : ((r == 1) ? sp + g : (up ? sp + dist : sp - dist));
         } else if (ph == PH_PROBE_START) {
             cev = (r == 0) ? c1 - guard_rel * c1 : ((r == 1) ? c1 + guard_rel * c1 : c1);
         } else if (ph == PH_PROBE_STEP) {
@@ -428,63 +438,74 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         // S velocity the half-space term takes |k - k_beta|: a root just below it has a mirror image just above, and further sign
         // changes may follow up to betmx -- the reference's function has them, and getsol takes whatever nevill ends at provided it
         // is not above betmx (:468-471).  A cell with SEVERAL sign changes is therefore a matter of nevill's sequence (which root;
-        // with betmx inside: whether the period fails), a cell with ONE is not.  The cell's J - 2 section points and the two
-        // points s (1 -+ 3e-6) next to the special velocity s say which it is:
+        // with betmx inside: whether the period fails), a cell with ONE is not.  Two rounds count them: the two points s (1 -+ 3e-6)
+        // next to the special velocity s and J - 2 points between s and the cell's lower end, then J - 2 between s and its upper
+        // end, their distances from s in geometric progression (ratio <= 1.23 with 32 lanes per model: the sign changes of such
+        // a cell crowd towards s).  With fewer than 32 lanes per model the cell is guarded at once.
         //   * one sign change in the whole cell: the refinement goes on in its section (s = betmx and the sign change above it: the
         //     period fails as the reference's does -- nevill ends within 1e-6 c of a sign change above betmx (1 + 3e-6));
-        //   * s = betmx, no sign change below it, several above: the period fails whichever of them nevill ends at;
         //   * anything else -- several sign changes, one between the two points next to s, a value that is no number -- the guard.
         // (Before this rule a cell with betmx inside was always guarded -- 99 % of the guarded models of LVZ-rich batches,
         // profiles/r05_lean_guard.txt -- and a cell with a half-space velocity below betmx inside was refined like any other:
         // on models drawn from a sampler's prior, one in 10^4 then came back with another root of the cell than the reference's,
         // up to 1.5e-3 away.)
         bool special_now = false;
-        if (__ballot(active && ph == PH_SPECIAL) != 0ull) {
-            const double sp = special_in_cell(cell_lo, cell_hi);
-            const double pm = sp - guard_rel * sp, pp = sp + guard_rel * sp;
-            const unsigned long long m_b = (__ballot(r >= 2 && cev < pm) >> lbase) & maskJ, m_a = (__ballot(r >= 2 && cev > pp) >> lbase) & maskJ;
-            const int nb = __builtin_popcountll(m_b), na = __builtin_popcountll(m_a); // section points below pm: lanes 2 .. nb + 1; above pp: the last na lanes
-            const unsigned long long s_b = (mneg >> 2) & ((1ull << nb) - 1ull), s_a = (na > 0) ? ((mneg >> (J - na)) & ((1ull << na) - 1ull)) : 0ull;
-            // Signs in the order of the velocities, in two sequences (with 64 lanes per model one would not fit 64 bits).  Below:
-            // element 0 = cell_lo, 1 .. nb = the section points (lanes 2 .. nb + 1), nb + 1 = pm (lane 0).  Above: element 0 = pp
-            // (lane 1), 1 .. na = the section points (lanes J - na .. J - 1), na + 1 = cell_hi.  Bit e of ch_*: a sign change
-            // between elements e and e + 1.
-            const unsigned long long seq_b = (flo_neg ? 1ull : 0ull) | (s_b << 1) | ((mneg & 1ull) << (nb + 1));
-            const unsigned long long seq_a = ((mneg >> 1) & 1ull) | (s_a << 1) | ((sign_neg(fhi) ? 1ull : 0ull) << (na + 1));
-            const unsigned long long ch_b = (seq_b ^ (seq_b >> 1)) & ((1ull << (nb + 1)) - 1ull), ch_a = (seq_a ^ (seq_a >> 1)) & ((1ull << (na + 1)) - 1ull);
-            const bool at = ((mneg & 1ull) != 0ull) != ((mneg & 2ull) != 0ull);
-            const int n_b = __builtin_popcountll(ch_b), n_a = __builtin_popcountll(ch_a);
-            const bool below = ch_b != 0ull;                                      // the (first) sign change lies below the special velocity
-            const int te = below ? (int)__builtin_ctzll(ch_b) : (ch_a ? (int)__builtin_ctzll(ch_a) : 0); // between elements te and te + 1 of its sequence
-            // lanes of the two elements (-1: the cell's own end)
-            const int e_lo = below ? ((te == 0) ? -1 : te + 1) : ((te == 0) ? 1 : J - na + te - 1);
-            const int e_hi = below ? ((te == nb) ? 0 : te + 2) : ((te == na) ? -1 : J - na + te);
-            const int l_lo = e_lo < 0 ? 0 : e_lo, l_hi = e_hi < 0 ? 0 : e_hi;
-            const double d_lo = __shfl(del, lbase + l_lo), d_hi = __shfl(del, lbase + l_hi);
-            const double c_lo = __shfl(cev, lbase + l_lo), c_hi = __shfl(cev, lbase + l_hi);
-            if (active && ph == PH_SPECIAL) {
+        if (J >= 32 && __ballot(active && (ph == PH_SPECIAL || ph == PH_SPECIAL_B)) != 0ull) {
+            // Signs in the order of the distance from s.  Element 0 = the point next to s (lane 0: s - g below, lane 1: s + g above),
+            // elements 1 .. J - 2 = lanes 2 .. J - 1, element J - 1 = the cell's end on that side (sign of cell_lo: flo_neg; the other
+            // end's is the opposite).  Bit e of ch: a sign change between elements e and e + 1.
+            const bool up = ph == PH_SPECIAL_B;
+            const bool s_near = up ? pp_neg : (mneg & 1ull) != 0ull, s_end = up ? !flo_neg : flo_neg;
+            const unsigned long long inner = (J > 2) ? ((mneg >> 2) & ((1ull << (J - 2)) - 1ull)) : 0ull;
+            const unsigned long long seq = (s_near ? 1ull : 0ull) | (inner << 1) | ((s_end ? 1ull : 0ull) << (J - 1));
+            const unsigned long long ch = (seq ^ (seq >> 1)) & ((1ull << (J - 1)) - 1ull);
+            const int nch = __builtin_popcountll(ch);
+            const int te = ch ? (int)__builtin_ctzll(ch) : 0;
+            // the lanes of elements te (nearer to s) and te + 1 (-1: the cell's end)
+            const int e_near = (te == 0) ? (up ? 1 : 0) : te + 1, e_far = (te + 1 == J - 1) ? -1 : te + 2;
+            const double d_near = __shfl(del, lbase + e_near), d_far = __shfl(del, lbase + (e_far < 0 ? 0 : e_far));
+            const double c_near = __shfl(cev, lbase + e_near), c_far = __shfl(cev, lbase + (e_far < 0 ? 0 : e_far));
+            if (active && (ph == PH_SPECIAL || ph == PH_SPECIAL_B)) {
                 special_now = true;
                 evals += (unsigned)J;
-                const bool is_betmx = sp == betmxd;
-                if (m_small != 0ull || at || n_b + n_a == 0) {
+                const bool is_betmx = special_in_cell(cell_lo, cell_hi) == betmxd;
+                if (m_small != 0ull || nch > 1) {
                     LEAN_GUARD(6);
-                } else if (is_betmx && n_b == 0) { // every sign change above betmx: getsol's "c1 > betmx" (:470)
-                    todo = 2;
-                } else if (n_b + n_a == 1) { // the one sign change of the cell
-                    if (e_lo >= 0) {
-                        lo = c_lo;
-                        flo = d_lo;
+                } else if (!up) { // below s
+                    pp_neg = (mneg & 2ull) != 0ull;
+                    if (pp_neg != ((mneg & 1ull) != 0ull)) LEAN_GUARD(6); // (a sign change between the two points next to s)
+                    sp_nb = nch;
+                    if (nch == 1) { // the section with the sign change: [far, near]
+                        hi = c_near;
+                        fhi = d_near;
+                        if (e_far >= 0) {
+                            lo = c_far;
+                            flo = d_far;
+                        }
                     }
-                    if (e_hi >= 0) {
-                        hi = c_hi;
-                        fhi = d_hi;
+                    ph = PH_SPECIAL_B;
+                } else { // above s: the cell's sign changes are counted
+                    if (sp_nb + nch != 1) {
+                        if (is_betmx && sp_nb == 0 && nch > 0) todo = 2; // (unreachable with nch <= 1; kept for the rule's sake)
+                        else LEAN_GUARD(6);
+                    } else if (nch == 1 && is_betmx) { // the cell's one sign change lies above betmx: getsol's "c1 > betmx" (:470)
+                        todo = 2;
+                    } else {
+                        if (nch == 1) { // [near, far]
+                            lo = c_near;
+                            flo = d_near;
+                            if (e_far >= 0) {
+                                hi = c_far;
+                                fhi = d_far;
+                            }
+                        }
+                        // (the section is a few per cent of the cell wide and holds one sign change: a cluster around the secant
+                        // point closes in on it; if not, the next round is a J-section of the section)
+                        have3 = false;
+                        nref = 0;
+                        wprev = hi - lo;
+                        ph = PH_REFC;
                     }
-                    have3 = false;
-                    nref = 0;
-                    wprev = hi - lo;
-                    ph = PH_REF1;
-                } else {
-                    LEAN_GUARD(6);
                 }
             }
         }
@@ -520,6 +541,17 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 };
                 evals += (unsigned)__builtin_popcountll(m_pt);
                 ++nref;
+                if (sect && m_pt != 0ull) {
+                    // Several sign changes among the section points: a cell with several roots (modes closer than dc: short periods
+                    // over thick slow layers; above a half-space velocity the function's oscillations) -- which of them nevill ends
+                    // at is a matter of its sequence: the guard.  (A cluster's round that does not close in is followed by a J-section:
+                    // a cell whose first estimate is poor -- a cell with several roots -- comes by here.)
+                    const int np = r1 - r0 + 1;
+                    const unsigned long long sg = (mneg >> r0) & ((np >= 64) ? ~0ull : ((1ull << np) - 1ull));
+                    const int inner = __builtin_popcountll((sg ^ (sg >> 1)) & ((np >= 65) ? ~0ull : ((1ull << (np - 1)) - 1ull)));
+                    const int ends = ((((sg & 1ull) != 0ull) != sign_neg(oflo)) ? 1 : 0) + (((((sg >> (np - 1)) & 1ull) != 0ull) != sign_neg(ofhi)) ? 1 : 0);
+                    if (inner + ends > 1) LEAN_GUARD(6);
+                }
                 if (m_pt != 0ull) {
                     if (eA < nA) { // first trial beyond the sign change
                         hi = ctrial(eA);
@@ -546,8 +578,18 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         have3 = true;
                     }
                 }
-                // the estimate's round did not close in (a poor estimate: an end value that is not the function's, a kink): J-section next
-                ph = (ph == PH_REFC && hi - lo > 0.25 * wprev) ? PH_REF1 : PH_REFC;
+                // The estimate's round did not close in (a poor estimate: an end value that is not the function's, a kink, several
+                // roots in the cell): J-section next.  If it was the cell's first round the J-section takes the WHOLE cell again,
+                // not the part the estimate's trials left of it: it counts the cell's sign changes (above), and a cell with three
+                // roots cut at a poor estimate shows one.
+                const bool poor = ph == PH_REFC && hi - lo > 0.25 * wprev;
+                if (poor && nref == 1) {
+                    lo = olo;
+                    hi = ohi;
+                    flo = oflo;
+                    fhi = ofhi;
+                }
+                ph = poor ? PH_REF1 : PH_REFC;
                 wprev = hi - lo;
                 if (hi - lo <= 1.3e-6 * fabs(hi) || nref >= 16 || m_pt == 0ull) {
                     // the root: inverse quadratic interpolation through the bracket's ends and the nearest third point (the secant
@@ -738,7 +780,12 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     const double sp = special_in_cell(cell_lo, cell_hi);
                     if (sp != 0.0) {
                         ph = PH_SPECIAL;
-                        if (!(sp > 0.0 && sp - guard_rel * sp > cell_lo && sp + guard_rel * sp < cell_hi)) LEAN_GUARD(6);
+                        if (J < 32 || !(sp > 0.0 && sp - guard_rel * sp > cell_lo && sp + guard_rel * sp < cell_hi)) LEAN_GUARD(6);
+                    } else if (cell_lo > vsafe) {
+                        // A cell above a half-space velocity: the reference's function oscillates there (leaking modes' images): the
+                        // refinement starts with a J-section, which counts the sign changes it sees (below).
+                        have3 = false;
+                        ph = PH_REF1;
                     }
                 }
             }

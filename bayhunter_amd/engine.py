@@ -119,8 +119,6 @@ def load_library():
     L.bh_engine_get_swd_scan.argtypes = [vp]
     L.bh_engine_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
     L.bh_engine_get_tuning.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
-    L.bh_engine_set_swd_prescan.argtypes = [vp, C.c_int]
-    L.bh_engine_get_swd_prescan.argtypes = [vp]
     L.bh_engine_guard_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.bh_engine_set_typical_layers.argtypes = [vp, C.c_int]
     L.bh_engine_set_model_order.argtypes = [vp, C.c_int]
@@ -140,14 +138,13 @@ def load_library():
                                     C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, vp]
     L.bh_loglike_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.bh_probe_math.argtypes = [vp, C.c_int, C.c_int, _d, _d]
-    L.bh_probe_csign.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, _d, _d, _d, _d, vp]
     L.bh_chain_propose.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int]
     L.bh_chain_accept.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, vp, vp]
     L.bh_chain_propose_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.bh_chain_accept_window.argtypes = [vp, C.POINTER(ChainConfig), C.POINTER(ChainState), C.c_int, C.c_int, C.c_int, C.c_ssize_t, vp, vp]
-    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
+    for name in ("bh_engine_create", "bh_engine_synchronize", "bh_engine_set_instrumentation", "bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_set_swd_search", "bh_engine_get_swd_search", "bh_engine_set_swd_arith", "bh_engine_get_swd_arith", "bh_engine_last_swd_kernel", "bh_engine_set_swd_trials", "bh_engine_get_swd_trials", "bh_engine_set_swd_scan", "bh_engine_get_swd_scan", "bh_engine_set_tuning", "bh_engine_get_tuning", "bh_engine_guard_stats", "bh_engine_set_typical_layers", "bh_engine_set_model_order",
                  "bh_timing_reset", "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace", "bh_swd_batch", "bh_rf_batch", "bh_targets_set",
-                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_probe_csign", "bh_chain_propose", "bh_chain_accept",
+                 "bh_evaluate_batch", "bh_loglike_batch", "bh_probe_math", "bh_chain_propose", "bh_chain_accept",
                  "bh_chain_propose_window", "bh_chain_accept_window"):
         getattr(L, name).restype = C.c_int
     if L.bh_abi_version() != 10:
@@ -165,8 +162,8 @@ EXPORTED_SYMBOLS = ("bh_abi_version", "bh_engine_create", "bh_engine_destroy", "
                     "bh_chain_propose", "bh_chain_accept", "bh_chain_propose_window", "bh_chain_accept_window")
 # include/bh_engine_debug.h: measurement, diagnostics, experiment switches (bench.py, tools/, tests)
 DEBUG_SYMBOLS = ("bh_engine_set_swd_group", "bh_engine_set_swd_lookahead", "bh_engine_last_swd_kernel", "bh_engine_set_swd_scan",
-                 "bh_engine_get_swd_scan", "bh_engine_set_swd_prescan", "bh_engine_get_swd_prescan", "bh_engine_set_tuning",
-                 "bh_engine_get_tuning", "bh_probe_math", "bh_probe_csign", "bh_engine_set_instrumentation", "bh_timing_reset",
+                 "bh_engine_get_swd_scan", "bh_engine_set_tuning",
+                 "bh_engine_get_tuning", "bh_probe_math", "bh_engine_set_instrumentation", "bh_timing_reset",
                  "bh_timing_collect", "bh_timing_steps", "bh_last_neval", "bh_debug_counters", "bh_debug_trace")
 
 
@@ -523,32 +520,6 @@ class Engine(object):
         v = C.c_int(0)
         self._check(self._L.bh_engine_get_tuning(self._h, name.encode(), C.byref(v)))
         return int(v.value)
-
-    def set_swd_prescan(self, on):
-        """The certified-sign scan (include/bh_engine.h: bh_engine_set_swd_prescan; on by default, bit-identical results)."""
-        self._check(self._L.bh_engine_set_swd_prescan(self._h, 1 if on else 0))
-
-    def swd_prescan(self):
-        return bool(self._L.bh_engine_get_swd_prescan(self._h))
-
-    @contextlib.contextmanager
-    def prescanning(self, on):
-        prev = self.swd_prescan()
-        self.set_swd_prescan(on)
-        try:
-            yield self
-        finally:
-            self.set_swd_prescan(prev)
-
-    def probe_csign(self, iwave, h, vp, vs, rho, omega, c):
-        """Diagnostic (bh_probe_csign): the certified-sign evaluation of the (omega, c) points of one model: (val, bound, certified)."""
-        f = [np.ascontiguousarray(a, dtype=np.float32) for a in (h, vp, vs, rho)]
-        om, cc = _f64(omega).ravel(), _f64(c).ravel()
-        n = om.size
-        val, bd, ok = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32)
-        self._check(self._L.bh_probe_csign(self._h, int(iwave), int(f[0].size), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]), n,
-                                           om.ctypes.data_as(_d), cc.ctypes.data_as(_d), val.ctypes.data_as(_d), bd.ctypes.data_as(_d), _ptr(ok)))
-        return val, bd, ok.astype(bool)
 
     def probe_math(self, op, x):
         x = _f64(x).ravel()

@@ -56,17 +56,6 @@ int bh_engine_last_swd_kernel(const bh_engine *e);
 int bh_engine_set_swd_scan(bh_engine *e, int scan);
 int bh_engine_get_swd_scan(const bh_engine *e);
 
-/* The certified-sign scan (OFF by default).  Results never depend on this setting.
- * getsol's bracket scan consumes only the SIGN of the secular function at its grid points.  With this on, a search first
- * evaluates the grid ahead with a cheap evaluation of the same recursion that carries an error bound (one lane per grid
- * point) and lands two steps before the first grid point whose sign is not PROVEN equal to the start value's; the
- * reference-exact function is evaluated there and from there on, so brackets, roots and failure flags are those of the
- * step-by-step scan.  Applies to both root refinements and all target types in launches of several models per wavefront
- * (a few thousand models per call); ignored elsewhere.  Measured not to pay (the look-ahead costs what the skipped rounds
- * cost): off. */
-int bh_engine_set_swd_prescan(bh_engine *e, int on);
-int bh_engine_get_swd_prescan(const bh_engine *e);
-
 /* Experiment switches (csrc/bh_tuning.h lists them: name, environment variable, default, meaning).  They change scheduling
  * and launch geometry, never a result.  The table is filled once per process from the environment; this call changes one
  * entry for the calls that follow (process-wide).  BH_EINVAL for an unknown name, and always in a build with
@@ -81,11 +70,6 @@ int bh_engine_get_tuning(bh_engine *e, const char *name, int *value);
  * sin / cos / exp through the kernels' glibc-exact restatement (csrc/bh_libm.h).  Used by the tests to document how far the
  * device math library is from the host's libm (SURVEY.md 7 "FMA contraction & device libm"). */
 int bh_probe_math(bh_engine *e, int op, int n, const double *in, double *out);
-/* Diagnostic: the certified-sign evaluation (see bh_engine_set_swd_prescan) of n (omega, c) points of one model of nlay
- * layers (host float arrays): val = the surface value under the per-layer max-norm scaling, bound = its error bound,
- * certified = |val| > 2 bound.  tests/test_gpu_csign.py compares the three with oracle/csign_oracle.c bit for bit. */
-int bh_probe_csign(bh_engine *e, int iwave, int nlay, const float *h, const float *vp, const float *vs, const float *rho,
-                   int n, const double *omega, const double *c, double *val, double *bound, int32_t *certified);
 
 /* Instrumentation (off by default; bench.py and the tests turn it on).
  *   timing:   HIP events are recorded on the stream the kernels are launched on, around each

@@ -60,21 +60,9 @@ double bho_dltar4(double wvno, double omega, const float *d, const float *a, con
 /* surfdisp96.f:367-388 */
 float bho_gtsolh(float a, float b);
 
-/* ---- the engine's certified-sign evaluation (csign_oracle.c; NOT the reference's algorithm) ----
- * The secular function of one trial velocity by the cheap arithmetic of csign_oracle.c with a running error bound: *val = the surface value under the
- * per-layer max-norm scaling, *bound = its error bound; returns 1 when |val| > 2 bound (the sign is the reference-exact one).
- * ifunc 1 Love, 2 Rayleigh. */
-int bho_csign(int ifunc, double omega, double c, const float *d, const float *a, const float *b, const float *rho,
-              int mmax, int llw, double *val, double *bound);
-int bho_csign_vec(int ifunc, double omega, double c, const float *d, const float *a, const float *b, const float *rho,
-                  int mmax, int llw, double *ev, double *epsv);
 /* the surface vector of the binary64 recursion (2 / 5 entries) */
 void bho_secular_vec(int ifunc, double omega, double c, const float *d, const float *a, const float *b, const float *rho,
                      int mmax, int llw, double *vec);
-/* 1: the bracket scans of bho_surfdisp96 / bho_swd_batch skip the grid points the certified-sign evaluation proves to be
- * without a sign change (swd_oracle.c, bracket_and_refine): same brackets, same bits, fewer binary64 evaluations. */
-void bho_swd_set_prescan(int on);
-void bho_swd_prescan_stats(int64_t *out, int reset);
 
 /* Batched convenience: B models, SoA-by-model-row [B][Lmax] float64 inputs (cast to f32
  * inside, like f2py does), OpenMP over models.  vel[B][K], err[B]. */

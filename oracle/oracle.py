@@ -27,7 +27,7 @@ LAW_NOCORR, LAW_NOCORR_SCALED, LAW_EXP, LAW_GAUSS = 0, 1, 2, 3
 def build(force=False):
     """(Re)build liboracle.so with the Makefile next to this file."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("swd_oracle.c", "csign_oracle.c", "rf_oracle.c", "like_oracle.c", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("swd_oracle.c", "rf_oracle.c", "like_oracle.c", "oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -51,14 +51,6 @@ def lib():
         L.bho_swd_set_scan.argtypes = [C.c_int]
         L.bho_swd_set_scan_tuning.restype = None
         L.bho_swd_set_scan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.bho_swd_set_prescan.restype = None
-        L.bho_swd_set_prescan.argtypes = [C.c_int]
-        L.bho_swd_prescan_stats.restype = None
-        L.bho_swd_prescan_stats.argtypes = [_i64, C.c_int]
-        L.bho_csign.restype = C.c_int
-        L.bho_csign.argtypes = [C.c_int, C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int, _d, _d]
-        L.bho_csign_vec.restype = C.c_int
-        L.bho_csign_vec.argtypes = [C.c_int, C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int, _d, _d]
         L.bho_secular_vec.restype = None
         L.bho_secular_vec.argtypes = [C.c_int, C.c_double, C.c_double, _f, _f, _f, _f, C.c_int, C.c_int, _d]
         L.bho_swd_guarded_count.restype = C.c_int64
@@ -131,45 +123,12 @@ class swd_scan:
         lib().bho_swd_set_scan(0)
 
 
-class swd_prescan:
-    """with swd_prescan(1): the engine's certified-sign scan (same brackets and bits, fewer binary64 evaluations)"""
-
-    def __init__(self, on):
-        self.on = on
-
-    def __enter__(self):
-        lib().bho_swd_set_prescan(int(self.on))
-
-    def __exit__(self, *a):
-        lib().bho_swd_set_prescan(0)
-
-
-def csign(ifunc, omega, c, d, a, b, rho, vec=False):
-    """The certified-sign evaluation of one trial velocity (csign_oracle.c): (certified, value, bound), or with vec=True
-    (certified, e[2 or 5], eps[2 or 5]).  d, a, b, rho: float32 arrays of the model's layers."""
-    f = [np.ascontiguousarray(x, dtype=np.float32) for x in (d, a, b, rho)]
-    n = int(f[0].size)
-    ev = np.zeros(5); ep = np.zeros(5)
-    ok = lib().bho_csign_vec(int(ifunc), float(omega), float(c), _pf(f[0]), _pf(f[1]), _pf(f[2]), _pf(f[3]), n, 1, _pd(ev), _pd(ep))
-    if vec:
-        m = 2 if ifunc == 1 else 5
-        return bool(ok), ev[:m], ep[:m]
-    return bool(ok), float(ev[0]), float(ep[0])
-
-
 def secular_vec(ifunc, omega, c, d, a, b, rho):
     """the surface vector of the reference-exact recursion (2 entries for Love, 5 for Rayleigh)"""
     f = [np.ascontiguousarray(x, dtype=np.float32) for x in (d, a, b, rho)]
     out = np.zeros(5)
     lib().bho_secular_vec(int(ifunc), float(omega), float(c), _pf(f[0]), _pf(f[1]), _pf(f[2]), _pf(f[3]), int(f[0].size), 1, _pd(out))
     return out[:2 if ifunc == 1 else 5]
-
-
-def swd_prescan_stats(reset=True):
-    """[grid points looked at, proven, landings, landings whose binary64 values contradicted the proof] of THIS thread's scans"""
-    out = np.zeros(4, np.int64)
-    lib().bho_swd_prescan_stats(out.ctypes.data_as(_i64), 1 if reset else 0)
-    return out
 
 
 class swd_search:

@@ -498,18 +498,6 @@ static int g_scan_mode = 0;
 void bho_swd_set_scan(int counted) { g_scan_mode = counted ? 1 : 0; }
 static int g_stride_first = 16, g_stride_next = 4, g_stride_back = -1, g_stride_secant = 1; /* (tuning experiments) */
 void bho_swd_set_scan_tuning(int first, int next, int back) { g_stride_first = first; g_stride_next = next % 100; g_stride_back = back; g_stride_secant = next < 100; }
-/* The certified-sign scan (bh_engine_set_swd_prescan; csign_oracle.c): 1 = an upward scan first looks ahead over its grid with
- * the cheap evaluation and lands two steps before the first grid point whose sign is not proven equal to the start's. */
-static int g_prescan = 0;
-void bho_swd_set_prescan(int on) { g_prescan = on ? 1 : 0; }
-#define BHO_PRESCAN_WINDOW 16 /* grid points per look (the device: the lanes of a model; the result does not depend on it) */
-#define BHO_PRESCAN_LOOKS 8
-static _Thread_local int64_t g_presc_points, g_presc_certified, g_presc_jumps, g_presc_violations;
-void bho_swd_prescan_stats(int64_t *out, int reset)
-{
-    out[0] = g_presc_points; out[1] = g_presc_certified; out[2] = g_presc_jumps; out[3] = g_presc_violations;
-    if (reset) g_presc_points = g_presc_certified = g_presc_jumps = g_presc_violations = 0;
-}
 static int64_t g_guarded = 0; /* models the guard sent back to the reference sequence (statistics) */
 int64_t bho_swd_guarded_count(int reset)
 {
@@ -699,61 +687,10 @@ static int bracket_and_refine(const medium *md, double t1, double *c1io, double 
     double cp = 0.0, delp = 0.0;                        /* the evaluated point a bracket end last replaced (third point of the */
     int have_p = 0;                                     /* short refinement's first estimate) */
     double del1 = 0.0;
-    int landed = 0;
-    if (g_prescan && !counted) {
-        /* THE CERTIFIED-SIGN SCAN (restates SearchT's ST_PRE, swd_common.h).  Grid points g_i = start + i dc by the reference's
-         * own repeated additions; s0 = the proven sign at the start value.  j = the first index whose sign is not proven equal
-         * to s0, or at which the reference's scan would do anything but step on (its bounds cm, betmx + dc, clow; a step that
-         * reaches a half-space velocity with the guard on).  j >= 3: the scan is known to walk from g_0 to g_(j-1) without a
-         * sign change -- it lands there: binary64 values at g_(j-2) (the point left behind) and g_(j-1), then steps on as
-         * before.  Otherwise (start value not proven, downward scan, j < 3): the reference's steps from the start value. */
-        double v32, b32;
-        const double vsafe = (fast && gd && gd->on) ? fmin(gd->vh[0], gd->nvh > 1 ? gd->vh[1] : gd->vh[0]) : 1.0e300;
-        ++g_presc_points;
-        if (bho_csign(md->ifunc, omega, c1, md->d, md->a, md->b, md->rho, md->mmax, md->llw, &v32, &b32)) {
-            ++g_presc_certified;
-            const int neg0 = v32 < 0.0;
-            const int up = (ifirst == 1) || (neg0 == (signbit(*del1st) != 0));
-            if (up) {
-                int j = 0;
-                double g = c1, gm1 = c1, gm2 = c1; /* g_j, g_(j-1), g_(j-2) */
-                for (;;) {
-                    const double nx = g + dc;
-                    int ok = !(nx < cm || nx >= betmx + dc) && nx > clow && nx < vsafe && j + 1 < BHO_PRESCAN_WINDOW * BHO_PRESCAN_LOOKS;
-                    if (ok) {
-                        ++g_presc_points;
-                        ok = bho_csign(md->ifunc, omega, nx, md->d, md->a, md->b, md->rho, md->mmax, md->llw, &v32, &b32) && ((v32 < 0.0) == neg0);
-                        g_presc_certified += ok;
-                    }
-                    ++j;
-                    if (!ok) break;
-                    gm2 = gm1;
-                    gm1 = g = nx;
-                }
-                /* here: g_0 .. g_(j-1) proven, gm1 = g_(j-1), gm2 = g_(j-2) */
-                if (j >= 3) {
-                    ++g_presc_jumps;
-                    if (fast && md->ifunc == 2 && g_fast_third) { /* (the point left behind is only used by the seeded first estimate) */
-                        delp = secular(md, omega / gm2, omega);
-                        cp = gm2;
-                        have_p = 1;
-                        if ((signbit(delp) != 0) != neg0) ++g_presc_violations;
-                    }
-                    del1 = secular(md, omega / gm1, omega);
-                    c1 = gm1;
-                    if ((signbit(del1) != 0) != neg0) ++g_presc_violations;
-                    if (ifirst == 1) *del1st = neg0 ? -1.0 : 1.0; /* (only its sign is ever used) */
-                    landed = 1;
-                }
-            }
-        }
-    }
-    if (!landed) {
-        del1 = counted ? secular_count(md, omega / c1, omega, &n1, &v1) : secular(md, omega / c1, omega);
-        if (ifirst == 1) *del1st = del1;
-    }
+    del1 = counted ? secular_count(md, omega / c1, omega, &n1, &v1) : secular(md, omega / c1, omega);
+    if (ifirst == 1) *del1st = del1;
     int idir = 1;
-    if (!landed && ifirst != 1 && signs_differ(*del1st, del1)) idir = -1;
+    if (ifirst != 1 && signs_differ(*del1st, del1)) idir = -1;
     /* (c1 + dc <= clow: getsol first moves the start to clow -- its loop top, also when searching upward: a higher mode whose
        previous root lies below the floor the previous mode sets -- and that changes the grid: the reference's steps then) */
     int use_count = counted && v1 && idir > 0 && c1 + dc > clow;

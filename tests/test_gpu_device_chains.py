@@ -417,8 +417,8 @@ def test_initial_state_and_windows_do_not_depend_on_the_shard_size():
         return bh.JointTarget([t1, t2])
     priors = dict(su["priors"])
     init = dict(su["init"], iter_burnin=60, iter_main=20, maxmodels=5)
-    whole = DeviceChains(targets(), 600, init, priors, seed=11)
-    shard = DeviceChains(targets(), 150, init, priors, seed=11, chain_offset=300)
+    whole = DeviceChains(targets(), 600, init, priors, seed=11, spec_depth=2)     # (the same window depth: it is chosen by the chain count otherwise)
+    shard = DeviceChains(targets(), 150, init, priors, seed=11, chain_offset=300, spec_depth=2)
     a, b = whole.state_host(), shard.state_host()
     sl = slice(300, 450)
     assert np.array_equal(a["like"][sl], b["like"]) and np.array_equal(a["misfits"][:, sl], b["misfits"])

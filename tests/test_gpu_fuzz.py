@@ -6,7 +6,7 @@ The default path has no bit-level restatement: it is held to the reference by to
 this test draws ~200 000 NEW models on every tree: the seed is BH_FUZZ_SEED if set, else derived from the commit (`git rev-parse
 HEAD` where a work tree is present) or -- on the GPU box, whose snapshot has no .git -- from the bytes of the built library, so a
 new build walks new models, and a failure is reproduced with the printed seed.  Checked against the ORACLE's reference sequence
-(oracle/swd_oracle.c search mode 0, bit-identical to the compiled reference): failure flags, zero rows, 2e-6 -- for bh_swd_batch on
+(oracle/swd_oracle.c search mode 0, bit-identical to the compiled reference): failure flags, zero rows, 2.5e-6 -- for bh_swd_batch on
 sorted-velocity models with a low-velocity zone and on models drawn from a sampler's prior, and for the fused call's failure
 pattern."""
 import hashlib
@@ -79,7 +79,10 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
               "guarded %d, calls on the trial-per-lane kernel %d" % (seed, source, nmodels, worst, flagdiff, zerodiff, nguard, nlean))
     assert nlean > 0
     assert flagdiff == 0 and zerodiff == 0, "seed %d" % seed
-    assert worst <= 2e-6, "seed %d: %.3g" % (seed, worst)       # (north_star: 1e-5)
+    # north_star: 1e-5.  The fixed sets of test_gpu_swd_lean.py are held to 2e-6 (seen there: 1.4e-6); the bound is 2.3e-6 --
+    # the root lies inside this path's final bracket (<= 1.3e-6 c wide) and inside the reference's (1e-6 c), either returns a point
+    # of its own -- and fresh models have come to 1.8e-6: asserted here with that bound's margin
+    assert worst <= 2.5e-6, "seed %d: %.3g" % (seed, worst)
 
 
 def test_fused_call_failure_pattern_on_fresh_models(engine, oracle, capsys):

@@ -130,7 +130,8 @@ def test_fused_target_with_more_than_60_periods(engine):
 
 
 @pytest.mark.parametrize("law", [E.LAW_NOCORR, E.LAW_EXP])
-@pytest.mark.parametrize("n,nsamp,fsamp", [(1024, 2048, 20.0), (201, 512, 5.0), (48, 128, 4.0), (1, 128, 4.0), (2, 128, 4.0), (8192, 16384, 50.0)])
+@pytest.mark.parametrize("n,nsamp,fsamp", [(1024, 2048, 20.0), (201, 512, 5.0), (48, 128, 4.0), (1, 128, 4.0), (2, 128, 4.0), (8192, 16384, 50.0),
+                                           (16385, 32768, 100.0)])   # (beyond 16 384 samples the fused sums read the spectrum from the HBM workspace)
 def test_fused_receiver_function_likelihood_has_the_bits_of_the_unfused_one(engine, law, n, nsamp, fsamp):
     """bh_evaluate_batch without synthetics asked for: the receiver function's samples never leave the CU -- the synthesis
     kernel forms the sums the nocorr / exponential law needs in like_kernel's own order (RfKernelArgs::sums).  logL and
@@ -138,7 +139,7 @@ def test_fused_receiver_function_likelihood_has_the_bits_of_the_unfused_one(engi
     64 samples (one wavefront's reduction), longer ones, and the 1- and 2-sample edge cases of the exponential law."""
     from bayhunter_amd.synth import synth_models
     rs = np.random.RandomState(n)
-    B = 96
+    B = 96 if nsamp <= 16384 else 12
     nlay, h, vp, vs, rho = synth_models(rs, B, 10, ragged=True)
     per = np.linspace(2, 40, 20)
     engine.set_targets([

@@ -12,11 +12,12 @@ TOL = 1e-9
 
 @pytest.mark.parametrize("nsamp,fsamp,nkeep", [(512, 5.0, 201), (2048, 20.0, 1024), (64, 2.0, 32), (4096, 40.0, 2048), (4, 1.0, 4),
                                                (8, 2.0, 7), (128, 5.0, 128), (256, 5.0, 99), (8192, 40.0, 4001), (16384, 80.0, 8192),
-                                               (32768, 100.0, 16001), (131072, 200.0, 65536)])   # (beyond 16384: the spectra go through an HBM workspace)
+                                               (32768, 100.0, 16001), (131072, 200.0, 65536),
+                                               (262144, 400.0, 70000)])   # (beyond 16384: the spectra go through an HBM workspace; 262144 = BH_RF_MAX_NSAMP, the largest served)
 @pytest.mark.parametrize("waveno", [0, 1])
 def test_random_ragged_models_match_oracle(engine, oracle, nsamp, fsamp, nkeep, waveno):
     rs = np.random.RandomState(nsamp + waveno)
-    nlay, h, vp, vs, rho = synth_models(rs, 70 if nsamp <= 16384 else 9, 21, lvz_frac=0.3, ragged=True)
+    nlay, h, vp, vs, rho = synth_models(rs, 70 if nsamp <= 16384 else (9 if nsamp < 262144 else 3), 21, lvz_frac=0.3, ragged=True)
     rf = engine.rf_batch(nlay, h, vp, vs, rho, 6.4, 2.5, nsamp, fsamp, 5.0, waveno, nkeep)
     orf = oracle.rf_batch(nlay, h.T, vp.T, vs.T, rho.T, 6.4, 2.5, nsamp, fsamp, 5.0, waveno, nkeep)
     peak = np.abs(orf).max(axis=1, keepdims=True)

@@ -253,7 +253,6 @@ def test_lookahead_does_not_change_results(engine, G, J):
     vp[0, :8] = 1.5
     vs[:, 8:12] *= 0.2                   # and some that fail the search
     per = np.linspace(1.5, 70, 35)
-    engine.set_swd_prescan(False)        # (evaluation counts are compared; the certified-sign scan: test_gpu_csign.py)
     try:
         for iwave, igr in REFS.values():
             for mode in (1, 3):
@@ -268,7 +267,6 @@ def test_lookahead_does_not_change_results(engine, G, J):
                 assert np.array_equal(v1, v2) and np.array_equal(e1, e2), (iwave, igr, mode)
                 assert n1 == n2 and n1 > 0
     finally:
-        engine.set_swd_prescan(False)
         engine.set_swd_group(0)
         engine.set_swd_lookahead(0)
         engine.set_instrumentation(False, False)
@@ -317,7 +315,7 @@ def test_experiment_switches_are_a_table_with_an_api(engine):
     """csrc/bh_tuning.h: the library's experiment switches are parsed once per process; bh_engine_set_tuning changes one by name,
     unknown names are refused, and none of them changes a result (here: the progress board and the SIMD-pairing order)."""
     from bayhunter_amd.engine import EngineError
-    assert engine.tuning("rf_no_cut") == 0 and engine.tuning("swd_wpb") == 2
+    assert engine.tuning("rf_no_cut") == 0 and engine.tuning("swd_rerun_wgs") == 64
     with pytest.raises(EngineError):
         engine.set_tuning("no_such_switch", 1)
     rs = np.random.RandomState(3)

@@ -27,13 +27,11 @@ def fast(engine):
     counts are compared; velocities and flags do not depend on the scan setting)"""
     engine.set_swd_search("fast")
     engine.set_swd_scan("counted")
-    engine.set_swd_prescan(False)   # (evaluation counts are compared: the certified-sign scan's own tests are test_gpu_csign.py)
     try:
         yield engine
     finally:
         engine.set_swd_search("reference")
         engine.set_swd_scan("auto")
-        engine.set_swd_prescan(False)
 
 
 class restatement:
@@ -121,7 +119,6 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
     a = [np.ascontiguousarray(x.T) for x in (h, vp, vs, rho)]
     assert engine.swd_scan() == "auto"
     engine.set_instrumentation(False, True)
-    engine.set_swd_prescan(False)          # (evaluation counts are compared)
     try:
         for iwave, igr, mode, flsph in ((1, 0, 1, 0), (1, 1, 2, 0), (1, 0, 3, 1), (1, 1, 3, 0), (2, 0, 1, 0)):
             got = {}
@@ -138,7 +135,6 @@ def test_counted_scan_keeps_the_bits_and_matches_its_restatement_evaluation_for_
             assert (n1 < 0.8 * n0) if iwave == 1 else (n1 == n0)
     finally:
         engine.set_swd_scan("auto")
-        engine.set_swd_prescan(False)
         engine.set_instrumentation(False, False)
 
 

@@ -89,7 +89,9 @@ def test_within_tolerance_of_the_reference_lvz_rich(lean, oracle, ref):
     # between the two trial counts: the last bit of the binary32 output, except where one of them sends the model to the
     # reference's sequence and the other does not (the guard's tests look at the root's last digits) -- then the reference's 1e-6
     assert worst_rel(v16, v[:n], v16 != 0) <= ACHIEVED
-    assert np.mean(v16 != v[:n]) < 0.01
+    # (round 6: with 32 trials per round a cell that holds betmx or a half-space velocity is resolved inside the kernel, with 8
+    # it goes to the reference's sequence -- Love's long periods sit next to the half-space velocity: a few per cent of the values)
+    assert np.mean(v16 != v[:n]) < 0.06
 
 
 BIG = [  # (target, layers up to, earth flattening, models): 1.7 million in all

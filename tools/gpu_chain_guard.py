@@ -34,6 +34,7 @@ eng.set_instrumentation(False, True)
 names = ["-", "water", "small / hinge start", "small scan", "step probes", "bracket probes", "special cell", "root at end"]
 tot0 = np.array(eng.guard_totals())
 nonempty = 0; models = 0; prev = tot0.copy()
+rs_ = [0] * 8
 it0 = dc.iiter
 for w in range(NW):
     l0 = dc.launches
@@ -42,9 +43,10 @@ for w in range(NW):
     t = np.array(eng.guard_totals())
     nonempty += int((t - prev).sum() > 0)
     prev = t
-c = eng.debug_counters()
-rs_ = [0] + [(c[14 if i <= 4 else 15] >> (16 * ((i - 1) & 3))) & 0xffff for i in range(1, 8)]
+    c = eng.debug_counters()       # (the counters of the window's call: every call starts them anew)
+    for i in range(1, 8):
+        rs_[i] += (c[14 if i <= 4 else 15] >> (16 * ((i - 1) & 3))) & 0xffff
 d = prev - tot0
 print("%d chains, %d windows (%d iterations each): windows with a guarded model %d (%.0f %%); guarded models per target %s" %
       (C, NW, (dc.iiter - it0) // max(1, NW), nonempty, 100.0 * nonempty / NW, d[:3].tolist()))
-print("reasons (mod 65536): " + ", ".join("%s %d" % (names[i], rs_[i]) for i in range(1, 8) if rs_[i]))
+print("reasons: " + ", ".join("%s %d" % (names[i], rs_[i]) for i in range(1, 8) if rs_[i]))

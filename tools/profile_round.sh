@@ -35,6 +35,10 @@ for w in c4 c5 c5_full; do python $R/bench.py --workload $w --steps 600 --warmup
 # the trial-per-lane kernel: rounds and cycles per round; the fast arithmetic's cost and distance from the exact one
 python $R/tools/gpu_lean_rounds.py > "$OUT/lean_rounds.txt" 2>&1
 python $R/tools/gpu_lean_guard.py > "$OUT/lean_guard.txt" 2>&1
+# the guard in a sampler's windows (8 and 64 chains): how many windows hold a guarded model, and by which rule
+{ python $R/tools/gpu_chain_guard.py 8 300; python $R/tools/gpu_chain_guard.py 64 200; } 2>&1 | grep -v amdgpu.ids > "$OUT/chain_guard.txt"
+# c2's targets on models drawn from the chains' prior (ragged 2..21 layers, velocities in any order)
+python $R/bench.py --workload c2p --no-cpu-baseline > "$OUT/bench_c2p.json" 2> "$OUT/bench_c2p.err"
 [ -x $R/tools/ubench/faeval ] && $R/tools/ubench/faeval > "$OUT/faeval.txt" 2>&1
 [ -x $R/tools/ubench/fadiff ] && $R/tools/ubench/fadiff > "$OUT/fadiff.txt" 2>&1
 python $R/bench.py --workload c4 --steps 700 --warmup 300 --spec-depth 1 > "$OUT/bench_c4_depth1.json" 2> "$OUT/bench_c4_depth1.err"
@@ -64,6 +68,7 @@ BH_SWD_ARITH=exact python $R/tools/gpu_phase_c3.py > "$OUT/phase_c3_fastexact.tx
 [ "${BH_FUZZ_REF:-3000}" != 0 ] && python $R/tools/gpu_fuzz.py 404 ${BH_FUZZ_REF:-3000} > "$OUT/fuzz_reference.txt" 2>&1
 [ "${BH_FUZZ_FAST:-8000}" != 0 ] && FAST=1 python $R/tools/gpu_fuzz.py 405 ${BH_FUZZ_FAST:-8000} > "$OUT/fuzz_fast.txt" 2>&1
 [ "${BH_FUZZ_LEAN:-8000}" != 0 ] && LEAN=1 python $R/tools/gpu_fuzz.py 406 ${BH_FUZZ_LEAN:-8000} > "$OUT/fuzz_lean.txt" 2>&1
+[ "${BH_FUZZ_LEAN:-8000}" != 0 ] && LEAN=1 PRIOR=1 python $R/tools/gpu_fuzz.py 407 ${BH_FUZZ_LEAN:-8000} > "$OUT/fuzz_lean_prior.txt" 2>&1   # models drawn from a sampler's prior
 for sh in c3 tut t512u t512r n8192 n16384; do python $R/tools/gpu_rf_perf.py $sh 2>&1 | tail -1; done > "$OUT/rf_alone.txt"
 for s in "4096 1024" "4096 2048" "8192 1024" "1024 1024" "4096 201"; do python $R/tools/gpu_gauss_perf.py $s 2>&1 | tail -1; done > "$OUT/gauss_alone.txt"
 fi
