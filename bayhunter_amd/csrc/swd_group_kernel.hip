@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BH_WAVE * WPB) __attribute__((amdgpu_waves_per_eu(B
     // Rayleigh round, 61 per Love round).  A workgroup's wavefronts only share the libm tables.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / BH_WAVE));
     // PASSES (the re-run of the models a guard listed, one model per wavefront, reference sequence): the launch is a SMALL grid
-    // (bh_launch_swd_group: bh_tuning.h swd_rerun_wgs = 64 per target) whose workgroups stride over the list, whose length lives on
+    // (bh_launch_swd_group: bh_tuning.h swd_rerun_wgs = 256 per target) whose workgroups stride over the list, whose length lives on
     // the device -- nearly always it is empty or a handful of models, and a launch sized for the worst case (one wavefront per
     // model of the batch: 2048 workgroups at B = 4096) had to be dispatched workgroup by workgroup only to leave at once (4.5 us
     // alone, 0.2 ms when receiver-function workgroups of the other stream were waiting for the same wave slots).

@@ -404,6 +404,12 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
         const bool inB = ph == PH_REFC && spec && r >= NC;
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
+        // (NOT guarded: a root within 1e-6 c of a grid point with a second root less than a step away -- the cell that holds both
+        // shows no sign change, so one grid sees a bracket where the reference's, 1e-6 c beside it, walks past the pair, or the
+        // other way round -- and root pairs closer together than the guard's 3e-6 next to a half-space velocity.  A rule for the
+        // first (|f| two orders of magnitude below its neighbours', both of one sign) was built in round 6: it also fired on the
+        // cusp of failing Love models at betmx -- one of the bench's 16 384 models, 0.65 -> 0.83 ms per step -- and could not see
+        // the steep roots of channel modes at all.  Four models in 10 million drawn from a sampler's prior: DESIGN.md 4.)
         if (ph <= PH_SCAN || inB) {
             const bool first = ph == PH_START || inB;        // the window is a period's first round: trial 0 = the start value,
             const int rr = inB ? r - NC : r;                 // the steps upward (consumed only if the start value says so)
@@ -582,7 +588,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 // roots in the cell): J-section next.  If it was the cell's first round the J-section takes the WHOLE cell again,
                 // not the part the estimate's trials left of it: it counts the cell's sign changes (above), and a cell with three
                 // roots cut at a poor estimate shows one.
-                const bool poor = ph == PH_REFC && hi - lo > 0.25 * wprev;
+                // (the cell's first round: "closed in" = the sign change lies BETWEEN two of the cluster's trials -- an estimate that is
+                // merely in the right fifth of a cell with three roots leaves a bracket around one of them)
+                const bool poor = ph == PH_REFC && (hi - lo > 0.25 * wprev || (nref == 1 && !(eA > 0 && eA < nA)));
                 if (poor && nref == 1) {
                     lo = olo;
                     hi = ohi;
@@ -783,7 +791,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         if (J < 32 || !(sp > 0.0 && sp - guard_rel * sp > cell_lo && sp + guard_rel * sp < cell_hi)) LEAN_GUARD(6);
                     } else if (cell_lo > vsafe) {
                         // A cell above a half-space velocity: the reference's function oscillates there (leaking modes' images): the
-                        // refinement starts with a J-section, which counts the sign changes it sees (below).
+                        // refinement starts with a J-section, which counts the sign changes it sees (below).  (No measurable cost: c4 8.72
+                        // against 8.68 x 10^4 chain-iterations/s with / without.)
                         have3 = false;
                         ph = PH_REF1;
                     }

@@ -315,7 +315,7 @@ def test_experiment_switches_are_a_table_with_an_api(engine):
     """csrc/bh_tuning.h: the library's experiment switches are parsed once per process; bh_engine_set_tuning changes one by name,
     unknown names are refused, and none of them changes a result (here: the progress board and the SIMD-pairing order)."""
     from bayhunter_amd.engine import EngineError
-    assert engine.tuning("rf_no_cut") == 0 and engine.tuning("swd_rerun_wgs") == 64
+    assert engine.tuning("rf_no_cut") == 0 and engine.tuning("swd_rerun_wgs") == 256
     with pytest.raises(EngineError):
         engine.set_tuning("no_such_switch", 1)
     rs = np.random.RandomState(3)

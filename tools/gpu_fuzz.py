@@ -55,6 +55,7 @@ for it in range(ncfg):
     hint = int(rs.choice([0, 0, 3, 6, 12]))
     if LEAN:
         G = J = 0
+        eng.set_swd_trials(int(rs.choice([0, 0, 0, 4, 8, 16, 32, 64])))   # trials per round: by the call's shape, or pinned
     eng.set_swd_group(G); eng.set_swd_lookahead(J); eng.set_typical_layers(hint)
     with O.swd_search(2 if FAST else 0):
         ov, oe, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
