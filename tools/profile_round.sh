@@ -130,4 +130,7 @@ fi
 stamp "summaries"
 cd $R
 python tools/summarize_profiles.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
+# the kernels of one steady step of the fused call and of a sampler's window, from the kernel traces (who runs beside whom)
+[ -d "$OUT/trace_c3fast" ] && python tools/trace_timeline.py "$OUT/trace_c3fast" > "profiles/${TAG}_c3_timeline.txt" 2>&1
+[ -d "$OUT/trace_c4" ] && python tools/trace_timeline.py "$OUT/trace_c4" > "profiles/${TAG}_c4_timeline.txt" 2>&1
 cat "$OUT/summary.txt"
