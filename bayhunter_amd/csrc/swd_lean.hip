@@ -17,11 +17,15 @@
 //     2 or 8 lanes, see the kernel), by J-section where a cluster does not close in; the root returned is the inverse-quadratic
 //     point of the final bracket (<= 1.3e-6 |c| wide, typically 8e-7).  The reference (nevill) stops at a bracket of 1e-6 c1 and
 //     returns one of its ends: velocities agree to ~1e-6 relative (north_star: 1e-5).
-//   * THE GUARD of the short refinement (SearchT, swd_common.h) with the same rules and the same probes -- a root within two
-//     steps of a half-space velocity, a scan step over a half-space velocity that showed no sign change, a bracket that
-//     contains betmx -- plus the rule of the fast arithmetic: a scan or probe value that is not a number or below fa::SIGN_FLOOR fires it.  A
-//     guarded model is listed and run again by the engine with the reference's sequence in the reference's arithmetic
-//     (launch_swd_rerun), so failure flags and zero rows are the reference's.
+//   * THE GUARD of the short refinement (SearchT, swd_common.h) with its rules and probes -- a root within two steps of a
+//     half-space velocity with a sign change right outside the bracket, a scan step over a half-space velocity that showed no sign
+//     change -- plus, since round 6 (models drawn from a sampler's prior): a cell that holds betmx or a half-space velocity has its
+//     sign changes COUNTED (32 lanes per model and more; one: the refinement goes on, several: the guard; fewer lanes: the guard at
+//     once), a J-section counts the sign changes among its points (several roots in a cell: the guard), a cell's first estimate
+//     that does not bracket the root between two of its trials is followed by a J-section of the whole cell, a start value next to
+//     a sign change of the wrong polarity is guarded -- and the rule of the fast arithmetic: a scan or probe value that is not a
+//     number or below fa::SIGN_FLOOR fires it.  A guarded model is listed and run again by the engine with the reference's sequence
+//     in the reference's arithmetic (launch_swd_rerun), so failure flags and zero rows are the reference's.
 //   * A model with a water layer (unreachable from BayHunter) is guarded at once.
 #include "../../include/bh_engine_debug.h"
 #include "bh_device.h"
