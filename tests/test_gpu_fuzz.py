@@ -53,10 +53,11 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
     total = int(os.environ.get("BH_FUZZ_MODELS", "200000"))
     engine.set_swd_search("fast")
     engine.set_swd_arith("fast")
-    worst, flagdiff, zerodiff, nmodels, nguard, nlean, jumps = 0.0, 0, 0, 0, 0, 0, []
+    worst, nmodels, nguard, nlean, jumps = 0.0, 0, 0, 0, []
     for B, L, K in _configs(rs, total):
         ragged = bool(rs.rand() < 0.6) and L > 2
-        if rs.rand() < 0.5 and L >= 2:
+        prior = bool(rs.rand() < 0.5) and L >= 2
+        if prior:
             nlay, h, vp, vs, rho = prior_models(rs, B, L, nmin=2 if ragged else L)
         else:
             nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=float(rs.choice([0.0, 0.2, 0.5])), ragged=ragged)
@@ -75,28 +76,28 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
         both = (v != 0) & (rv != 0)
         rel = np.zeros_like(v)
         rel[both] = np.abs(v[both] - rv[both]) / np.abs(rv[both])
-        far = rel.max(axis=1) > 1e-5 if B else np.zeros(0, bool)          # another ROOT than the reference's (see below)
-        jumps += [(B, L, K, iwave, flsph, int(b), float(rel[b].max())) for b in np.where(far)[0]]
+        # a model on ANOTHER ROOT than the reference's (the known exception, below): beyond north_star's tolerance, or -- further along
+        # the other mode's branch -- with another failure flag / zero row
+        far = (rel.max(axis=1) > 1e-5) | (e != re_) | ((v == 0) != (rv == 0)).any(axis=1) if B else np.zeros(0, bool)
+        jumps += [(prior, B, L, K, iwave, flsph, int(b), float(rel[b].max()), int(e[b]), int(re_[b])) for b in np.where(far)[0]]
         if (~far).any():
             worst = max(worst, float(rel[~far].max()))
-        flagdiff += int((e != re_).sum())
-        zerodiff += int(((v == 0) != (rv == 0)).any(axis=1).sum())
         nmodels += B
     with capsys.disabled():
-        print("\n[fuzz] seed %d (%s): %d models, worst relative difference %.3g, failure flags differing %d, zero rows differing %d, "
-              "guarded %d, calls on the trial-per-lane kernel %d, models on another root than the reference's %d %s" %
-              (seed, source, nmodels, worst, flagdiff, zerodiff, nguard, nlean, len(jumps), jumps[:4]))
+        print("\n[fuzz] seed %d (%s): %d models, worst relative difference %.3g, guarded %d, calls on the trial-per-lane kernel %d, "
+              "models on another root than the reference's %d %s" % (seed, source, nmodels, worst, nguard, nlean, len(jumps), jumps[:4]))
     assert nlean > 0
-    assert flagdiff == 0 and zerodiff == 0, "seed %d" % seed
     # north_star: 1e-5.  The fixed sets of test_gpu_swd_lean.py are held to 2e-6 (seen there: 1.4e-6); the bound is 2.3e-6 --
     # the root lies inside this path's final bracket (<= 1.3e-6 c wide) and inside the reference's (1e-6 c), either returns a point
-    # of its own -- and fresh models have come to 1.9e-6: asserted here with that bound's margin
+    # of its own -- and fresh models have come to 1.95e-6: asserted here with that bound's margin
     assert worst <= 2.5e-6, "seed %d: %.3g" % (seed, worst)
-    # The known exception: a root that crosses zero within 1e-6 c of a scan grid point so steeply that no grid value
-    # shows it (a channel mode's pole-zero pair under a fast lid), with its partner less than a step away: this grid sees the
-    # bracket, the reference's -- 1e-6 c beside it -- does not, or the other way round; the scan then finds another mode.  Seen once
-    # in 5 million models drawn from a sampler's prior (tools/gpu_fuzz.py, seed 912).  More than one such model here is a bug.
-    assert len(jumps) <= 1, "seed %d: %s" % (seed, jumps)
+    # Failure flags and zero rows: the reference's -- with the known exception: a root within ~1e-6 c of a scan grid
+    # point with a second root less than a step away (two modes that nearly touch, a channel mode's pole-zero pair), or two roots
+    # within 2e-6 of a half-space velocity: the cell that holds both shows no sign change, so this grid sees a bracket where the
+    # reference's -- 1e-6 c beside it -- walks past to another mode, or the other way round.  Measured on 9.2 million models drawn
+    # from a sampler's prior (profiles/r06_fuzz_prior_final.txt): fewer than one in a million.  More than ONE such model among the
+    # ~100 000 prior-like ones of this test is a bug; on the sorted-velocity models none has ever been seen.
+    assert len(jumps) <= 1 and not [j for j in jumps if not j[0]], "seed %d: %s" % (seed, jumps)
 
 
 def test_fused_call_failure_pattern_on_fresh_models(engine, oracle, capsys):
