@@ -283,7 +283,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
     double cell_lo = 0.0, cell_hi = 0.0, pb = 0.0, delb = 0.0;
     bool pp_neg = false; // PH_SPECIAL -> PH_SPECIAL_B: the sign just above the special velocity
     int sp_nb = 0;       // ... and the sign changes found below it
-    bool nx_back = false; // the grid point after the bracket's far end has the sign of the point before the bracket
     bool flo_neg = false, chk = false; // chk: this period's start value has been probed (PH_PROBE_START)
     unsigned evals = 0;
     if (active) {
@@ -409,30 +408,15 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const unsigned long long m_pt = (__ballot(pt) >> lbase) & maskJ;
         const bool inB = ph == PH_REFC && spec && r >= NC;
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
-        // A ROOT NEXT TO A GRID POINT AND A SECOND ONE LESS THAN A STEP AWAY (two modes that nearly touch; 8 models in 10 million drawn
-        // from a sampler's prior).  The cell that holds both shows no sign change: a grid whose point falls between the two sees a
-        // bracket, the reference's -- up to 2e-6 c beside it -- may walk past the pair to another mode, or the other way round.
-        // Two rules, for roots of ordinary slope (a channel mode's pole-zero pair, a thousand times steeper than the function's
-        // scale over a step, shows in no grid value):
-        //   walking past (wpast, here): a plain step's value f_t that the line through f_(t-1), f_t sends through zero within 3
-        //     guard distances beyond the point, while the next point has the same sign and is LARGER again (a decaying |f| -- the scans
-        //     of failing Love models above betmx -- is not) -- a pair may sit right behind this grid point: the step from it to the
-        //     next point gets the guard's step probes (ev = 3, PH_PROBE_STEP: a sign change within the guard's distance of the
-        //     step's ends: the guard; none: an ordinary step.  One of the bench's 16 384 models has such a point: f = 0.31, 0.0008,
-        //     0.32 -- a near-tangency 6e-6 above the grid point's reach; guarded outright it cost the benchmark a re-run launch every
-        //     fourth step);
-        //   seeing the bracket (nx_back, at the bracket and at its acceptance): the root within the guard's distance of the bracket's
-        //     far end, and the grid point after it back at the sign before the bracket -- the partner right behind it: the guard.
-        const double d_up = __shfl(del, lane > 0 ? lane - 1 : 0), d_dn = __shfl(del, lane < BH_WAVE - 1 ? lane + 1 : lane);
-        bool wpast = false;
-        if ((ph <= PH_SCAN || inB) && !((ph == PH_START || inB) && (inB ? r - NC : r) == 0)) {
-            const int rr = inB ? r - NC : r;
-            if (rr < (inB ? NR : J) - 1) { // (the window's last point has no successor here: not looked at)
-                const double fprev = (rr == 0) ? del1 : d_up;
-                wpast = fabs(del) < 6.6e-3 * fabs(fprev - del) && fabs(d_dn) > fabs(del) && sign_neg(d_dn) == dneg && sign_neg(fprev) == dneg;
-            }
-        }
-        const unsigned long long m_wpw = __ballot(wpast); // (wavefront-wide: bit = lane)
+        // (NOT guarded: a root within ~1e-6 c of a grid point with a second root less than a step away -- the cell that holds both
+        // shows no sign change, so one grid sees a bracket where the reference's, 1e-6 c beside it, walks past the pair to another
+        // mode, or the other way round -- and root pairs closer together than the guard's 3e-6 next to a half-space velocity: 7 models
+        // in 9.2 million drawn from a sampler's prior, three of them with another failure flag further along the other branch
+        // (profiles/r06_fuzz_prior_final.txt).  Two forms of a rule for the first were built in round 6 and dropped:
+        // "|f| two orders of magnitude below both neighbours'" also fired on a near-tangency of one of the bench's 16 384 models
+        // (a re-run launch every fourth step: 0.65 -> 0.83 ms); step probes behind every point that the local slope sends through
+        // zero, plus a look at the grid point after an accepted root next to its bracket's end, caught 3 of 7 and cost every round
+        // two more neighbour exchanges: c2 0.670 -> 0.702 ms.  Neither can see a channel mode's steep pole-zero pair.)
         if (ph <= PH_SCAN || inB) {
             const bool first = ph == PH_START || inB;        // the window is a period's first round: trial 0 = the start value,
             const int rr = inB ? r - NC : r;                 // the steps upward (consumed only if the start value says so)
@@ -443,7 +427,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                 const double floor_ = inB ? cm : clow;
                 if (down && cev <= floor_) ev = 1;
                 else if (dneg != refneg) ev = 2;
-                else if (rr >= 1 && ((m_wpw >> (lane - 1)) & 1ull) != 0ull) ev = 3; // (the point before this one: see wpast)
                 else if (b_ >= vsafe && ((a_ <= vh0 && vh0 <= b_) || (a_ <= vh1 && vh1 <= b_))) ev = 3;
                 else if (cev < cm || cev >= betmxd + dc) ev = 4;
             }
@@ -657,8 +640,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             if (todo == 3) { // the guard at an accepted bracket
                 const double m2 = 2.0 * dc;
                 todo = 4;
-                // (the root next to the bracket's far end and a second sign change right behind it: see nx_back)
-                if (nx_back && fabs(c3 - ((idir > 0) ? cell_hi : cell_lo)) < guard_rel * fabs(c3)) LEAN_GUARD(7);
                 if (fabs(c3 - vh0) < m2 || fabs(c3 - vh1) < m2 || fabs(c3 - betmxd) < m2) {
                     const double eps = guard_rel * fabs(c3);
                     if (cell_hi - c3 < eps || c3 - cell_lo < eps || fabs(c3 - betmxd) < eps) {
@@ -712,8 +693,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         const int wb = lbase + w0;
         const int ev_e = __shfl(ev, wb + (e < wn ? e : wn - 1));
         const double d_e = __shfl(del, wb + (e < wn ? e : wn - 1)), d_em = __shfl(del, wb + (e > 0 ? e - 1 : 0)),
-                     d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb), d_second = __shfl(del, wb + 1),
-                     d_ep = __shfl(del, wb + (e + 1 < wn ? e + 1 : wn - 1));
+                     d_em2 = __shfl(del, wb + (e > 1 ? e - 2 : 0)), d_first = __shfl(del, wb), d_second = __shfl(del, wb + 1);
         if (active && scan_now) {
             const bool start = sc_first;
             const unsigned long long msm = (w0 != 0) ? ((m_small >> NC) & maskR) : m_small;
@@ -785,7 +765,6 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                         pb = cgrid(e);
                         delb = d_e;
                         todo2 = 1;
-                        nx_back = e + 1 < wn && sign_neg(d_ep) != sign_neg(d_e); // the point after the bracket: back at the sign before it
                     } else if (ev_e == 3) {
                         pb = cgrid(e);
                         delb = d_e;

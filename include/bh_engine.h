@@ -86,9 +86,10 @@ const char *bh_engine_last_error(const bh_engine *e);
  *                        root, or on WHICH of several roots of one scan cell nevill ends at (a cell that holds a half-space
  *                        velocity or betmx can hold a root, its mirror image and more), is detected and run again with the
  *                        reference's sequence inside the same call; bh_engine_guard_stats counts them.  (Known exception,
- *                        4 models in 10 million drawn from a sampler's prior: a root within 1e-6 c of a scan grid point with a
- *                        second root less than a step away, or two roots within 2e-6 of a half-space velocity -- the scan can
- *                        end on another mode than the reference's; flags were equal in all.  DESIGN.md 4.)  NOT the reference's
+ *                        fewer than one in a million models drawn from a sampler's prior, none seen on models with sorted
+ *                        velocities: a root within ~1e-6 c of a scan grid point with a second root less than a step away, or two
+ *                        roots within 2e-6 of a half-space velocity -- the scan can end on another mode than the reference's,
+ *                        and fail where it does not or the other way round further along that branch.  DESIGN.md 4.)  NOT the reference's
  *                        bits.  WHAT A RESULT DEPENDS ON: the model, and -- in its last digits, ~1e-9 relative, up to the
  *                        reference's own 1e-6 where the guard fires under one setting and not under another -- the kernel that
  *                        ran and its trials per round.  With BH_ARITH_EXACT that is the model alone.  With BH_ARITH_FAST
