@@ -173,6 +173,9 @@ struct SwdLaunchInfo {
 // the launches of the builds with the fast arithmetic (swd_group_fa.hip); called by bh_launch_swd_group
 void bh_launch_swd_group_fa(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
                             bool adapt, bool counted, bool cntb);
+// the launches of the one-model-per-wavefront builds (swd_group_adapt.hip); called by bh_launch_swd_group
+void bh_launch_swd_group_adapt(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
+                               int fm, bool pr, bool cn);
 // the launch of the build that needs one wavefront per SIMD as its register budget (swd_group_big.hip); called by bh_launch_swd_group
 void bh_launch_swd_group_big(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds);
 int bh_launch_swd_group(const SwdMultiArgs &a, int G, hipStream_t stream, SwdLaunchInfo *info = nullptr, int wavefronts_per_workgroup = 2,

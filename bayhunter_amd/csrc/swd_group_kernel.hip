@@ -826,7 +826,7 @@ restart_with_the_reference_sequence:
     }
 }
 
-#if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_BIG_TU)
+#if !defined(BH_GROUP_FA_TU) && !defined(BH_GROUP_BIG_TU) && !defined(BH_GROUP_ADAPT_TU)
 size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 {
     const int MPW = BH_WAVE / (G * J);
@@ -846,6 +846,28 @@ size_t group_lds_bytes(int G, int J, int Lmax, int Kmax, int maxmode)
 void bh_launch_swd_group_big(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds)
 {
     hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, 1, true, true, true, true>), grid, block, lds, stream, a, redundant, wave_lds);
+}
+#elif defined(BH_GROUP_ADAPT_TU)
+// The one-model-per-wavefront builds (ADAPT: a sampler's windows, single models, the re-run of guarded models) in a translation unit
+// of their own (swd_group_adapt.hip: the same source, the same flags) -- a third of this file's instantiations: it halves the
+// build's longest compile.  fm = the sequences compiled in (FASTM), pr = with counters and clocks, cn = with the counted Love scan.
+void bh_launch_swd_group_adapt(const SwdMultiArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t stream, int redundant, int wave_lds,
+                               int fm, bool pr, bool cn)
+{
+#define BH_AD_(FM, PR, CN) hipLaunchKernelGGL((swd_group_kernel<GROUP_WPB, FM, true, PR, true, CN>), grid, block, lds, stream, a, redundant, wave_lds)
+#define BH_AD(FM, PR) do { if (cn) BH_AD_(FM, PR, true); else BH_AD_(FM, PR, false); } while (0)
+    if (fm == 2) {
+        if (pr) BH_AD(2, true);
+        else BH_AD(2, false);
+    } else if (fm == 1) {
+        if (pr) BH_AD_(1, true, false); // (with the counted scan as well: swd_group_big.hip)
+        else BH_AD(1, false);
+    } else {
+        if (pr) BH_AD(0, true);
+        else BH_AD(0, false);
+    }
+#undef BH_AD
+#undef BH_AD_
 }
 #elif defined(BH_GROUP_FA_TU)
 // The launches of the builds with the fast arithmetic (this translation unit: swd_group_fa.hip).
@@ -1147,7 +1169,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
     a.counted = cntb ? 1 : 0;
 #define BH_GROUP_LAUNCH_(WP, FM, SI, PR, AD, CN) hipLaunchKernelGGL((swd_group_kernel<WP, FM, SI, PR, AD, CN>), grid, block, lds, stream, a, redundant, (int)wave_lds)
 #define BH_GROUP_LAUNCH(WP, FM, SI, PR) do { if (cntb) BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, true); else BH_GROUP_LAUNCH_(WP, FM, SI, PR, false, false); } while (0)
-#define BH_GROUP_LAUNCH_ADAPT(FM, PR) do { if (cntb) BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, true); else BH_GROUP_LAUNCH_(GROUP_WPB, FM, true, PR, true, false); } while (0)
+#define BH_GROUP_LAUNCH_ADAPT(FM, PR) bh_launch_swd_group_adapt(a, grid, block, lds, stream, redundant, (int)wave_lds, FM, PR, cntb) /* swd_group_adapt.hip */
     // The builds without the counters exist for the SIMPLE launches only: there they are worth 2 % (c2 3.44 -> 3.37 ms; 4 instead
     // of 33 spilled SGPRs); a launch with group-velocity targets is 2 % SLOWER without them (c2g 5.55 -> 5.67 ms).
     // the fast arithmetic (FA, see the kernel): every target of the launch takes the short refinement, the usual targets
@@ -1163,7 +1185,7 @@ int bh_launch_swd_group(const SwdMultiArgs &a0, int G0, hipStream_t stream, SwdL
         // (the instrumented build with both sequences AND the counted scan needs more than 256 registers: it is compiled with
         //  the one-wavefront-per-SIMD budget of swd_group_big.hip -- counters and clocks are what it is for, not speed)
         if (counted && cntb) bh_launch_swd_group_big(a, grid, block, lds, stream, redundant, (int)wave_lds);
-        else if (counted) BH_GROUP_LAUNCH_(GROUP_WPB, 1, true, true, true, false);
+        else if (counted) bh_launch_swd_group_adapt(a, grid, block, lds, stream, redundant, (int)wave_lds, 1, true, false);
         else BH_GROUP_LAUNCH_ADAPT(1, false);
     } else if (adapt) {
         if (a.rerun && tun.swd_rerun_wgs > 0 && grid.x > (unsigned)tun.swd_rerun_wgs) grid.x = (unsigned)tun.swd_rerun_wgs; // (the kernel's PASSES: its workgroups stride over the list)
