@@ -81,6 +81,11 @@ struct SwdKernelArgs {
     int counted;      // 1: Love scans skip the steps a mode count proves empty (SearchT: the counted scan; same bits)
     int farith;       // 1: a launch of the short refinement (fundamental-mode phase velocities) computes with the fast arithmetic (swd_fa.h)
     int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
+    // A group velocity's two chains of roots (SearchT: F_CHAIN_A / F_ONE).  igr = 2: the chain of first roots, unrounded into vel,
+    // the value getsol keeps from the mode's first search into first[model].  second = 1 (igr = 1): B = Bm x K searches, entry
+    // v = the second root of period v / Bm of model v % Bm, which reads vel and first and writes the group velocity (err untouched).
+    int second, Bm;
+    double *first;
 };
 
 void bh_launch_swd(const SwdKernelArgs &a, int iwave, hipStream_t stream);
@@ -105,6 +110,7 @@ struct SwdTarget {
                           // re-run of the models the short refinement's guard fired on: perm = that list)
     int32_t *gcount, *glist; // short refinement: models its guard fired on are appended here (count, indices), see SearchT
     int refseq;              // 1: in a launch with the short refinement this (phase-velocity) target keeps the reference's sequence
+    double *first;           // igr = 2 (the chain of a group velocity's first roots, SwdKernelArgs): [B]
 };
 struct SwdMultiArgs {
     int B, Lmax, ntargets;

@@ -40,6 +40,7 @@ void tuning_clamp()
     if (g_tuning.rf_lds_gated < 0 || g_tuning.rf_lds_gated > 160 * 1024) g_tuning.rf_lds_gated = 0;
     if (g_tuning.rf_lds_beside > 160 * 1024) g_tuning.rf_lds_beside = -1;
     if (g_tuning.swd_love_inlook < 0 || g_tuning.swd_love_inlook > 4) g_tuning.swd_love_inlook = 0;
+    if (g_tuning.swd_gsplit < 0 || g_tuning.swd_gsplit > (1 << 24)) g_tuning.swd_gsplit = 0; // (the launch's entry index is an int)
 }
 void tuning_parse()
 {
@@ -127,7 +128,7 @@ struct bh_engine {
     std::string err;
     // staging / workspace
     DevBuf nlay, h, vp, vs, rho, qp, qs, periods, vel, errb, rf, coef, ymod, noise, logL,
-        misfits, err_t, probe_in, probe_out, counter, sph, perm, board, nevhi, rfz;
+        misfits, err_t, probe_in, probe_out, counter, sph, perm, board, nevhi, rfz, gfirst, nevhi2;
     unsigned swd_stamp = 0;                // launch counter of the group kernel (marks its progress-board entries)
     // targets
     int nt = 0;
@@ -334,6 +335,7 @@ struct SwdJob {
     int32_t *err;
     int mode = 1;
     int flsph = 0;
+    double *first = nullptr; // igr = 2 (launch_swd_jobs: the chain of a group velocity's first roots): SwdKernelArgs::first
 };
 
 int swd_counter(bh_engine *e, hipStream_t st, unsigned long long **out)
@@ -413,10 +415,45 @@ int launch_swd_rerun(bh_engine *e, hipStream_t st, const SwdMultiArgs &main, int
 // All dispersion targets of one call.  Small batches go to the group kernel (G lanes per model,
 // one launch for all targets); batches that fill the chip by themselves use one lane per model.
 int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged &m, ptrdiff_t sl,
-                    ptrdiff_t sb, int njobs, const SwdJob *jobs)
+                    ptrdiff_t sb, int njobs, const SwdJob *jobs_given)
 {
     if (B == 0 || njobs == 0) return BH_OK;
     int rc;
+    // Group velocities of the fundamental mode: two launches.  The root at t/(1+h) of period k + 1 starts from the root at
+    // t/(1+h) of period k (surfdisp96.f:262-266); the root at t/(1-h) starts from the root at t/(1+h) of ITS OWN period
+    // (:282-287) and nothing starts from it.  One search after the other is a chain of 2 K dependent roots; here the target
+    // first runs as the chain of its K first roots (igr = 2: beside the call's other targets, in whatever kernel the call
+    // takes, every root stored unrounded in the output row), then a launch of B x K independent searches (one lane each, or
+    // up to 16 trial lanes while that still fits the chip at once: swd_kernel, SwdKernelArgs::second) finds the second roots
+    // and puts the group velocities in their place.  The same searches on the same values: the same bits (tests/test_gpu_swd.py's
+    // golden rows and oracle comparisons run through here).  Measured, one launch -> two (ms per call): one model 2.26 -> 1.43;
+    // two targets x 256 / 1024 / 4096 / 8192 / 16 384 / 65 536 models: 2.64 -> 1.90, 2.91 -> 2.10, 5.51 -> 4.64, 11.2 -> 8.09,
+    // 17.2 -> 12.5, 31.5 -> 29.9 (the second roots are a third of the evaluations but run as full wavefronts of independent
+    // searches, one lane each; in one launch they sit in the chain's wavefronts, whose lanes wait for each other's searches).
+    // bh_tuning.h swd_gsplit: the largest call in (model, period) pairs that is split (0: none).
+    SwdJob jobs_split[BH_MAX_TARGETS];
+    const SwdJob *jobs = jobs_given;
+    int nsplit = 0;
+    {
+        const long cap = bh_tuning().swd_gsplit;
+        bool take[BH_MAX_TARGETS] = {false};
+        for (int j = 0; j < njobs && njobs <= BH_MAX_TARGETS; ++j) {
+            take[j] = jobs_given[j].K != 0 && jobs_given[j].igr == 1 && jobs_given[j].mode <= 1 && cap > 0 && (long)B * jobs_given[j].K <= cap;
+            nsplit += take[j] ? 1 : 0;
+        }
+        if (nsplit > 0) {
+            if ((rc = ensure(e, e->gfirst, (size_t)nsplit * B * sizeof(double)))) return rc;
+            int n = 0;
+            for (int j = 0; j < njobs; ++j) {
+                jobs_split[j] = jobs_given[j];
+                if (take[j]) {
+                    jobs_split[j].igr = 2;
+                    jobs_split[j].first = (double *)e->gfirst.p + (size_t)(n++) * B;
+                }
+            }
+            jobs = jobs_split;
+        }
+    }
     int kmax = 0, maxmode = 1, nlive = 0;
     bool any_sphere = false;
     for (int j = 0; j < njobs; ++j) {
@@ -477,6 +514,46 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     if (lean && G <= 1) G = bh_swd_pick_group(B, nlive, Lmax); // (the launch is set up where the group kernel's is)
     unsigned long long *counter = nullptr;
     if ((rc = swd_counter(e, st, &counter))) return rc;
+    // the launches of the second roots of the group-velocity targets run as two chains (above), after the call's other launches
+    auto second_roots = [&]() -> int {
+        int J2 = 16; // trial lanes per search while all searches of the call still fit the chip at once (2048 wavefronts)
+        {
+            long searches = 0;
+            for (int j = 0; j < njobs; ++j) searches += jobs[j].igr == 2 ? (long)B * jobs[j].K : 0;
+            while (J2 > 1 && searches * J2 > 2048L * 64) J2 >>= 1;
+        }
+        size_t off[BH_MAX_TARGETS + 1] = {0};
+        int n = 0;
+        for (int j = 0; j < njobs; ++j)
+            if (jobs[j].igr == 2) {
+                off[n + 1] = off[n] + bh_swd_nev_high_doubles(B * jobs[j].K, J2);
+                ++n;
+            }
+        int rc2 = ensure(e, e->nevhi2, off[n] * sizeof(double));
+        if (rc2) return rc2;
+        n = 0;
+        for (int j = 0; j < njobs; ++j) {
+            const SwdJob &J = jobs[j];
+            if (J.igr != 2) continue;
+            SwdKernelArgs a{};
+            a.B = B * J.K; a.Bm = B; a.second = 1; a.first = J.first;
+            a.Lmax = Lmax; a.K = J.K; a.igr = 1; a.mode = 1; a.perm = nullptr;
+            a.nlay = m.nlay; a.h = m.h; a.vp = m.vp; a.vs = m.vs; a.rho = m.rho; a.sl = sl; a.sb = sb;
+            if (J.flsph == 1) {
+                a.h = sh; a.vp = svp; a.vs = svs; a.rho = (J.iwave == BH_WAVE_LOVE) ? srl : srr;
+                a.sl = B; a.sb = 1;
+            }
+            a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
+            a.look = J2;
+            const long waves = ((long)a.B * J2 + 63) / 64;
+            a.fair = waves <= 1024 ? -1 : (waves <= 2048 ? 18 : 12);
+            a.nev_high = (double *)e->nevhi2.p + off[n++];
+            a.fast = 0; a.farith = 0; a.counted = e->swd_scan;
+            bh_launch_swd(a, J.iwave, st);
+        }
+        HIPCHK(e, hipGetLastError());
+        return BH_OK;
+    };
     // processing order: deepest models first, wavefronts of (nearly) one depth
     const int32_t *perm = nullptr, *split = nullptr;
     int Lcut = Lmax;
@@ -574,6 +651,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
                 a.sl = B; a.sb = 1;
             }
             a.periods = J.periods_dev; a.vel = J.vel; a.ldv = J.ldv; a.err = J.err; a.neval = counter;
+            a.first = J.first;
             a.look = look[nth] > 1 ? look[nth] : 1;
             // priority time slice (log2 cycles) of wavefronts that share a SIMD, see swd_kernel; wavefronts with a SIMD of
             // their own are left alone (a low-priority phase costs them 8 %: the CU's front end is shared)
@@ -599,6 +677,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
         }
         HIPCHK(e, hipGetLastError());
         if (any_fast && (rc = launch_swd_rerun(e, st, ra, gcounts, glists))) return rc;
+        if (nsplit > 0 && (rc = second_roots())) return rc;
         ev_end(e, 0, st);
         return BH_OK;
     }
@@ -627,6 +706,7 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             t.sl = B; t.sb = 1;
         }
         t.periods = J.periods_dev; t.vel = J.vel; t.err = J.err;
+        t.first = J.first;
     }
     // which targets take the short refinement: phase velocities; with BH_SEARCH_FAST_RAYLEIGH only the Rayleigh ones
     auto takes_fast = [&](const SwdTarget &t) {
@@ -701,6 +781,10 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
     }
     if (e->started) e->started_expected += e->last_swd.workgroups;
     if (a.fast && !e->last_swd.restarts_in_place && (rc = launch_swd_rerun(e, st, a, gcounts, glists))) {
+        ev_end(e, 0, st);
+        return rc;
+    }
+    if (nsplit > 0 && (rc = second_roots())) {
         ev_end(e, 0, st);
         return rc;
     }
@@ -961,7 +1045,7 @@ void bh_engine_destroy(bh_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->nlay, &e->h, &e->vp, &e->vs, &e->rho, &e->qp, &e->qs, &e->periods, &e->vel,
                       &e->errb, &e->rf, &e->coef, &e->ymod, &e->noise, &e->logL, &e->misfits,
-                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard, &e->rfz})
+                      &e->err_t, &e->probe_in, &e->probe_out, &e->counter, &e->sph, &e->perm, &e->board, &e->nevhi, &e->guard, &e->rfz, &e->gfirst, &e->nevhi2})
         release(*b);
     for (auto &t : e->targets) {
         release_target(t);

@@ -39,6 +39,7 @@
     X(swd_lean_l,        "BH_SWD_LEAN_L",         0, "trial-per-lane kernel: trials per round of Love targets (0 = planned)")                         \
     X(swd_lean_xcd,      "BH_SWD_LEAN_XCD",       1, "trial-per-lane kernel: 1 = the models ordered inside eight blocks of the batch, a block per XCD (0: one order for the chip)") \
     X(swd_rerun_wgs,     "BH_SWD_RERUN_WGS",    256, "workgroups per target of the re-run launch of guarded models, striding over the list (0 = one wavefront per model of the batch, as before round 6)") \
+    X(swd_gsplit,        "BH_SWD_GSPLIT",  16777216, "group velocities (fundamental mode): calls of up to this many (model, period) pairs per target -- 2^24, the most the launch indexes -- run the chain of first roots and the second roots as two launches (0 = one search after the other in one launch)") \
     X(swd_lean_flip,     "BH_SWD_LEAN_FLIP",    256, "trial-per-lane kernel, two targets: 256 = the second target takes the models in the opposite order (0: the same order); + n: the targets of a wavefront pair swap with bit n-1 of the workgroup index") \
     X(no_order,          "BH_NO_ORDER",           0, "flag: models processed in the caller's order")                                                 \
     X(no_overlap,        "BH_NO_OVERLAP",         0, "flag: receiver function after the dispersion kernel, not beside it")                           \

@@ -561,7 +561,15 @@ struct SearchT {
     enum : unsigned { F_CNT_ON = 1u, F_CNT_OK = 2u, F_JUMP_READY = 4u, F_GUARD_ON = 8u, F_GUARD = 16u, F_FLO_NEG = 32u,
                       F_SEED3 = 64u,   // Rayleigh, short refinement: the scan's last replaced point seeds the first estimate
                       F_SEEDED = 128u, // this bracket's refinement started with a third point
-                      F_FA = 512u      // the values come from the fast arithmetic (swd_fa.h): values that are not numbers (below fa::SIGN_FLOOR) fire the guard
+                      F_FA = 512u,     // the values come from the fast arithmetic (swd_fa.h): values that are not numbers (below fa::SIGN_FLOOR) fire the guard
+                      // A group velocity's two chains of roots (igr = 2 / enter_second below): the root at t/(1+h) of period k + 1 starts
+                      // from the root at t/(1+h) of period k (:262-266), the root at t/(1-h) from the root at t/(1+h) of its own period
+                      // (:282-287) -- and nothing starts from it.  The first roots are a chain of K dependent searches, the second
+                      // roots K independent ones: a launch of the first chain (F_CHAIN_A: the periods t/(1+h), every root stored
+                      // unrounded in the output row), then a launch of one search per (model, period) (F_ONE) that reads the first
+                      // root there and puts the group velocity in its place.  Same searches, same values, same bits as one after the
+                      // other; the chain of dependent roots is half as long (not compiled into the builds without group velocities).
+                      F_CHAIN_A = 1024u, F_ONE = 2048u
     };
     // (F_GUARD_ON doubles as "this search takes the short refinement": in a build with both sequences (FASTM = 1) a phase-velocity
     //  target can be told to keep the reference's -- init(.., refseq) --, e.g. the Love targets under BH_SEARCH_FAST_RAYLEIGH)
@@ -637,7 +645,7 @@ struct SearchT {
     {
         const float h32 = 0.005f;
         double tt = per[kk];
-        if (group) {
+        if (group || (!NOGROUP && has(F_CHAIN_A))) {
             t1a = (float)(tt / (double)(1.0f + h32));
             t1b = (float)(tt / (double)(1.0f - h32));
             tt = (double)t1a;
@@ -684,7 +692,9 @@ struct SearchT {
         const double cc = (double)cc1;
         cm = cc;
         betmxd = (double)betmx;
-        group = !NOGROUP && igr > 0;
+        group = !NOGROUP && igr == 1;
+        put(F_CHAIN_A, !NOGROUP && igr == 2);
+        flg &= ~F_ONE;
         K = K_;
         per = per_;
         xl = xl_;
@@ -720,7 +730,7 @@ struct SearchT {
         flg &= ~(F_CNT_OK | F_JUMP_READY);
         iprev = iprevb = 0;
         vlim = fmin(md.Bv(mmax - 1), betmxd);
-        put(F_GUARD_ON, FAST && (PHASE_ONLY || (!group && !refseq)));
+        put(F_GUARD_ON, FAST && (PHASE_ONLY || (!group && !has(F_CHAIN_A) && !refseq)));
         // Rayleigh only: a Love scan may be the counted one, whose visited points differ -- the result must not depend on the scan mode
         put(F_SEED3, FAST && ifunc == 2 && has(F_GUARD_ON));
         flg &= ~F_GUARD;
@@ -730,6 +740,34 @@ struct SearchT {
         if (active) set_period(0);
         ceval = c1;
         if (counted) plan_first_jump();
+    }
+
+    // The second root of the group velocity of period kk alone (:282-287), after init() with igr = 1 and mode 1: the first root is
+    // read from the output row (a launch with igr = 2 put it there; 0 = that chain ended before period kk: nothing to do),
+    // d1st = the value getsol keeps from the first search of the mode (`del1st`, :420: only its sign is used, :425-435).
+    template <bool CNT = true>
+    __device__ __forceinline__ void enter_second(int kk, double d1st)
+    {
+        if (NOGROUP || !active) return;
+        const double ca = vel[kk];
+        if (!(ca > 0.0)) {
+            active = false;
+            return;
+        }
+        flg |= F_ONE;
+        k = kk;
+        set_period(kk);
+        ck = ca;
+        root = 1;
+        t1 = (double)t1b;
+        omega = twopi / t1;
+        ifirst = 0;
+        del1st = d1st;
+        clow = 0.0 + one * dc;
+        c1 = ca - onea * dc;
+        st = ST_FIRST;
+        ceval = c1;
+        if (CNT) plan_first_jump();
     }
 
     // The grid point `want` steps above `from` by the reference's repeated additions, stopping below vlim.
@@ -1273,7 +1311,9 @@ struct SearchT {
             if (period_done) {
                 const float cc0 = (float)ck;
                 double out;
-                if (!group) {
+                if (!NOGROUP && has(F_CHAIN_A)) {
+                    out = ck; // (unrounded: the launch of the second roots starts from it)
+                } else if (!group) {
                     out = (double)cc0;
                 } else { // all binary32 (:305)
                     const float cc1s = (float)c1b;
@@ -1282,8 +1322,12 @@ struct SearchT {
                     out = (double)gvel;
                 }
                 if (writer) vel[k] = out;
-                k = k + 1;
-                next_search<CNT>();
+                if (!NOGROUP && has(F_ONE)) {
+                    active = false;
+                } else {
+                    k = k + 1;
+                    next_search<CNT>();
+                }
             }
             todo = 0;
         }

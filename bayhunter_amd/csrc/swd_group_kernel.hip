@@ -781,6 +781,7 @@ restart_with_the_reference_sequence:
     if (board != nullptr) *reinterpret_cast<volatile unsigned *>(board + hw_slot) = (A.stamp << 16) | 0xffffu;
     if (valid && li == 0 && rr == 0 && !spare) {
         T.err[ib] = S.errflag;
+        if (!SIMPLE && T.igr == 2 && T.first != nullptr) T.first[ib] = S.del1st; // (the chain of a group velocity's first roots: SwdKernelArgs)
         if (FAST && S.has(S.F_GUARD) && T.gcount != nullptr) { // to be run again with the reference's sequence
             T.glist[atomicAdd(T.gcount, 1)] = ib;
             atomicAdd(T.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)

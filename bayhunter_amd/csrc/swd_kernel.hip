@@ -88,7 +88,10 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
     const int lbase = lane - r;           // first lane of the model
     const int sidx = (wid * BH_WAVE + lane) / J; // position in the processing order
     const bool valid = sidx < A.B;
-    const int ib = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
+    const int iv = valid ? (A.perm ? A.perm[sidx] : sidx) : 0;
+    // (a launch of second roots, SwdKernelArgs::second: entry iv = period iv / Bm of model iv % Bm -- neighbouring lanes, neighbouring models)
+    const bool second = !SIMPLE && FAST == 0 && A.second != 0;
+    const int ib = second ? iv % A.Bm : iv;
     const int Lmax = A.Lmax;
     const int K = A.K;
 
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
         double *hx = A.nev_high + (size_t)wid * BH_WAVE + lane;
         S.set_high(hx, hx + (size_t)(NEV_MAX - NEV_LO) * nl, nl);
     }
+    if (second) S.template enter_second<IFUNC == 1>(iv / A.Bm, A.first[ib]);
 
     // Two wavefronts share a SIMD (one of each target when the targets of a call run side by side); at equal
     // priority the hardware serves the OLDER one first and a Rayleigh / Love pair takes as long as the two in
@@ -195,7 +199,8 @@ __global__ __launch_bounds__(BH_WAVE * LANE_WPB) void swd_kernel(SwdKernelArgs A
         }
     }
     if (valid && r == 0) {
-        A.err[ib] = S.errflag;
+        if (!second) A.err[ib] = S.errflag;
+        if (!SIMPLE && FAST == 0 && A.igr == 2 && A.first != nullptr) A.first[ib] = S.del1st;
         if (FAST != 0 && S.has(S.F_GUARD) && A.gcount != nullptr) { // to be run again with the reference's sequence
             A.glist[atomicAdd(A.gcount, 1)] = ib;
             atomicAdd(A.gcount + 2 * BH_MAX_TARGETS, 1); // (cumulative, for bh_engine_guard_stats)

@@ -330,3 +330,24 @@ def test_experiment_switches_are_a_table_with_an_api(engine):
         finally:
             engine.set_tuning(name, 0)
         assert np.array_equal(v0, v1) and np.array_equal(e0, e1), name
+
+
+@pytest.mark.parametrize("iwave", [1, 2])
+def test_group_velocity_chains_as_two_launches_return_the_same_bits(engine, oracle, iwave):
+    """Fundamental-mode group velocities run as the chain of the first roots (t/(1+h)), then one independent search per (model,
+    period) for the second roots (t/(1-h), surfdisp96.f:282-287) -- bh_engine.hip launch_swd_jobs; bh_tuning.h swd_gsplit = 0
+    keeps the single launch.  Both ways, every batch shape, flattened or not: the oracle's bits."""
+    rs = np.random.RandomState(77 + iwave)
+    assert engine.tuning("swd_gsplit") == 1 << 24
+    try:
+        for B, L, K, flsph in ((1, 6, 30, 0), (7, 12, 5, 1), (300, 21, 30, 0), (2600, 9, 21, 0), (9000, 10, 30, 0)):
+            nlay, h, vp, vs, rho = synth_models(rs, B, L, lvz_frac=0.3, ragged=True)
+            per = np.sort(rs.uniform(1.5, 70.0, K))
+            ov, oe, _ = oracle.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, 1, flsph=flsph)
+            for cap in (0, 1 << 24):
+                engine.set_tuning("swd_gsplit", cap)
+                v, e = engine.swd_batch(nlay, h, vp, vs, rho, per, iwave, 1, flsph=flsph)
+                assert np.array_equal(e, oe), (B, cap)
+                assert np.array_equal(v, ov), (B, cap)
+    finally:
+        engine.set_tuning("swd_gsplit", 1 << 24)
