@@ -531,6 +531,12 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             }
         int rc2 = ensure(e, e->nevhi2, off[n] * sizeof(double));
         if (rc2) return rc2;
+        // (as with the one-lane-per-model launches below: every second target on a second stream, side by side)
+        const bool fork = n > 1 && e->aux2 != nullptr;
+        if (fork) {
+            HIPCHK(e, hipEventRecord(e->ev_fork2, st));
+            HIPCHK(e, hipStreamWaitEvent(e->aux2, e->ev_fork2, 0));
+        }
         n = 0;
         for (int j = 0; j < njobs; ++j) {
             const SwdJob &J = jobs[j];
@@ -547,9 +553,14 @@ int launch_swd_jobs(bh_engine *e, hipStream_t st, int B, int Lmax, const Staged 
             a.look = J2;
             const long waves = ((long)a.B * J2 + 63) / 64;
             a.fair = waves <= 1024 ? -1 : (waves <= 2048 ? 18 : 12);
-            a.nev_high = (double *)e->nevhi2.p + off[n++];
+            a.nev_high = (double *)e->nevhi2.p + off[n];
             a.fast = 0; a.farith = 0; a.counted = e->swd_scan;
-            bh_launch_swd(a, J.iwave, st);
+            bh_launch_swd(a, J.iwave, (fork && (n & 1)) ? e->aux2 : st);
+            ++n;
+        }
+        if (fork) {
+            HIPCHK(e, hipEventRecord(e->ev_join2, e->aux2));
+            HIPCHK(e, hipStreamWaitEvent(st, e->ev_join2, 0));
         }
         HIPCHK(e, hipGetLastError());
         return BH_OK;

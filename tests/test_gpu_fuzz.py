@@ -76,9 +76,11 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
         both = (v != 0) & (rv != 0)
         rel = np.zeros_like(v)
         rel[both] = np.abs(v[both] - rv[both]) / np.abs(rv[both])
-        # a model on ANOTHER ROOT than the reference's (the known exception, below): beyond north_star's tolerance, or -- further along
-        # the other mode's branch -- with another failure flag / zero row
-        far = (rel.max(axis=1) > 1e-5) | (e != re_) | ((v == 0) != (rv == 0)).any(axis=1) if B else np.zeros(0, bool)
+        # a model on ANOTHER ROOT than the reference's (the known exception, below): further from the reference's value than two
+        # end points of one root's brackets can be (2.3e-6, below) -- whether by 7e-6 (three sign changes within 2e-5 of a half-space
+        # velocity: seed 3790146708) or by a third of the velocity --, or, further along the other mode's branch, with another
+        # failure flag / zero row
+        far = (rel.max(axis=1) > 2.5e-6) | (e != re_) | ((v == 0) != (rv == 0)).any(axis=1) if B else np.zeros(0, bool)
         jumps += [(prior, B, L, K, iwave, flsph, int(b), float(rel[b].max()), int(e[b]), int(re_[b])) for b in np.where(far)[0]]
         if (~far).any():
             worst = max(worst, float(rel[~far].max()))
@@ -89,7 +91,7 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
     assert nlean > 0
     # north_star: 1e-5.  The fixed sets of test_gpu_swd_lean.py are held to 2e-6 (seen there: 1.4e-6); the bound is 2.3e-6 --
     # the root lies inside this path's final bracket (<= 1.3e-6 c wide) and inside the reference's (1e-6 c), either returns a point
-    # of its own -- and fresh models have come to 1.95e-6: asserted here with that bound's margin
+    # of its own -- and fresh models have come to 1.95e-6.  A model beyond 2.5e-6 is therefore on another root: counted below.
     assert worst <= 2.5e-6, "seed %d: %.3g" % (seed, worst)
     # Failure flags and zero rows: the reference's -- with the known exception: a root within ~1e-6 c of a scan grid
     # point with a second root less than a step away (two modes that nearly touch, a channel mode's pole-zero pair), or two roots
