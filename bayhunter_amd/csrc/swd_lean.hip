@@ -116,7 +116,8 @@ enum : int {
     PH_PROBE_ACC = 5,  // the guard's probes outside an accepted bracket (ST_GH / ST_GL)
     PH_SPECIAL = 6,    // a bracket that contains betmx or a half-space velocity: the sign changes BELOW that velocity (see the kernel)
     PH_PROBE_START = 7, // the guard's probes next to a start value that lies next to a root
-    PH_SPECIAL_B = 8   // ... and those above it
+    PH_SPECIAL_B = 8,  // ... and those above it
+    PH_SPECIAL_C = 9   // ... and, where the cell holds ONE, a look inside the guard's distance of that velocity
 };
 
 __device__ __forceinline__ bool sign_neg(double x) { return __double_as_longlong(x) < 0; }
@@ -385,6 +386,12 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
             const float lg = log2f((float)(((up ? cell_hi - sp : sp - cell_lo)) / g)) * (1.0f / (float)(J - 1));
             const double dist = g * (double)exp2f(lg * (float)(r - 1));
             cev = (r == 0) ? (up ? sp + g : sp - g) : ((r == 1) ? sp + g : (up ? sp + dist : sp - dist));
+        } else if (J >= 32 && ph == PH_SPECIAL_C) {
+            // J points inside s (1 -+ 3e-6), J / 2 on either side of s, their distances from s in geometric progression from 1e-8 s
+            // (ratio 300^(2/J): 1.43 with 32 lanes)
+            const double sp = special_in_cell(cell_lo, cell_hi);
+            const double dist = (1.0e-8 * sp) * (double)exp2f((8.2288187f / (float)(J / 2)) * (float)(r >> 1));
+            cev = (r & 1) ? sp + dist : sp - dist;
         } else if (ph == PH_PROBE_START) {
             cev = (r == 0) ? c1 - guard_rel * c1 : ((r == 1) ? c1 + guard_rel * c1 : c1);
         } else if (ph == PH_PROBE_STEP) {
@@ -410,7 +417,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         int ev = 0; // 1 floor of a reversed search reached, 2 sign change, 3 step needs the guard's probes, 4 out of bounds
         // (NOT guarded: a root within ~1e-6 c of a grid point with a second root less than a step away -- the cell that holds both
         // shows no sign change, so one grid sees a bracket where the reference's, 1e-6 c beside it, walks past the pair to another
-        // mode, or the other way round -- and root pairs closer together than the guard's 3e-6 next to a half-space velocity: 7 models
+        // mode, or the other way round -- and, in a cell with a half-space velocity, two sign changes closer to each other than the
+        // count's points resolve (PH_SPECIAL: a distance ratio of <= 1.23; pairs INSIDE the guard's 3e-6 are looked for: PH_SPECIAL_C): 7 models
         // in 9.2 million drawn from a sampler's prior, three of them with another failure flag further along the other branch
         // (profiles/r06_fuzz_prior_final.txt).  Two forms of a rule for the first were built in round 6 and dropped:
         // "|f| two orders of magnitude below both neighbours'" also fired on a near-tangency of one of the bench's 16 384 models
@@ -463,6 +471,29 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         // on models drawn from a sampler's prior, one in 10^4 then came back with another root of the cell than the reference's,
         // up to 1.5e-3 away.)
         bool special_now = false;
+        // Third round, for a cell whose one sign change is about to be refined (or to fail the period): J points INSIDE the guard's
+        // distance of s.  The two points s (1 -+ 3e-6) showed the same sign, so between them lies no sign change or a PAIR -- a root
+        // 4e-7 below a half-space velocity with its image 9e-7 above: with a third sign change 6.5e-6 above, the cell counted one,
+        // this search refined it and the reference's nevill ended at the first, 6.9e-6 away (the suite's fuzz, seed 3790146708;
+        // docs/HISTORY.md).  Any other sign in there than the two points': the guard.
+        if (J >= 32 && __ballot(active && ph == PH_SPECIAL_C) != 0ull) {
+            if (active && ph == PH_SPECIAL_C) {
+                special_now = true;
+                evals += (unsigned)J;
+                if (m_small != 0ull || mneg != (pp_neg ? maskJ : 0ull)) {
+                    LEAN_GUARD(6);
+                } else if (sp_nb != 0) { // (the cell's one sign change lies above betmx: getsol's "c1 > betmx", :470)
+                    todo = 2;
+                } else {
+                    // (the section is a few per cent of the cell wide and holds one sign change: a cluster around the secant
+                    // point closes in on it; if not, the next round is a J-section of the section)
+                    have3 = false;
+                    nref = 0;
+                    wprev = hi - lo;
+                    ph = PH_REFC;
+                }
+            }
+        }
         if (J >= 32 && __ballot(active && (ph == PH_SPECIAL || ph == PH_SPECIAL_B)) != 0ull) {
             // Signs in the order of the distance from s.  Element 0 = the point next to s (lane 0: s - g below, lane 1: s + g above),
             // elements 1 .. J - 2 = lanes 2 .. J - 1, element J - 1 = the cell's end on that side (sign of cell_lo: flo_neg; the other
@@ -501,9 +532,8 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                     if (sp_nb + nch != 1) {
                         if (is_betmx && sp_nb == 0 && nch > 0) todo = 2; // (unreachable with nch <= 1; kept for the rule's sake)
                         else LEAN_GUARD(6);
-                    } else if (nch == 1 && is_betmx) { // the cell's one sign change lies above betmx: getsol's "c1 > betmx" (:470)
-                        todo = 2;
                     } else {
+                        sp_nb = (nch == 1 && is_betmx) ? 1 : 0; // (from here on: the cell's one sign change lies above betmx -- the period fails)
                         if (nch == 1) { // [near, far]
                             lo = c_near;
                             flo = d_near;
@@ -512,12 +542,7 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
                                 fhi = d_far;
                             }
                         }
-                        // (the section is a few per cent of the cell wide and holds one sign change: a cluster around the secant
-                        // point closes in on it; if not, the next round is a J-section of the section)
-                        have3 = false;
-                        nref = 0;
-                        wprev = hi - lo;
-                        ph = PH_REFC;
+                        ph = PH_SPECIAL_C; // (a look inside the guard's distance of s first)
                     }
                 }
             }

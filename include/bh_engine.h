@@ -87,8 +87,9 @@ const char *bh_engine_last_error(const bh_engine *e);
  *                        velocity or betmx can hold a root, its mirror image and more), is detected and run again with the
  *                        reference's sequence inside the same call; bh_engine_guard_stats counts them.  (Known exception,
  *                        fewer than one in a million models drawn from a sampler's prior, none seen on models with sorted
- *                        velocities: a root within ~1e-6 c of a scan grid point with a second root less than a step away, or two
- *                        roots within 2e-6 of a half-space velocity -- the scan can end on another mode than the reference's,
+ *                        velocities: a root within ~1e-6 c of a scan grid point with a second root less than a step away, or
+ *                        two sign changes of a cell with a half-space velocity closer to each other than the count's points
+ *                        (a distance ratio of 1.23 from that velocity) -- the scan can end on another mode than the reference's,
  *                        and fail where it does not or the other way round further along that branch.  DESIGN.md 4.)  NOT the reference's
  *                        bits.  WHAT A RESULT DEPENDS ON: the model, and -- in its last digits, ~1e-9 relative, up to the
  *                        reference's own 1e-6 where the guard fires under one setting and not under another -- the kernel that

@@ -94,8 +94,8 @@ def test_default_path_against_the_reference_sequence_on_fresh_models(engine, ora
     # of its own -- and fresh models have come to 1.95e-6.  A model beyond 2.5e-6 is therefore on another root: counted below.
     assert worst <= 2.5e-6, "seed %d: %.3g" % (seed, worst)
     # Failure flags and zero rows: the reference's -- with the known exception: a root within ~1e-6 c of a scan grid
-    # point with a second root less than a step away (two modes that nearly touch, a channel mode's pole-zero pair), or two roots
-    # within 2e-6 of a half-space velocity: the cell that holds both shows no sign change, so this grid sees a bracket where the
+    # point with a second root less than a step away (two modes that nearly touch, a channel mode's pole-zero pair): the cell that
+    # holds both shows no sign change, so this grid sees a bracket where the
     # reference's -- 1e-6 c beside it -- walks past to another mode, or the other way round.  Measured on 9.2 million models drawn
     # from a sampler's prior (profiles/r06_fuzz_prior_final.txt): fewer than one in a million.  More than ONE such model among the
     # ~100 000 prior-like ones of this test is a bug; on the sorted-velocity models none has ever been seen.

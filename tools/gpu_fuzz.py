@@ -55,7 +55,8 @@ for it in range(ncfg):
     hint = int(rs.choice([0, 0, 3, 6, 12]))
     if LEAN:
         G = J = 0
-        eng.set_swd_trials(int(rs.choice([0, 0, 0, 4, 8, 16, 32, 64])))   # trials per round: by the call's shape, or pinned
+        trials_set = int(rs.choice([0, 0, 0, 4, 8, 16, 32, 64]))          # trials per round: by the call's shape, or pinned
+        eng.set_swd_trials(trials_set)
     eng.set_swd_group(G); eng.set_swd_lookahead(J); eng.set_typical_layers(hint)
     with O.swd_search(2 if FAST else 0):
         ov, oe, _ = O.swd_batch(nlay, h.T, vp.T, vs.T, rho.T, per, iwave, igr, mode=mode, flsph=flsph)
@@ -91,7 +92,8 @@ for it in range(ncfg):
             for b_ in badm[:2]:
                 os.makedirs(os.environ["BH_FUZZ_DUMP"], exist_ok=True)
                 np.savez(os.path.join(os.environ["BH_FUZZ_DUMP"], "bad_%d_%d.npz" % (it, b_)), nlay=nlay[b_], h=h[:, b_], vp=vp[:, b_], vs=vs[:, b_], rho=rho[:, b_],
-                         per=per, iwave=iwave, flsph=flsph, lean=v[b_], ref=rv[b_], elean=e[b_], eref=re_[b_], k=int(np.argmax(rel[b_])))
+                         per=per, iwave=iwave, flsph=flsph, lean=v[b_], ref=rv[b_], elean=e[b_], eref=re_[b_], k=int(np.argmax(rel[b_])),
+                         B=B, Lmax=L, trials=(trials_set if LEAN else -1))   # (B, Lmax, trials: the call's shape decides the trials per round)
                 nbad_dumped += 1
         flagdiff += int((e != re_).sum())
         zerodiff += int(((v == 0) != (rv == 0)).any(axis=1).sum())
