@@ -463,8 +463,9 @@ __global__ __launch_bounds__(BH_WAVE * LEAN_WPB) void swd_lean_kernel(SwdMultiAr
         // next to the special velocity s and J - 2 points between s and the cell's lower end, then J - 2 between s and its upper
         // end, their distances from s in geometric progression (ratio <= 1.23 with 32 lanes per model: the sign changes of such
         // a cell crowd towards s).  With fewer than 32 lanes per model the cell is guarded at once.
-        //   * one sign change in the whole cell: the refinement goes on in its section (s = betmx and the sign change above it: the
-        //     period fails as the reference's does -- nevill ends within 1e-6 c of a sign change above betmx (1 + 3e-6));
+        //   * one sign change in the whole cell: a third round looks inside s (1 -+ 3e-6) (PH_SPECIAL_C below), then the refinement
+        //     goes on in the sign change's section (s = betmx and the sign change above it: the period fails as the reference's
+        //     does -- nevill ends within 1e-6 c of a sign change above betmx (1 + 3e-6));
         //   * anything else -- several sign changes, one between the two points next to s, a value that is no number -- the guard.
         // (Before this rule a cell with betmx inside was always guarded -- 99 % of the guarded models of LVZ-rich batches,
         // profiles/r05_lean_guard.txt -- and a cell with a half-space velocity below betmx inside was refined like any other:
