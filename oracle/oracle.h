@@ -47,6 +47,9 @@ int64_t bho_swd_guarded_count(int reset);
  * visited; swd_oracle.c, bracket_and_refine): the same brackets and bits with fewer evaluations, restated here so that the
  * device's evaluation counts can be checked and the certificate itself tested against mode 0 on the CPU. */
 void bho_swd_set_scan(int counted);
+/* 1: fundamental-mode group velocities as the device runs them -- the chain of the first roots, then the second roots on their own
+ * (swd_oracle.c, g_group_split): a different ORDER of the reference's searches, checked against the reference's on the CPU. */
+void bho_swd_set_group_split(int on);
 void bho_swd_set_scan_tuning(int first, int next, int back);
 double bho_dltar1_count(double wvno, double omega, const float *d, const float *b, const float *rho,
                         int mmax, int llw, int *count, int *valid);

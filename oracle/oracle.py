@@ -49,6 +49,8 @@ def lib():
         L.bho_swd_set_search.argtypes = [C.c_int]
         L.bho_swd_set_scan.restype = None
         L.bho_swd_set_scan.argtypes = [C.c_int]
+        L.bho_swd_set_group_split.restype = None
+        L.bho_swd_set_group_split.argtypes = [C.c_int]
         L.bho_swd_set_scan_tuning.restype = None
         L.bho_swd_set_scan_tuning.argtypes = [C.c_int, C.c_int, C.c_int]
         L.bho_secular_vec.restype = None
@@ -121,6 +123,18 @@ class swd_scan:
 
     def __exit__(self, *a):
         lib().bho_swd_set_scan(0)
+
+
+class swd_group_split:
+    """with swd_group_split(): fundamental-mode group velocities in the order the device runs them -- the chain of
+    the first roots (t/(1+h)) over all periods, then the second roots (t/(1-h)) one by one, last period first -- instead of the
+    reference's first / second / first / second ...: the same bits (tests/test_oracle_swd.py)"""
+
+    def __enter__(self):
+        lib().bho_swd_set_group_split(1)
+
+    def __exit__(self, *a):
+        lib().bho_swd_set_group_split(0)
 
 
 def secular_vec(ifunc, omega, c, d, a, b, rho):

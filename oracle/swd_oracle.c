@@ -498,6 +498,12 @@ static int g_scan_mode = 0;
 void bho_swd_set_scan(int counted) { g_scan_mode = counted ? 1 : 0; }
 static int g_stride_first = 16, g_stride_next = 4, g_stride_back = -1, g_stride_secant = 1; /* (tuning experiments) */
 void bho_swd_set_scan_tuning(int first, int next, int back) { g_stride_first = first; g_stride_next = next % 100; g_stride_back = back; g_stride_secant = next < 100; }
+/* Group velocities of the fundamental mode as the device runs them (bh_engine.hip launch_swd_jobs): first the chain
+ * of the roots at t/(1+h) over all periods, then -- each on its own, in any order -- the roots at t/(1-h), which start from the
+ * first root of their own period (:282-287) and from nothing else.  The same calls with the same arguments as one after the
+ * other: tests/test_oracle_swd.py checks the bits against the reference's order (and, in this container, the compiled reference). */
+static int g_group_split = 0;
+void bho_swd_set_group_split(int on) { g_group_split = on ? 1 : 0; }
 static int64_t g_guarded = 0; /* models the guard sent back to the reference sequence (statistics) */
 int64_t bho_swd_guarded_count(int reset)
 {
@@ -982,6 +988,10 @@ static int surfdisp96_run(const float *thkm, const float *vpm, const float *vsm,
                 break;
             }
             c[k - 1] = c1;
+            if (igr > 0 && g_group_split && mode == 1) { /* (the second roots follow the chain of the first ones, below) */
+                cg[k - 1] = 0.0;
+                continue;
+            }
             if (igr > 0) { /* second root at the slightly longer period */
                 t1 = (double)t1b;
                 clow = cb[k - 1] + one * dc;
@@ -1005,6 +1015,20 @@ static int surfdisp96_run(const float *thkm, const float *vpm, const float *vsm,
             if (iq == 1) err = 1;
             ift = k;
             for (int i = k; i <= kmax; ++i) cg[i - 1] = 0.0;
+        }
+        if (igr > 0 && g_group_split && mode == 1) {
+            /* the second roots of the periods the chain reached, LAST period first (any order will do: nothing carries over
+               from one to the next but the counted scan's stride, which starts anew -- same bracket, other evaluation count) */
+            const int reached = failed ? k - 1 : kmax;
+            for (int kk = reached; kk >= 1; --kk) {
+                const float t1a = (float)(t[kk - 1] / (double)(1.0f + h)), t1b = (float)(t[kk - 1] / (double)(1.0f - h));
+                scan_t sc3 = {g_scan_mode, 0};
+                double c2nd = c[kk - 1] - onea * dc;
+                const int iret = bracket_and_refine(&md, (double)t1b, &c2nd, 0.0 + one * dc, dc, cm, (double)betmx, 0, &del1st, 0, NULL, &sc3);
+                if (iret == -1) c2nd = c[kk - 1];
+                const float cc0 = (float)c[kk - 1], cc1s = (float)c2nd;
+                cg[kk - 1] = (double)((1.0f / t1a - 1.0f / t1b) / (1.0f / (t1a * cc0) - 1.0f / (t1b * cc1s)));
+            }
         }
     }
     return err;

@@ -230,3 +230,40 @@ def test_guarded_short_refinement_returns_the_reference_failure_flags(oracle):
         assert 0 < nguard < 0.3 * B or iwave == 2 or mode > 1
         assert ng < nref or iwave == 1 or mode > 1
     assert nraw > 10   # the unguarded sequence does differ on these sets
+
+
+def test_group_velocity_roots_in_the_device_order_are_the_reference_bits(oracle):
+    """The device runs a fundamental-mode group velocity as the chain of its first roots (t/(1+h)) and then the second roots (t/(1-h))
+    as independent searches (bh_engine.hip launch_swd_jobs): the second root of a period starts from the first root of
+    the same period and from nothing else (surfdisp96.f:282-287).  The oracle in that order (last period first) against the
+    reference's order: the same bits and flags -- golden models (with the models surf96 fails on), sorted velocities with a
+    low-velocity zone, models drawn from a sampler's prior, flat and flattened, with and without the counted Love scan; and
+    against the compiled reference where it is built."""
+    from bayhunter_amd.synth import synth_models, prior_models
+    from oracle import refshim
+    g = golden("swd_golden.npz")
+    sets = [(g["nlay"], g["h"], g["vp"], g["vs"], g["rho"], g["x_p30"])]
+    rs = np.random.RandomState(314)
+    for gen in (lambda: synth_models(rs, 150, 12, lvz_frac=0.4, ragged=True), lambda: prior_models(rs, 150, 21)):
+        nlay, h, vp, vs, rho = gen()
+        sets.append((nlay, h.T, vp.T, vs.T, rho.T, np.sort(rs.uniform(1.0, 70.0, 24))))
+    nfail = 0
+    for nlay, h, vp, vs, rho, per in sets:
+        for iwave in (1, 2):
+            for flsph in (0, 1):
+                for counted in (0, 1):
+                    with oracle.swd_scan(counted):
+                        ov, oe, _ = oracle.swd_batch(nlay, h, vp, vs, rho, per, iwave, 1, flsph=flsph)
+                        with oracle.swd_group_split():
+                            sv, se, _ = oracle.swd_batch(nlay, h, vp, vs, rho, per, iwave, 1, flsph=flsph)
+                    assert np.array_equal(se, oe) and np.array_equal(sv, ov), (iwave, flsph, counted)
+                nfail += int(oe.sum())
+    assert nfail > 0   # (models whose chain of first roots ends early are among them)
+    if refshim.available():
+        nlay, h, vp, vs, rho, per = sets[1]
+        with oracle.swd_group_split():
+            sv, se, _ = oracle.swd_batch(nlay, h, vp, vs, rho, per, 2, 1)
+        for b in range(0, nlay.size, 5):
+            n = int(nlay[b]); r = np.zeros(per.size)
+            er = refshim.surfdisp96(h[b, :n], vp[b, :n], vs[b, :n], rho[b, :n], n, 0, 2, 1, 1, per.size, per, r)
+            assert er == se[b] and np.array_equal(r, sv[b])
